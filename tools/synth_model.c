@@ -1,0 +1,239 @@
+/*
+ * tools/synth_model.c — deterministic synthetic Voxtral-Realtime checkpoint writer.
+ *
+ * There are no real weights on the build or GPU boxes (no network), so parity
+ * and benchmarks run on a seeded random-init model of the *exact* architecture:
+ * the same tensor names / shapes / BF16 dtype the reference loaders look up
+ * (voxtral_encoder.c:50-117, voxtral_decoder.c:49-108, voxtral.c:102-110;
+ * names listed in MODEL.md "Tensor Names").  Both the reference oracle and the
+ * HIP engine read the same file, so any weights work for parity; the scales
+ * (std = 1/sqrt(fan_in)) keep activations O(1) through all layers.
+ *
+ * Values are counter-based (splitmix64 of tensor-name hash + element index) so
+ * the file is bit-identical on every machine and can be generated in parallel.
+ *
+ * usage: synth_model <out_dir> <preset: full|small|tiny> [seed]
+ *   writes <out_dir>/consolidated.safetensors and <out_dir>/tekken.json
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <pthread.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+typedef struct {
+    int enc_dim, enc_layers, enc_heads, enc_head_dim, enc_hidden;
+    int dec_dim, dec_layers, dec_heads, dec_kv_heads, dec_head_dim, dec_hidden;
+    int vocab, ada_dim, mel_bins;
+} dims_t;
+
+static const dims_t PRESET_FULL  = {1280, 32, 32, 64, 5120, 3072, 26, 32, 8, 128, 9216, 131072, 32, 128};
+static const dims_t PRESET_SMALL = {1280,  2, 32, 64, 5120, 3072,  2, 32, 8, 128, 9216,   4096, 32, 128};
+static const dims_t PRESET_TINY  = { 256,  3,  4, 64,  512,  384,  3,  8, 2, 128,  768,   2048, 32, 128};
+
+typedef struct {
+    char name[200];
+    int64_t shape[3];
+    int ndim;
+    int kind;        /* 0 = matrix N(0, std), 1 = norm weight 1+N(0,.02), 2 = bias N(0,.02) */
+    float std;
+    uint64_t offset; /* byte offset in data section */
+    uint64_t numel;
+} tensor_t;
+
+static tensor_t *g_t = NULL;
+static int g_nt = 0, g_cap = 0;
+
+static void add(const char *name, int kind, float std, int ndim, int64_t a, int64_t b, int64_t c) {
+    if (g_nt == g_cap) { g_cap = g_cap ? g_cap * 2 : 1024; g_t = realloc(g_t, (size_t)g_cap * sizeof(tensor_t)); }
+    tensor_t *t = &g_t[g_nt++];
+    memset(t, 0, sizeof(*t));
+    snprintf(t->name, sizeof(t->name), "%s", name);
+    t->ndim = ndim; t->shape[0] = a; t->shape[1] = b; t->shape[2] = c;
+    t->kind = kind; t->std = std;
+    t->numel = (uint64_t)a * (ndim > 1 ? b : 1) * (ndim > 2 ? c : 1);
+}
+
+static uint64_t fnv1a(const char *s) {
+    uint64_t h = 1469598103934665603ull;
+    for (; *s; s++) { h ^= (unsigned char)*s; h *= 1099511628211ull; }
+    return h;
+}
+static inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+/* Irwin-Hall(4) approximate standard normal from one 64-bit hash. */
+static inline float approx_normal(uint64_t h) {
+    float s = (float)(h & 0xFFFF) + (float)((h >> 16) & 0xFFFF) +
+              (float)((h >> 32) & 0xFFFF) + (float)((h >> 48) & 0xFFFF);
+    s = s * (1.0f / 65536.0f) - 2.0f;   /* mean 0, var 1/3 */
+    return s * 1.7320508f;
+}
+static inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    uint32_t lsb = (u >> 16) & 1u;
+    u += 0x7FFFu + lsb;
+    return (uint16_t)(u >> 16);
+}
+
+typedef struct { uint16_t *dst; const tensor_t *t; uint64_t seed; uint64_t lo, hi; } job_t;
+
+static void *fill_job(void *arg) {
+    job_t *j = (job_t *)arg;
+    const tensor_t *t = j->t;
+    for (uint64_t i = j->lo; i < j->hi; i++) {
+        float n = approx_normal(splitmix64(j->seed + i));
+        float v = (t->kind == 1) ? 1.0f + 0.02f * n : (t->kind == 3) ? -3.0f + t->std * n : t->std * n;
+        j->dst[i] = f32_to_bf16_rne(v);
+    }
+    return NULL;
+}
+
+static void b64(const unsigned char *in, int n, char *out) {
+    static const char T[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    int o = 0;
+    for (int i = 0; i < n; i += 3) {
+        unsigned v = in[i] << 16 | (i + 1 < n ? in[i + 1] << 8 : 0) | (i + 2 < n ? in[i + 2] : 0);
+        out[o++] = T[(v >> 18) & 63]; out[o++] = T[(v >> 12) & 63];
+        out[o++] = (i + 1 < n) ? T[(v >> 6) & 63] : '=';
+        out[o++] = (i + 2 < n) ? T[v & 63] : '=';
+    }
+    out[o] = 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) { fprintf(stderr, "usage: %s <out_dir> <full|small|tiny> [seed]\n", argv[0]); return 2; }
+    const char *out_dir = argv[1];
+    dims_t d;
+    if (!strcmp(argv[2], "full")) d = PRESET_FULL;
+    else if (!strcmp(argv[2], "small")) d = PRESET_SMALL;
+    else if (!strcmp(argv[2], "tiny")) d = PRESET_TINY;
+    else { fprintf(stderr, "unknown preset %s\n", argv[2]); return 2; }
+    uint64_t seed = argc > 3 ? strtoull(argv[3], NULL, 10) : 1234;
+
+    char nm[256];
+    const char *EP = "mm_streams_embeddings.embedding_module.whisper_encoder";
+    int eq = d.enc_heads * d.enc_head_dim;
+    int dq = d.dec_heads * d.dec_head_dim, dkv = d.dec_kv_heads * d.dec_head_dim;
+#define STD(fan) (1.0f / sqrtf((float)(fan)))
+    /* tok_embeddings: logits std ~3 (realistic range); adapter output is scaled to a
+     * comparable norm below so that the previous-token feedback visibly steers the
+     * greedy sequence (a constant-token sequence would make id parity vacuous). */
+    add("mm_streams_embeddings.embedding_module.tok_embeddings.weight", 0, STD(d.dec_dim), 2, d.vocab, d.dec_dim, 0);
+    snprintf(nm, sizeof nm, "%s.conv_layers.0.conv.weight", EP); add(nm, 0, 3.0f * STD(d.mel_bins * 3), 3, d.enc_dim, d.mel_bins, 3);
+    snprintf(nm, sizeof nm, "%s.conv_layers.0.conv.bias", EP);   add(nm, 3, 0.02f, 1, d.enc_dim, 0, 0);
+    snprintf(nm, sizeof nm, "%s.conv_layers.1.conv.weight", EP); add(nm, 0, 8.0f * STD(d.enc_dim * 3), 3, d.enc_dim, d.enc_dim, 3);
+    snprintf(nm, sizeof nm, "%s.conv_layers.1.conv.bias", EP);   add(nm, 3, 0.02f, 1, d.enc_dim, 0, 0);
+    for (int i = 0; i < d.enc_layers; i++) {
+#define EN(sfx) snprintf(nm, sizeof nm, "%s.transformer.layers.%d." sfx, EP, i)
+        EN("attention.wq.weight"); add(nm, 0, STD(d.enc_dim), 2, eq, d.enc_dim, 0);
+        EN("attention.wq.bias");   add(nm, 2, 0.02f, 1, eq, 0, 0);
+        EN("attention.wk.weight"); add(nm, 0, STD(d.enc_dim), 2, eq, d.enc_dim, 0);
+        EN("attention.wv.weight"); add(nm, 0, STD(d.enc_dim), 2, eq, d.enc_dim, 0);
+        EN("attention.wv.bias");   add(nm, 2, 0.02f, 1, eq, 0, 0);
+        EN("attention.wo.weight"); add(nm, 0, STD(eq), 2, d.enc_dim, eq, 0);
+        EN("attention.wo.bias");   add(nm, 2, 0.02f, 1, d.enc_dim, 0, 0);
+        EN("attention_norm.weight"); add(nm, 1, 0, 1, d.enc_dim, 0, 0);
+        EN("feed_forward.w1.weight"); add(nm, 0, STD(d.enc_dim), 2, d.enc_hidden, d.enc_dim, 0);
+        EN("feed_forward.w2.weight"); add(nm, 0, STD(d.enc_hidden), 2, d.enc_dim, d.enc_hidden, 0);
+        EN("feed_forward.w2.bias");   add(nm, 2, 0.02f, 1, d.enc_dim, 0, 0);
+        EN("feed_forward.w3.weight"); add(nm, 0, STD(d.enc_dim), 2, d.enc_hidden, d.enc_dim, 0);
+        EN("ffn_norm.weight");        add(nm, 1, 0, 1, d.enc_dim, 0, 0);
+    }
+    snprintf(nm, sizeof nm, "%s.transformer.norm.weight", EP); add(nm, 1, 0, 1, d.enc_dim, 0, 0);
+    add("mm_streams_embeddings.embedding_module.audio_language_projection.0.weight", 0, STD(d.enc_dim * 4), 2, d.dec_dim, d.enc_dim * 4, 0);
+    add("mm_streams_embeddings.embedding_module.audio_language_projection.2.weight", 0, STD(d.dec_dim), 2, d.dec_dim, d.dec_dim, 0);
+    for (int i = 0; i < d.dec_layers; i++) {
+#define DN(sfx) snprintf(nm, sizeof nm, "layers.%d." sfx, i)
+        DN("ada_rms_norm_t_cond.0.weight"); add(nm, 0, STD(d.dec_dim), 2, d.ada_dim, d.dec_dim, 0);
+        DN("ada_rms_norm_t_cond.2.weight"); add(nm, 0, 0.1f * STD(d.ada_dim), 2, d.dec_dim, d.ada_dim, 0);
+        DN("attention.wq.weight"); add(nm, 0, STD(d.dec_dim), 2, dq, d.dec_dim, 0);
+        DN("attention.wk.weight"); add(nm, 0, STD(d.dec_dim), 2, dkv, d.dec_dim, 0);
+        DN("attention.wv.weight"); add(nm, 0, STD(d.dec_dim), 2, dkv, d.dec_dim, 0);
+        DN("attention.wo.weight"); add(nm, 0, STD(dq), 2, d.dec_dim, dq, 0);
+        DN("attention_norm.weight"); add(nm, 1, 0, 1, d.dec_dim, 0, 0);
+        DN("feed_forward.w1.weight"); add(nm, 0, STD(d.dec_dim), 2, d.dec_hidden, d.dec_dim, 0);
+        DN("feed_forward.w2.weight"); add(nm, 0, STD(d.dec_hidden), 2, d.dec_dim, d.dec_hidden, 0);
+        DN("feed_forward.w3.weight"); add(nm, 0, STD(d.dec_dim), 2, d.dec_hidden, d.dec_dim, 0);
+        DN("ffn_norm.weight"); add(nm, 1, 0, 1, d.dec_dim, 0, 0);
+    }
+    add("norm.weight", 1, 0, 1, d.dec_dim, 0, 0);
+
+    /* header */
+    uint64_t off = 0;
+    for (int i = 0; i < g_nt; i++) { g_t[i].offset = off; off += g_t[i].numel * 2; }
+    size_t hcap = (size_t)g_nt * 400 + 64, hl = 0;
+    char *hdr = malloc(hcap);
+    hl += snprintf(hdr + hl, hcap - hl, "{");
+    for (int i = 0; i < g_nt; i++) {
+        tensor_t *t = &g_t[i];
+        hl += snprintf(hdr + hl, hcap - hl, "%s\"%s\":{\"dtype\":\"BF16\",\"shape\":[", i ? "," : "", t->name);
+        for (int k = 0; k < t->ndim; k++) hl += snprintf(hdr + hl, hcap - hl, "%s%lld", k ? "," : "", (long long)t->shape[k]);
+        hl += snprintf(hdr + hl, hcap - hl, "],\"data_offsets\":[%llu,%llu]}", (unsigned long long)t->offset,
+                       (unsigned long long)(t->offset + t->numel * 2));
+    }
+    hl += snprintf(hdr + hl, hcap - hl, "}");
+    while (hl % 8) hdr[hl++] = ' ';
+
+    mkdir(out_dir, 0755);
+    char path[1024];
+    snprintf(path, sizeof path, "%s/consolidated.safetensors", out_dir);
+    FILE *f = fopen(path, "wb");
+    if (!f) { perror(path); return 1; }
+    uint64_t hl64 = hl;
+    fwrite(&hl64, 8, 1, f);
+    fwrite(hdr, 1, hl, f);
+
+    int nthreads = (int)sysconf(_SC_NPROCESSORS_ONLN);
+    if (nthreads > 32) nthreads = 32;
+    if (nthreads < 1) nthreads = 1;
+    for (int i = 0; i < g_nt; i++) {
+        tensor_t *t = &g_t[i];
+        uint16_t *buf = malloc(t->numel * 2);
+        if (!buf) { fprintf(stderr, "oom\n"); return 1; }
+        uint64_t tseed = splitmix64(fnv1a(t->name) ^ seed) ;
+        int nt = t->numel < 65536 ? 1 : nthreads;
+        pthread_t th[32]; job_t jobs[32];
+        for (int k = 0; k < nt; k++) {
+            jobs[k] = (job_t){buf, t, tseed, t->numel * k / nt, t->numel * (k + 1) / nt};
+            if (nt == 1) fill_job(&jobs[k]); else pthread_create(&th[k], NULL, fill_job, &jobs[k]);
+        }
+        if (nt > 1) for (int k = 0; k < nt; k++) pthread_join(th[k], NULL);
+        if (fwrite(buf, 2, t->numel, f) != t->numel) { perror("write"); return 1; }
+        free(buf);
+    }
+    fclose(f);
+
+    /* tekken.json (format parsed by voxtral_tokenizer.c:186-331): every vocab
+     * string encodes its own id so string parity implies id parity.  Rank 0
+     * (token id 1000) is the NUL byte like the real Tekken vocab (voxtral.c:487). */
+    snprintf(path, sizeof path, "%s/tekken.json", out_dir);
+    f = fopen(path, "wb");
+    if (!f) { perror(path); return 1; }
+    int n_vocab = d.vocab - 1000;
+    fprintf(f, "{\"config\":{\"default_vocab_size\":%d,\"default_num_special_tokens\":1000},\"vocab\":[", d.vocab);
+    for (int r = 0; r < n_vocab; r++) {
+        unsigned char raw[32]; char enc[64]; int n;
+        if (r == 0) { raw[0] = 0; n = 1; }
+        else n = snprintf((char *)raw, sizeof raw, " t%d", 1000 + r);
+        b64(raw, n, enc);
+        fprintf(f, "%s{\"rank\":%d,\"token_bytes\":\"%s\",\"token_str\":null}", r ? "," : "", r, enc);
+    }
+    fprintf(f, "],\"special_tokens\":[");
+    for (int r = 0; r < 1000; r++) {
+        const char *s = r == 0 ? "<unk>" : r == 1 ? "<s>" : r == 2 ? "</s>" : r == 32 ? "[STREAMING_PAD]" : NULL;
+        char tmp[32];
+        if (!s) { snprintf(tmp, sizeof tmp, "<SPECIAL_%d>", r); s = tmp; }
+        fprintf(f, "%s{\"rank\":%d,\"token_str\":\"%s\",\"is_control\":true}", r ? "," : "", r, s);
+    }
+    fprintf(f, "]}\n");
+    fclose(f);
+    fprintf(stderr, "synth_model: %d tensors, %.1f MB -> %s\n", g_nt, (double)off / 1e6, out_dir);
+    return 0;
+}

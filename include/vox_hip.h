@@ -1,0 +1,186 @@
+/*
+ * vox_hip.h — thin C-ABI boundary between the plain-C host library (libvoxtral.so)
+ * and the hand-written HIP/CDNA4 device engine (libvoxhip.so, gfx950 only).
+ *
+ * Plain pointers and sizes only; no HIP, C++ or torch types cross this line and the
+ * host .c files never include a HIP header.  The seam mirrors the only places where
+ * the reference ever leaves its CPU kernels for a GPU backend (the USE_METAL hooks):
+ *
+ *   reference seam (file:line)                         ->  entry point here
+ *   ---------------------------------------------------------------------------------
+ *   vox_metal_init / shutdown          main.c:178,404      vox_hip_engine_create/destroy
+ *   weight warm-up in vox_load         voxtral.c:163-235   vox_hip_upload_bf16 / _f32
+ *   KV pre-allocation                  voxtral.c:237-245   (inside engine_create)
+ *   vox_mel_feed / mel_compute_avail.  voxtral_audio.c:454,560   vox_hip_mel_frames
+ *   stream_conv_stem                   voxtral.c:537       vox_hip_conv_stem
+ *   vox_metal_encoder_full_step        voxtral_encoder.c:508-517 vox_hip_encoder_chunk
+ *   vox_adapter_forward                voxtral_encoder.c:642     vox_hip_adapter
+ *   4x alignment + adapter_buf append  voxtral.c:824-890   vox_hip_stream_encode
+ *   vox_metal_decoder_prefill_step     voxtral_decoder.c:448-456 vox_hip_decoder_prefill
+ *   vox_metal_decoder_full_step        voxtral_decoder.c:632-645 vox_hip_decoder_step
+ *   prompt / step embedding build      voxtral.c:993-999,1057-1061 vox_hip_decoder_prefill_stream /
+ *                                                           vox_hip_decoder_run
+ *   stream_reset_*                     voxtral.c:734-780   vox_hip_reset_encoder/_decoder
+ *
+ * Conventions: int returns are 0 on success, -1 on error (message on stderr), like
+ * the reference (voxtral.h:246-251).  All calls are synchronous on return unless the
+ * name ends in _async.  One engine = one GPU = one active stream (voxtral.c:1227).
+ */
+#ifndef VOX_HIP_H
+#define VOX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vox_hip_engine vox_hip_engine_t;
+
+/* Model geometry (voxtral.h:19-50 are the Voxtral-Realtime-4B values). */
+typedef struct vox_hip_dims {
+    int mel_bins;                                  /* 128 */
+    int enc_dim, enc_layers, enc_heads, enc_head_dim, enc_hidden, enc_window;
+    int dec_dim, dec_layers, dec_heads, dec_kv_heads, dec_head_dim, dec_hidden, dec_window;
+    int vocab, ada_dim;
+    float enc_eps, dec_eps, rope_theta;
+} vox_hip_dims_t;
+
+/* Tensor slots.  "layer" is ignored for the global ones. */
+enum vox_hip_tensor {
+    /* bf16 matrices, uploaded byte-for-byte from the mmap'd safetensors */
+    VOXT_TOK_EMB = 0,      /* [vocab, dec_dim]                                  */
+    VOXT_CONV0_W,          /* [enc_dim, mel_bins*3]                             */
+    VOXT_CONV1_W,          /* [enc_dim, enc_dim*3]                              */
+    VOXT_ENC_WQ, VOXT_ENC_WK, VOXT_ENC_WV,   /* [heads*hd, enc_dim] (merged QKV in HBM) */
+    VOXT_ENC_WO,           /* [enc_dim, heads*hd]                               */
+    VOXT_ENC_W1, VOXT_ENC_W3,                /* [enc_hidden, enc_dim] (merged W1;W3)    */
+    VOXT_ENC_W2,           /* [enc_dim, enc_hidden]                             */
+    VOXT_ADAPTER0,         /* [dec_dim, enc_dim*4]                              */
+    VOXT_ADAPTER1,         /* [dec_dim, dec_dim]                                */
+    VOXT_DEC_WQ, VOXT_DEC_WK, VOXT_DEC_WV,   /* merged QKV [ (h+2kvh)*hd, dec_dim ]     */
+    VOXT_DEC_WO,           /* [dec_dim, heads*hd]                               */
+    VOXT_DEC_W1, VOXT_DEC_W3,                /* [dec_hidden, dec_dim]                   */
+    VOXT_DEC_W2,           /* [dec_dim, dec_hidden]                             */
+    /* f32 vectors (the reference converts these to f32 at load: load_f32,
+     * voxtral_encoder.c:32, voxtral_decoder.c:31) */
+    VOXT_CONV0_B, VOXT_CONV1_B,
+    VOXT_ENC_BQ, VOXT_ENC_BV, VOXT_ENC_BO, VOXT_ENC_B2,
+    VOXT_ENC_ATTN_NORM, VOXT_ENC_FFN_NORM, VOXT_ENC_FINAL_NORM,
+    VOXT_DEC_ATTN_NORM, VOXT_DEC_FFN_NORM, VOXT_DEC_FINAL_NORM,
+    VOXT_DEC_ADA_SCALE,    /* [dec_dim] per layer: ada_up(gelu(ada_down(t_cond))), voxtral.c:47-80 */
+    VOXT_COUNT
+};
+
+/* ---- lifetime ------------------------------------------------------------------ */
+int  vox_hip_device_count(void);
+vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dims_t *dims);
+void vox_hip_engine_destroy(vox_hip_engine_t *e);
+const char *vox_hip_last_error(void);
+/* Bytes of HBM currently held by the engine. */
+size_t vox_hip_memory_used(const vox_hip_engine_t *e);
+
+/* ---- weights: host (mmap) -> HBM ----------------------------------------------- */
+int vox_hip_upload_bf16(vox_hip_engine_t *e, int tensor, int layer,
+                        const uint16_t *host_bf16, size_t n_elems);
+int vox_hip_upload_f32(vox_hip_engine_t *e, int tensor, int layer,
+                       const float *host_f32, size_t n_elems);
+/* Mel tables built by the host exactly as voxtral_audio.c:248-285,531-542 does:
+ * filters [mel_bins,201], hann[400], dft_cos/sin [201,400]. */
+int vox_hip_upload_mel_tables(vox_hip_engine_t *e, const float *filters, const float *hann,
+                              const float *dft_cos, const float *dft_sin);
+
+/* ---- stage-level entry points (host buffers in, host buffers out) --------------
+ * Same argument meaning as the reference functions they replace; used by the
+ * voxtral.h "internal" API and by the parity tests. */
+
+/* Log-mel frames: frame t uses samples[t*160 .. t*160+399] (voxtral_audio.c:454-513).
+ * samples must hold (n_frames-1)*160+400 floats. out_mel: [n_frames, mel_bins] or NULL
+ * (frames are also appended to the engine's device mel queue when to_queue != 0). */
+int vox_hip_mel_frames(vox_hip_engine_t *e, const float *samples, int n_frames,
+                       float *out_mel, int to_queue);
+
+/* vox_encoder_forward_incremental (voxtral_encoder.c:452): x_new [new_len, enc_dim]
+ * post-conv-stem rows -> out [new_len, enc_dim]; advances the encoder KV window. */
+int vox_hip_encoder_chunk(vox_hip_engine_t *e, const float *x_new, int new_len, float *out);
+
+/* vox_adapter_forward (voxtral_encoder.c:642): enc_out [enc_len, enc_dim] ->
+ * out [enc_len/4, dec_dim]. Returns number of adapter rows or -1. */
+int vox_hip_adapter(vox_hip_engine_t *e, const float *enc_out, int enc_len, float *out);
+
+/* stream_conv_stem (voxtral.c:537) on host mel rows [n_mel, mel_bins]; keeps the
+ * boundary state on the device. out may be NULL. Returns rows produced ([rows, enc_dim]). */
+int vox_hip_conv_stem(vox_hip_engine_t *e, const float *mel_new, int n_mel, float *out, int out_cap_rows);
+
+/* vox_decoder_prefill (voxtral_decoder.c:410): embeds [seq_len, dec_dim]. */
+int vox_hip_decoder_prefill(vox_hip_engine_t *e, const float *embeds, int seq_len);
+
+/* vox_decoder_forward (voxtral_decoder.c:586): embed [dec_dim] -> greedy token id
+ * (lowest index wins ties); logits [vocab] may be NULL. Returns token or -1. */
+int vox_hip_decoder_step(vox_hip_engine_t *e, const float *embed, float *logits);
+
+/* ---- fused streaming path (activations never leave HBM) ------------------------
+ * vox_hip_stream_encode consumes n_mel frames from the device mel queue and runs
+ * conv stem -> encoder -> 4x alignment -> adapter, appending adapter rows to the
+ * device adapter buffer (stream_run_encoder, voxtral.c:783-907). Outputs the counters
+ * the host state machine needs. Returns number of new adapter rows or -1. */
+int vox_hip_stream_encode(vox_hip_engine_t *e, int n_mel, int *conv_rows, int *enc_residual);
+
+/* Prompt prefill straight from the adapter buffer (voxtral.c:990-1012):
+ * embeds[i] = adapter[first_row+i] + tok_emb[i==0 ? bos : pad], i < n_prompt;
+ * prefill n_prompt-1 rows, then one step. Returns the first generated token. */
+int vox_hip_decoder_prefill_stream(vox_hip_engine_t *e, int64_t first_row, int n_prompt,
+                                   int bos_token, int pad_token, float *logits);
+
+/* Greedy loop (voxtral.c:1056-1093): for i < n_steps: embed = adapter[first_row+i] +
+ * tok_emb[prev]; prev = step(embed). The previous token lives on the device, so all
+ * n_steps are enqueued back-to-back with one synchronisation at the end.
+ * tokens_out[n_steps]; stops early after eos_token (< 0: never). logits_out is
+ * [n_steps, vocab] or NULL. Returns number of steps actually taken (<= n_steps). */
+int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n_steps, int prev_token,
+                        int eos_token, int *tokens_out, float *logits_out);
+
+/* Copy rows out of the device adapter buffer (tests / multi-GPU gather). */
+int vox_hip_adapter_read(vox_hip_engine_t *e, int64_t first_row, int n_rows, float *out);
+/* Append externally produced adapter rows (multi-GPU: rows gathered over xGMI). */
+int vox_hip_adapter_append(vox_hip_engine_t *e, const float *rows, int n_rows);
+int64_t vox_hip_adapter_rows(const vox_hip_engine_t *e);
+/* Device pointer of the adapter ring (for RCCL/torch interop) and its row capacity. */
+void *vox_hip_adapter_devptr(vox_hip_engine_t *e, int64_t *cap_rows);
+
+/* ---- state ---------------------------------------------------------------------- */
+void vox_hip_reset_encoder(vox_hip_engine_t *e);   /* mel queue, conv tails, encoder KV, 4x residual */
+void vox_hip_reset_decoder(vox_hip_engine_t *e);   /* decoder KV + adapter buffer */
+void vox_hip_reset_decoder_kv(vox_hip_engine_t *e);/* decoder KV only (prefill restart, voxtral.c:1001-1002) */
+int  vox_hip_decoder_kv_len(const vox_hip_engine_t *e);   /* logical positions stored so far */
+int  vox_hip_mel_queue_len(const vox_hip_engine_t *e);
+void vox_hip_sync(vox_hip_engine_t *e);
+
+/* ---- kernel-level test/bench surface (host buffers; mirrors voxtral_kernels.h) -- */
+/* y[M,N] = x[M,K] @ W_bf16[N,K]^T (+bias) — vox_linear_bf16 (voxtral_kernels.c:216).
+ * impl: 0 auto (M==1 -> GEMV, else MFMA GEMM), 1 force GEMV rows, 2 force MFMA GEMM,
+ * 3 scalar reference kernel (plain fp32 FMA loop, for cross-checks). */
+int vox_hip_linear_bf16(vox_hip_engine_t *e, float *y, const float *x, const uint16_t *w,
+                        const float *bias, int M, int K, int N, int impl);
+/* vox_causal_attention (voxtral_kernels.c:412) for head_dim 64 (encoder) / 128 (decoder). */
+int vox_hip_causal_attention(vox_hip_engine_t *e, float *out, const float *q, const float *k,
+                             const float *v, int seq_q, int seq_k, int n_heads, int n_kv_heads,
+                             int head_dim, float scale, int window, int q_offset);
+/* Micro-benchmark of the decode GEMV on resident weights: streams `bytes` of the
+ * decoder weights `iters` times; returns average seconds per pass measured with HIP
+ * events on the engine stream (used by bench.py's roofline leg). */
+double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int kv_len);
+
+/* Timing of the last fused calls (HIP events on the engine stream), milliseconds. */
+typedef struct vox_hip_timing {
+    double encode_ms, prefill_ms, decode_ms;
+    int    decode_steps;
+} vox_hip_timing_t;
+void vox_hip_get_timing(const vox_hip_engine_t *e, vox_hip_timing_t *t);
+void vox_hip_reset_timing(vox_hip_engine_t *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOX_HIP_H */

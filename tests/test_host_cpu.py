@@ -1,0 +1,133 @@
+"""CPU: host-side logic and the C-ABI surface (no GPU compute)."""
+import ctypes as C
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, model_dir
+
+LIBDIR = os.path.join(ROOT, "voxtral_c_amd")
+
+
+def exported(lib):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(LIBDIR, lib)], text=True)
+    return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+
+
+def declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\b(vox_[a-z0-9_]+)\s*\(", txt))
+
+
+def test_libraries_export_every_declared_symbol():
+    hip = exported("libvoxhip.so")
+    host = exported("libvoxtral.so")
+    missing = declared("vox_hip.h") - hip
+    assert not missing, f"libvoxhip.so misses {missing}"
+    for h in ("voxtral.h", "voxtral_audio.h", "voxtral_tokenizer.h", "voxtral_mic.h"):
+        missing = declared(h) - host
+        assert not missing, f"libvoxtral.so misses {missing} from {h}"
+    for g in ("vox_verbose", "vox_monitor", "vox_verbose_audio"):
+        assert g in host
+
+
+def test_import_and_loud_failure_without_gpu(tiny_dir):
+    import voxtral_c_amd as v
+    if v.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(v.VoxError):
+        v.Model(tiny_dir)
+
+
+def test_host_never_routes_through_the_oracle():
+    """The product must not import/link anything under oracle/."""
+    for root, _, files in os.walk(LIBDIR):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip")):
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                assert "vox_oracle" not in txt and "ref_binding" not in txt and "libvoxref" not in txt, f
+    deps = subprocess.check_output(["ldd", os.path.join(LIBDIR, "libvoxtral.so")], text=True)
+    assert "voxref" not in deps and "openblas" not in deps
+
+
+def test_tokenizer_matches_synthetic_vocab(tiny_dir):
+    import voxtral_c_amd as v
+    lib = v.lib
+    lib.vox_tokenizer_load.restype = C.c_void_p
+    lib.vox_tokenizer_load.argtypes = [C.c_char_p]
+    lib.vox_tokenizer_decode.restype = C.c_char_p
+    lib.vox_tokenizer_decode.argtypes = [C.c_void_p, C.c_int]
+    lib.vox_tokenizer_free.argtypes = [C.c_void_p]
+    t = lib.vox_tokenizer_load(os.path.join(tiny_dir, "tekken.json").encode())
+    assert t
+    assert lib.vox_tokenizer_decode(t, 1) == b"<s>"
+    assert lib.vox_tokenizer_decode(t, 2) == b"</s>"
+    assert lib.vox_tokenizer_decode(t, 32) == b"[STREAMING_PAD]"
+    assert lib.vox_tokenizer_decode(t, 1000) == b""          # NUL byte piece
+    assert lib.vox_tokenizer_decode(t, 1234) == b" t1234"
+    assert lib.vox_tokenizer_decode(t, 2047) == b" t2047"
+    assert lib.vox_tokenizer_decode(t, 2048) is None
+    assert lib.vox_tokenizer_decode(t, -1) is None
+    lib.vox_tokenizer_free(t)
+
+
+def _wav(samples_i16, rate=16000, channels=1, data_size=None):
+    raw = np.asarray(samples_i16, np.int16).tobytes()
+    ds = len(raw) if data_size is None else data_size
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, channels, rate,
+                                                                                         rate * channels * 2, channels * 2, 16)
+    return hdr + b"LIST" + struct.pack("<I", 3) + b"abc\0" + b"data" + struct.pack("<I", ds) + raw
+
+
+def test_wav_parser_cases(tmp_path):
+    import voxtral_c_amd as v
+    x = (np.sin(np.arange(3200) * 0.05) * 12000).astype(np.int16)
+    p = tmp_path / "a.wav"
+    p.write_bytes(_wav(x))
+    s = v.load_wav(str(p))
+    assert np.array_equal(s, x.astype(np.float32) / 32768.0)
+    # stereo -> mono mean, odd-sized LIST chunk skipped, 0xFFFFFFFF data size (piped ffmpeg)
+    st = np.stack([x, -x // 2], 1).reshape(-1)
+    p.write_bytes(_wav(st, channels=2, data_size=0xFFFFFFFF))
+    s2 = v.load_wav(str(p))
+    assert np.allclose(s2, (x.astype(np.float32) + (-x // 2).astype(np.float32)) / 2 / 32768.0, atol=1e-7)
+    # 8 kHz -> 16 kHz linear resample: doubles the length
+    p.write_bytes(_wav(x, rate=8000))
+    s3 = v.load_wav(str(p))
+    assert len(s3) == 2 * len(x)
+    assert np.allclose(s3[::2], x.astype(np.float32) / 32768.0, atol=1e-7)
+    p.write_bytes(b"RIFFxxxxWAVEjunk")
+    with pytest.raises(v.VoxError):
+        v.load_wav(str(p))
+
+
+def test_wav_parser_matches_reference(tmp_path, ref_tiny):
+    import voxtral_c_amd as v
+    x = (np.random.default_rng(1).standard_normal(5000) * 3000).astype(np.int16)
+    for rate, ch in [(16000, 1), (44100, 2), (8000, 1), (22050, 1)]:
+        p = tmp_path / f"r{rate}_{ch}.wav"
+        p.write_bytes(_wav(np.repeat(x, ch) if ch > 1 else x, rate=rate, channels=ch))
+        a = v.load_wav(str(p))
+        b = ref_tiny.load_wav(str(p))
+        assert a.shape == b.shape and np.abs(a - b).max() < 1e-6
+
+
+def test_safetensors_index_against_python_reader(tiny_dir):
+    """The C safetensors index sees the same tensors as an independent reader (via vox_st_* is
+    internal, so check through the public loader's error path: a truncated file must fail)."""
+    import voxtral_c_amd as v
+    from oracle.vox_oracle import read_safetensors_bf16
+    t = read_safetensors_bf16(os.path.join(tiny_dir, "consolidated.safetensors"))
+    assert len(t) == 81
+    assert t["norm.weight"].shape == (384,)
+    bad = os.path.join(os.path.dirname(tiny_dir), "bad_model")
+    os.makedirs(bad, exist_ok=True)
+    src = open(os.path.join(tiny_dir, "consolidated.safetensors"), "rb").read()
+    open(os.path.join(bad, "consolidated.safetensors"), "wb").write(src[: len(src) // 2])
+    with pytest.raises(v.VoxError):
+        v.Model(bad)

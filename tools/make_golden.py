@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""tools/make_golden.py — generate tests/golden/*.npz from the REAL reference.
+
+Runs only where /root/reference has been compiled into oracle/_ref (this container:
+`make -C oracle`).  Drives the reference's own stream API (vox_stream_feed/finish, i.e. what
+main.c does) on deterministic synthetic checkpoints (tools/synth_model.c) and synthetic
+audio (tests/audio_util.py) and stores, per case:
+  tokens      every decoder-step token id (captured with --wrap=vox_decoder_forward)
+  pieces      the strings vox_stream_get surfaced
+  top_ids/top_vals   the 8 largest logits of every step
+  logits_head full logits rows for the first 4 steps
+  margin      top1-top2 logit gap per step (how fragile the argmax is)
+  mel_sha/adapter checks are covered by stage-level goldens (stage_*.npz)
+The fixtures are small (a few hundred kB) and committed; the generator is committed so they
+can be re-derived.  usage: python tools/make_golden.py [--full]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle.ref_binding import RefLib  # noqa: E402
+from oracle import vox_oracle as vo  # noqa: E402
+from audio_util import synth_speech  # noqa: E402
+from conftest import model_dir  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+CASES = [
+    # name, preset, seconds, audio seed, feed sizes (None = one feed), interval, continuous
+    ("tiny_batch", "tiny", 12.0, 1, None, None, False),
+    ("tiny_stream", "tiny", 12.0, 1, "1s", None, False),
+    ("tiny_smallint", "tiny", 12.0, 1, 4096, 0.1, False),
+    ("tiny_long", "tiny", 100.0, 2, None, None, False),        # > 1126 steps: decoder window roll-over
+    ("tiny_continuous", "tiny", 200.0, 3, 4096, 0.5, True),    # restarts at kv > 2000
+    ("small_batch", "small", 8.0, 4, None, None, False),
+]
+
+
+def summarise(r, vocab):
+    lg = r["logits"]
+    out = dict(tokens=r["tokens"].astype(np.int32), pieces=np.array(r["pieces"], dtype=object))
+    if lg is not None and len(lg):
+        order = np.argsort(-lg, axis=1)[:, :8]
+        out["top_ids"] = order.astype(np.int32)
+        out["top_vals"] = np.take_along_axis(lg, order, axis=1).astype(np.float32)
+        out["logits_head"] = lg[:4].astype(np.float32)
+        srt = np.sort(lg, axis=1)
+        out["margin"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)
+    return out
+
+
+def feeds_for(spec, n):
+    if spec is None:
+        return None
+    if spec == "1s":
+        return [16000] * (n // 16000 + 1)
+    return [int(spec)] * (n // int(spec) + 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true", help="also run the full-size (8.9 GB) model (minutes of CPU)")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    libs = {}
+    cases = list(CASES)
+    if args.full:
+        cases.append(("full_batch", "full", 6.0, 5, None, None, False))
+    for name, preset, secs, aseed, feed, interval, cont in cases:
+        if args.only and args.only != name:
+            continue
+        if preset not in libs:
+            libs[preset] = RefLib(preset)
+        R = libs[preset]
+        d = vo.PRESETS[preset]
+        audio = synth_speech(secs, aseed)
+        ctx = R.load(model_dir(preset))
+        r = R.transcribe_stream(ctx, audio, feed_sizes=feeds_for(feed, len(audio)), interval=interval,
+                                continuous=cont, vocab=d.vocab, max_logit_rows=4096 if preset != "full" else 512)
+        R.free(ctx)
+        out = summarise(r, d.vocab)
+        out["meta"] = np.array([preset, str(secs), str(aseed), str(feed), str(interval), str(int(cont))], dtype=object)
+        np.savez_compressed(os.path.join(GOLD, f"stream_{name}.npz"), **out)
+        mg = out.get("margin")
+        print(f"{name}: {len(out['tokens'])} steps, {len(set(out['tokens'].tolist()))} distinct tokens, "
+              f"{len(out['pieces'])} pieces, min margin {mg.min() if mg is not None else None}")
+
+    # ---- stage-level goldens on the tiny model (reference functions called directly) ----
+    if not args.only or args.only == "stage":
+        R = libs.get("tiny") or RefLib("tiny")
+        d = vo.PRESETS["tiny"]
+        rng = np.random.default_rng(7)
+        audio = synth_speech(3.0, 9)
+        mel = R.mel_stream(audio, feeds=[7000, 1, 159, 20000, len(audio) - 27160])
+        ctx = R.load(model_dir("tiny"))
+        xs = [rng.standard_normal((n, d.enc_dim)).astype(np.float32) for n in (30, 7, 50, 64, 1, 3)]
+        enc = [R.encoder_forward_incremental(ctx, x, d.enc_dim) for x in xs]
+        ad = R.adapter_forward(ctx, np.concatenate(enc)[:152], d.dec_dim)
+        emb = (rng.standard_normal((45, d.dec_dim)) * 0.5).astype(np.float32)
+        R.decoder_prefill(ctx, emb[:38])
+        toks, logs = [], []
+        for i in range(38, 45):
+            t, lg = R.decoder_forward(ctx, emb[i], d.vocab)
+            toks.append(t); logs.append(lg)
+        R.free(ctx)
+        np.savez_compressed(os.path.join(GOLD, "stage_tiny.npz"), audio=audio, mel=mel,
+                            **{f"enc_in{i}": x for i, x in enumerate(xs)},
+                            **{f"enc_out{i}": e for i, e in enumerate(enc)},
+                            adapter_out=ad, dec_emb=emb, dec_tokens=np.array(toks, np.int32), dec_logits=np.stack(logs))
+        print("stage_tiny: mel", mel.shape, "enc chunks", [e.shape[0] for e in enc], "dec tokens", toks)
+
+
+if __name__ == "__main__":
+    main()

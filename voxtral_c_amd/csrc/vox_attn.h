@@ -1,0 +1,290 @@
+// vox_attn.h — causal sliding-window attention kernels (vox_causal_attention,
+// voxtral_kernels.c:412-482) for the two shapes the model uses.
+//
+//  * k_attn_rows<64>  — encoder / large-M: MHA, head_dim 64, window 750.  One thread owns
+//    one query row (q and the output accumulator live in registers, 64+64 VGPRs), a block
+//    of 128 consecutive queries of one head walks the union of their key windows in
+//    32-key tiles staged through LDS (all lanes read the same K/V row => LDS broadcast,
+//    no bank conflicts).  Keys are visited in increasing position with the reference's own
+//    online-softmax recurrence, so the arithmetic order per query matches the oracle.
+//    FLOP-bound on the fp32 VALU (2*2*64 FLOP per (q,k) pair).
+//
+//  * k_attn_dec<128,4> — decoder (prefill rows and the M=1 step): GQA with 4 query heads per
+//    KV head, head_dim 128, fp32 KV ring.  HBM-bound on the KV read, so one wave streams
+//    every K/V row once for all 4 query heads: 16 lanes x 32 bytes cover one 512-byte head
+//    row, a wave-instruction covers 4 keys; the 16-lane dot products are reduced with DPP
+//    row operations; each 16-lane group keeps its own online-softmax state which is merged
+//    once at the end (lane groups -> waves through LDS -> optional split-K partials).
+//
+// Key addressing is by logical position: keys with position < posB0 live in a ring
+// (slot = pos % cap, filled by previous chunks), keys >= posB0 in a linear array (the
+// current chunk's merged QKV buffer, or the caller's K/V for the kernel-level API).
+// "Attend to physical rows max(0,p-W+1)..p of the compacted cache" in the reference is
+// exactly "logical positions max(0,P-W+1)..P" here.
+#pragma once
+#include "vox_common.h"
+
+namespace vox {
+
+struct AttnArgs {
+    float *out; int ldo;            // [n_q, n_heads*HD]
+    const float *q; int ldq;        // [n_q, ...] head h at column h*HD
+    int n_q;
+    int qpos0;                      // logical position of query row 0
+    const float *kB, *vB; int ldB;  // linear segment: row r <-> position posB0 + r
+    int posB0;                      // keys with position < posB0 come from the ring
+    int last_key;                   // last key position that exists (k_end = min(gpos+1, seq_k))
+    const float *kA, *vA;           // ring segment (positions < posB0): [capA][ldA]
+    int capA, ldA;
+    int n_heads, n_kv_heads;
+    float scale;
+    int window;
+    const DecState *st;             // decoder step: qpos0 = st->pos (when non-null)
+    // split-K (decoder)
+    int split_keys;                 // keys per blockIdx.y
+    float *part_o, *part_ml;        // [n_q][n_heads][nsplit][HD], [..][2]
+};
+
+template <int HD>
+__global__ __launch_bounds__(128) void k_attn_rows(const AttnArgs a) {
+    constexpr int TK = 32;
+    __shared__ __attribute__((aligned(16))) float Ks[TK][HD];
+    __shared__ __attribute__((aligned(16))) float Vs[TK][HD];
+    const int tid = threadIdx.x;
+    const int h = blockIdx.y;
+    const int kvh = h / (a.n_heads / a.n_kv_heads);
+    const int qi = blockIdx.x * 128 + tid;
+    const bool valid = qi < a.n_q;
+    const int P = a.qpos0 + qi;
+    const int last_key = a.last_key;
+    int lo_i = P - a.window + 1; if (lo_i < 0) lo_i = 0;
+    int hi_i = P < last_key ? P : last_key;
+    if (!valid) { lo_i = 1; hi_i = 0; }
+
+    // block-wide key range
+    const int q_first = blockIdx.x * 128;
+    const int q_last = min(q_first + 127, a.n_q - 1);
+    int blo = a.qpos0 + q_first - a.window + 1; if (blo < 0) blo = 0;
+    int bhi = a.qpos0 + q_last; if (bhi > last_key) bhi = last_key;
+
+    float qv[HD], o[HD];
+    if (valid) {
+        const float *qp = a.q + (size_t)qi * a.ldq + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(qp + d);
+            qv[d] = t.x; qv[d + 1] = t.y; qv[d + 2] = t.z; qv[d + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < HD; d++) qv[d] = 0.f;
+    }
+#pragma unroll
+    for (int d = 0; d < HD; d++) o[d] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    for (int t0 = blo; t0 <= bhi; t0 += TK) {
+        __syncthreads();
+        // cooperative tile load: TK rows x HD floats for K and V
+        for (int i = tid; i < TK * (HD / 4); i += 128) {
+            const int r = i / (HD / 4), c = (i % (HD / 4)) * 4;
+            const int pos = t0 + r;
+            float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+            if (pos <= bhi) {
+                if (pos >= a.posB0) {
+                    const size_t off = (size_t)(pos - a.posB0) * a.ldB + kvh * HD + c;
+                    kk = *reinterpret_cast<const float4 *>(a.kB + off);
+                    vv = *reinterpret_cast<const float4 *>(a.vB + off);
+                } else {
+                    const size_t off = (size_t)(pos % a.capA) * a.ldA + kvh * HD + c;
+                    kk = *reinterpret_cast<const float4 *>(a.kA + off);
+                    vv = *reinterpret_cast<const float4 *>(a.vA + off);
+                }
+            }
+            *reinterpret_cast<float4 *>(&Ks[r][c]) = kk;
+            *reinterpret_cast<float4 *>(&Vs[r][c]) = vv;
+        }
+        __syncthreads();
+        const bool any_here = (t0 + TK - 1 >= lo_i) && (t0 <= hi_i);
+        if (!__any(any_here)) continue;
+#pragma unroll 1
+        for (int j = 0; j < TK; j++) {
+            const int pos = t0 + j;
+            const bool in = (pos >= lo_i) && (pos <= hi_i);
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                const float4 kk = *reinterpret_cast<const float4 *>(&Ks[j][d]);
+                s = fmaf(qv[d], kk.x, s); s = fmaf(qv[d + 1], kk.y, s);
+                s = fmaf(qv[d + 2], kk.z, s); s = fmaf(qv[d + 3], kk.w, s);
+            }
+            s *= a.scale;
+            if (in) {
+                // reference recurrence (voxtral_kernels.c:456-470), branch-free form
+                const float mn = fmaxf(m, s);
+                const float corr = expf(m - mn);
+                const float p = expf(s - mn);
+                l = l * corr + p;
+#pragma unroll
+                for (int d = 0; d < HD; d += 4) {
+                    const float4 vv = *reinterpret_cast<const float4 *>(&Vs[j][d]);
+                    o[d] = o[d] * corr + p * vv.x; o[d + 1] = o[d + 1] * corr + p * vv.y;
+                    o[d + 2] = o[d + 2] * corr + p * vv.z; o[d + 3] = o[d + 3] * corr + p * vv.w;
+                }
+                m = mn;
+            }
+        }
+    }
+    if (valid) {
+        float *op = a.out + (size_t)qi * a.ldo + h * HD;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            float4 t;
+            t.x = o[d] * inv; t.y = o[d + 1] * inv; t.z = o[d + 2] * inv; t.w = o[d + 3] * inv;
+            *reinterpret_cast<float4 *>(op + d) = t;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Decoder attention.  grid = (n_kv_heads, nsplit, n_q); block = 256 (4 waves).
+// ---------------------------------------------------------------------------------
+template <int HD, int HPK, bool USE_DPP>
+__global__ __launch_bounds__(256) void k_attn_dec(const AttnArgs a, const int nsplit) {
+    static_assert(HD == 128, "16 lanes x 8 dims");
+    __shared__ float sm_m[4][HPK], sm_l[4][HPK];
+    __shared__ __attribute__((aligned(16))) float sm_o[4][HPK][HD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ks = lane >> 4, dc = lane & 15;
+    const int kvh = blockIdx.x, split = blockIdx.y, qi = blockIdx.z;
+    static_assert(HPK == 4, "one wave per query head in the cross-wave merge");
+    const int P = (a.st ? a.st->pos : a.qpos0) + qi;
+    const int last_key = a.st ? P : a.last_key;
+    int lo = P - a.window + 1; if (lo < 0) lo = 0;
+    int hi = P < last_key ? P : last_key;
+    // this block's slice, then this wave's quarter of it
+    const int s_lo = lo + split * a.split_keys;
+    int s_hi = s_lo + a.split_keys - 1; if (s_hi > hi) s_hi = hi;
+    const int per_wave = a.split_keys / 4;
+    const int w_lo = s_lo + wave * per_wave;
+    int w_hi = w_lo + per_wave - 1; if (w_hi > s_hi) w_hi = s_hi;
+
+    float qv[HPK][8], o[HPK][8], m[HPK], l[HPK];
+#pragma unroll
+    for (int h = 0; h < HPK; h++) {
+        const float *qp = a.q + (size_t)qi * a.ldq + (kvh * HPK + h) * HD + dc * 8;
+        const float4 t0 = *reinterpret_cast<const float4 *>(qp);
+        const float4 t1 = *reinterpret_cast<const float4 *>(qp + 4);
+        qv[h][0] = t0.x; qv[h][1] = t0.y; qv[h][2] = t0.z; qv[h][3] = t0.w;
+        qv[h][4] = t1.x; qv[h][5] = t1.y; qv[h][6] = t1.z; qv[h][7] = t1.w;
+        m[h] = -1e30f; l[h] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; d++) o[h][d] = 0.f;
+    }
+
+    for (int t = w_lo + ks; t <= w_hi; t += 4) {
+        const float *kp, *vp;
+        if (t >= a.posB0) {
+            const size_t off = (size_t)(t - a.posB0) * a.ldB + kvh * HD + dc * 8;
+            kp = a.kB + off; vp = a.vB + off;
+        } else {
+            const size_t off = (size_t)(t % a.capA) * a.ldA + kvh * HD + dc * 8;
+            kp = a.kA + off; vp = a.vA + off;
+        }
+        const float4 k0 = *reinterpret_cast<const float4 *>(kp);
+        const float4 k1 = *reinterpret_cast<const float4 *>(kp + 4);
+        const float4 v0 = *reinterpret_cast<const float4 *>(vp);
+        const float4 v1 = *reinterpret_cast<const float4 *>(vp + 4);
+#pragma unroll
+        for (int h = 0; h < HPK; h++) {
+            float s = qv[h][0] * k0.x;
+            s = fmaf(qv[h][1], k0.y, s); s = fmaf(qv[h][2], k0.z, s); s = fmaf(qv[h][3], k0.w, s);
+            s = fmaf(qv[h][4], k1.x, s); s = fmaf(qv[h][5], k1.y, s); s = fmaf(qv[h][6], k1.z, s);
+            s = fmaf(qv[h][7], k1.w, s);
+            s = row16_sum<USE_DPP>(s) * a.scale;
+            const float mn = fmaxf(m[h], s);
+            const float corr = expf(m[h] - mn);
+            const float p = expf(s - mn);
+            l[h] = l[h] * corr + p;
+            o[h][0] = o[h][0] * corr + p * v0.x; o[h][1] = o[h][1] * corr + p * v0.y;
+            o[h][2] = o[h][2] * corr + p * v0.z; o[h][3] = o[h][3] * corr + p * v0.w;
+            o[h][4] = o[h][4] * corr + p * v1.x; o[h][5] = o[h][5] * corr + p * v1.y;
+            o[h][6] = o[h][6] * corr + p * v1.z; o[h][7] = o[h][7] * corr + p * v1.w;
+            m[h] = mn;
+        }
+    }
+
+    // merge the 4 lane groups of the wave (same dims dc, disjoint key subsets)
+#pragma unroll
+    for (int h = 0; h < HPK; h++) {
+        float mm = fmaxf(m[h], __shfl_xor(m[h], 16, 64));
+        mm = fmaxf(mm, __shfl_xor(mm, 32, 64));
+        const float f = expf(m[h] - mm);
+        float ll = l[h] * f;
+        ll += __shfl_xor(ll, 16, 64);
+        ll += __shfl_xor(ll, 32, 64);
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            float ov = o[h][d] * f;
+            ov += __shfl_xor(ov, 16, 64);
+            ov += __shfl_xor(ov, 32, 64);
+            o[h][d] = ov;
+        }
+        m[h] = mm; l[h] = ll;
+        if (ks == 0) {
+#pragma unroll
+            for (int d = 0; d < 8; d++) sm_o[wave][h][dc * 8 + d] = o[h][d];
+            if (dc == 0) { sm_m[wave][h] = mm; sm_l[wave][h] = ll; }
+        }
+    }
+    __syncthreads();
+    // merge the 4 waves: thread -> (head, 2 dims)
+    {
+        const int h = tid >> 6;          // HPK == 4 -> one wave per head here
+        const int d0 = (tid & 63) * 2;
+        if (h < HPK) {
+            float mm = sm_m[0][h];
+#pragma unroll
+            for (int w = 1; w < 4; w++) mm = fmaxf(mm, sm_m[w][h]);
+            float ll = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const float f = expf(sm_m[w][h] - mm);
+                ll += sm_l[w][h] * f;
+                o0 += sm_o[w][h][d0] * f;
+                o1 += sm_o[w][h][d0 + 1] * f;
+            }
+            const int head = kvh * HPK + h;
+            if (nsplit == 1) {
+                const float inv = ll > 0.f ? 1.0f / ll : 0.f;
+                float *op = a.out + (size_t)qi * a.ldo + head * HD + d0;
+                op[0] = o0 * inv; op[1] = o1 * inv;
+            } else {
+                const size_t pidx = ((size_t)qi * a.n_heads + head) * nsplit + split;
+                a.part_o[pidx * HD + d0] = o0;
+                a.part_o[pidx * HD + d0 + 1] = o1;
+                if (d0 == 0) { a.part_ml[pidx * 2] = mm; a.part_ml[pidx * 2 + 1] = ll; }
+            }
+        }
+    }
+}
+
+// Merge split-K partials.  grid = (n_heads, n_q), block = HD threads.
+template <int HD>
+__global__ __launch_bounds__(HD) void k_attn_combine(float *out, int ldo, const float *part_o,
+                                                     const float *part_ml, int n_heads, int nsplit) {
+    const int head = blockIdx.x, qi = blockIdx.y, d = threadIdx.x;
+    const size_t base = ((size_t)qi * n_heads + head) * nsplit;
+    float mm = -1e30f;
+    for (int s = 0; s < nsplit; s++) mm = fmaxf(mm, part_ml[(base + s) * 2]);
+    float ll = 0.f, ov = 0.f;
+    for (int s = 0; s < nsplit; s++) {
+        const float f = expf(part_ml[(base + s) * 2] - mm);
+        ll += part_ml[(base + s) * 2 + 1] * f;
+        ov += part_o[(base + s) * HD + d] * f;
+    }
+    out[(size_t)qi * ldo + head * HD + d] = ll > 0.f ? ov * (1.0f / ll) : 0.f;
+}
+
+}  // namespace vox

@@ -1,0 +1,93 @@
+// vox_common.h — device helpers shared by all gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vox {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Device-resident decoder cursor.  Every kernel of a decode step reads its position
+// from here, so an identical launch sequence (or one captured hipGraph) serves every
+// step and several steps can be queued without a host round trip.
+struct DecState {
+    int pos;          // logical position of the token being processed (RoPE / KV slot)
+    int token;        // previous token id -> embedding of the next step
+    int n_out;        // tokens written to tokens_out so far (this run)
+    int stop;         // set once eos was produced (later queued steps become no-ops)
+    long long adapter_row;  // physical adapter row of this step
+};
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// Full-wave (64 lane) butterfly reductions; every lane ends with the result.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Sum across the 16 lanes of a DPP row (lanes 16r..16r+15); all 16 lanes get the sum.
+// DPP path: quad_perm xor1 (0xB1), quad_perm xor2 (0x4E), row_half_mirror (0x141),
+// row_mirror (0x140) — four VALU ops, no LDS traffic.  USE_DPP=false is the
+// __shfl_xor (ds_bpermute) form with identical semantics; the engine self-tests
+// the DPP form at start-up and falls back if the two ever disagree.
+template <bool USE_DPP>
+__device__ __forceinline__ float row16_sum(float v) {
+    if (USE_DPP) {
+        int x;
+        x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);
+        v += __int_as_float(x);
+        x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);
+        v += __int_as_float(x);
+        x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true);
+        v += __int_as_float(x);
+        x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true);
+        v += __int_as_float(x);
+        return v;
+    } else {
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        return v;
+    }
+}
+
+// tanh-approximation GELU exactly as voxtral_kernels.c:376-384.
+__device__ __forceinline__ float gelu_tanh(float v) {
+    float x3 = v * v * v;
+    float inner = 0.7978845608028654f * (v + 0.044715f * x3);
+    return 0.5f * v * (1.0f + tanhf(inner));
+}
+// SiLU as voxtral_kernels.c:369-374.
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
+
+// 16-byte streaming load of weights that are read exactly once per pass.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream(const uint4 *p) {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ float dot8_bf16(const uint4 w, const float4 x0, const float4 x1, float acc) {
+    acc = fmaf(bf16_lo(w.x), x0.x, acc);
+    acc = fmaf(bf16_hi(w.x), x0.y, acc);
+    acc = fmaf(bf16_lo(w.y), x0.z, acc);
+    acc = fmaf(bf16_hi(w.y), x0.w, acc);
+    acc = fmaf(bf16_lo(w.z), x1.x, acc);
+    acc = fmaf(bf16_hi(w.z), x1.y, acc);
+    acc = fmaf(bf16_lo(w.w), x1.z, acc);
+    acc = fmaf(bf16_hi(w.w), x1.w, acc);
+    return acc;
+}
+
+}  // namespace vox

@@ -1,0 +1,177 @@
+// vox_gemm.h — large-M  y[M,N] = x[M,K](f32) . W[N,K]^T(bf16)  for gfx950.
+//
+// Replaces the reference's "convert the whole bf16 matrix to f32, then cblas_sgemm"
+// path (voxtral_kernels.c:197-240, 88-116) used by the encoder chunk, decoder prefill,
+// adapter and (via im2col) the conv stem (voxtral_kernels.c:293-340).
+//
+// Precision contract: the oracle multiplies exact-bf16 weights (upcast to f32) by f32
+// activations with f32 accumulation.  k_gemm_mfma_f32 does exactly that on the matrix
+// cores with v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bitwise an fmaf chain,
+// 157 TFLOP/s peak) — bf16 weights are upcast while being staged into LDS, activations
+// are never rounded.  Roofline: MFMA(f32) for M >~ 200 rows, HBM/L2 (weight streaming)
+// for the small streaming chunks.
+//
+// Tiling (64-wide waves): 128x128 output tile per 256-thread block, 4 waves as 2x2,
+// each wave 64x64 = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs).  K is consumed in
+// 32-wide slices staged through LDS with a +4 float row pad: every ds_read_b128 of a
+// 16-lane service group lands on 16 distinct 16-byte slots (conflict-free, see the
+// bank model in MI355X_MICROARCH.md §LDS).  A lane reads 4 consecutive k of its row with
+// one ds_read_b128 and feeds them to 4 MFMA k-steps; A and B use the same k<->slot map,
+// which is all the dot product needs.  Global loads of slice t+1 are issued before the
+// MFMAs of slice t (register-staged software pipeline).
+//
+// Fused epilogue: + bias[n], activation (none | tanh-GELU | SiLU), + residual[m,n].
+#pragma once
+#include "vox_common.h"
+
+namespace vox {
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
+
+constexpr int GB_M = 128, GB_N = 128, GB_K = 32, GB_LD = GB_K + 4;
+constexpr int GEMM_LDS_BYTES = (GB_M + GB_N) * GB_LD * 4;
+
+struct GemmArgs {
+    const float *X; int ldx;       // [M, K]
+    const uint16_t *W;             // [N, K]
+    float *Y; int ldy;             // [M, N]
+    int M, N, K;
+    const float *bias;             // [N] or null
+    const float *resid; int ldr;   // [M, N] or null (may alias Y)
+    int act;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_GELU) return gelu_tanh(v);
+    if (act == ACT_SILU) return silu(v);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_gemm_mfma_f32(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                     // [GB_M][GB_LD]
+    float *Bs = smem + GB_M * GB_LD;      // [GB_N][GB_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bm0 = blockIdx.y * GB_M, bn0 = blockIdx.x * GB_N;
+    const int M = a.M, N = a.N, K = a.K;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // staging assignment
+    //   A slice: 128 rows x 32 f32 = 1024 float4 -> 4 per thread (row = idx>>3, c4 = idx&7)
+    //   B slice: 128 rows x 32 bf16 = 512 uint4  -> 2 per thread (row = idx>>2, c8 = idx&3)
+    float4 ra[4];
+    uint4 rb[2];
+    auto load_slice = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = tid + i * 256, row = idx >> 3, c4 = idx & 7;
+            const int gm = bm0 + row;
+            ra[i] = (gm < M) ? *reinterpret_cast<const float4 *>(a.X + (size_t)gm * a.ldx + k0 + c4 * 4)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int idx = tid + i * 256, row = idx >> 2, c8 = idx & 3;
+            const int gn = bn0 + row;
+            rb[i] = (gn < N) ? *reinterpret_cast<const uint4 *>(a.W + (size_t)gn * K + k0 + c8 * 8)
+                             : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = tid + i * 256, row = idx >> 3, c4 = idx & 7;
+            *reinterpret_cast<float4 *>(As + row * GB_LD + c4 * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int idx = tid + i * 256, row = idx >> 2, c8 = idx & 3;
+            float4 lo, hi;
+            lo.x = bf16_lo(rb[i].x); lo.y = bf16_hi(rb[i].x); lo.z = bf16_lo(rb[i].y); lo.w = bf16_hi(rb[i].y);
+            hi.x = bf16_lo(rb[i].z); hi.y = bf16_hi(rb[i].z); hi.z = bf16_lo(rb[i].w); hi.w = bf16_hi(rb[i].w);
+            *reinterpret_cast<float4 *>(Bs + row * GB_LD + c8 * 8) = lo;
+            *reinterpret_cast<float4 *>(Bs + row * GB_LD + c8 * 8 + 4) = hi;
+        }
+    };
+
+    const int nk = K / GB_K;
+    load_slice(0);
+    store_slice();
+    __syncthreads();
+
+    const int li = lane & 31, lg = lane >> 5;
+    for (int kt = 0; kt < nk; kt++) {
+        if (kt + 1 < nk) load_slice((kt + 1) * GB_K);
+#pragma unroll
+        for (int kk = 0; kk < GB_K; kk += 8) {
+            float4 av[2], bv[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                av[t] = *reinterpret_cast<const float4 *>(As + (wm * 64 + t * 32 + li) * GB_LD + kk + lg * 4);
+                bv[t] = *reinterpret_cast<const float4 *>(Bs + (wn * 64 + t * 32 + li) * GB_LD + kk + lg * 4);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].x, bv[tn].x, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].y, bv[tn].y, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].z, bv[tn].z, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm].w, bv[tn].w, acc[tm][tn], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_slice();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++) {
+            const int col = bn0 + wn * 64 + tn * 32 + li;
+            if (col >= N) continue;
+            const float b = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = bm0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                if (row < M) {
+                    float v = acc[tm][tn][r];
+                    if (a.bias) v += b;
+                    v = apply_act(v, a.act);
+                    if (a.resid) v = a.resid[(size_t)row * a.ldr + col] + v;
+                    a.Y[(size_t)row * a.ldy + col] = v;
+                }
+            }
+        }
+}
+
+// Plain fp32 FMA reference kernel (one thread per output, sequential k like the
+// reference's non-BLAS loop, voxtral_kernels.c:103-114).  Used for the start-up MFMA
+// layout self-test, for odd shapes (K % 32 != 0) and as a cross-check in the tests.
+__global__ __launch_bounds__(256) void k_gemm_scalar(const GemmArgs a) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (m >= a.M || n >= a.N) return;
+    const float *x = a.X + (size_t)m * a.ldx;
+    const uint16_t *w = a.W + (size_t)n * a.K;
+    float acc = 0.f;
+    for (int k = 0; k < a.K; k++) acc = fmaf(x[k], bf16_to_f32(w[k]), acc);
+    if (a.bias) acc += a.bias[n];
+    acc = apply_act(acc, a.act);
+    if (a.resid) acc = a.resid[(size_t)m * a.ldr + n] + acc;
+    a.Y[(size_t)m * a.ldy + n] = acc;
+}
+
+}  // namespace vox

@@ -1,0 +1,246 @@
+// vox_gemv.h — decode-time (M = 1) bf16-weight matrix-vector kernels for gfx950.
+//
+// Replaces bf16_matvec_fused (voxtral_kernels.c:154-195) and everything the reference
+// wraps around it per decoder step (voxtral_decoder.c:653-704): RMSNorm, ada scaling,
+// RoPE, KV append, residual adds, SwiGLU gating, tied-embedding logits and argmax are
+// fused into the prologue / epilogue of the GEMV that produces or consumes them.
+//
+// Roofline: HBM.  2 FLOP per 2-byte weight; algorithmic bytes = N*K*2 per launch.
+// Layout: W row-major [N, K] bf16 exactly as stored in the safetensors file.  One
+// wave owns RPW consecutive rows; the 64 lanes stride the row in 16-byte pieces
+// (8 bf16), so a wave-instruction reads 1 KiB of contiguous weights (fully coalesced,
+// non-temporal: every weight byte is touched once per token).  x (K floats) is staged
+// once per block in LDS as f32 after the fused normalisation; fp32 FMA accumulation,
+// butterfly reduction across the wave => same arithmetic as the oracle up to the
+// summation order.  Deterministic: no atomics, fixed reduction trees.
+#pragma once
+#include "vox_common.h"
+
+namespace vox {
+
+enum { PRO_NONE = 0, PRO_RMS = 1 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3, EPI_LOGITS = 4 };
+
+struct GemvArgs {
+    const uint16_t *W;     // [N, K]
+    const uint16_t *W2;    // EPI_SWIGLU: up-projection rows (w3) [N, K]
+    const float *x;        // [K]
+    const float *norm_w;   // PRO_RMS: [K]
+    const float *ada;      // PRO_RMS: optional [K] (x_norm *= 1 + ada), voxtral_decoder.c:679-682
+    float eps;
+    float *y;              // EPI_STORE/RESID/SWIGLU/LOGITS: [N]; EPI_QKV: q buffer [q_rows]
+    const float *bias;     // optional [N] (EPI_STORE / EPI_RESID)
+    int N, K;
+    // EPI_QKV
+    int q_rows, k_rows;    // rows [0,q_rows) -> q, [q_rows, q_rows+k_rows) -> K cache, rest -> V cache
+    int head_dim;
+    const float *rope;     // [head_dim/2][2] cos,sin for the current position
+    float *kcache, *vcache;  // this layer's ring: [kv_cap][kv_dim]
+    int kv_cap, kv_dim;
+    const DecState *st;
+    // EPI_LOGITS
+    float *blk_val;
+    int *blk_idx;
+};
+
+template <int PRO, int EPI, int RPW>
+__global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *xs = smem;                 // [K]
+    float *red = smem + a.K;          // [16] scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, N = a.N;
+
+    // ---- prologue: stage x in LDS, optionally RMS-normalised --------------------
+    float ss = 0.f;
+    for (int i = tid * 4; i < K; i += 256 * 4) {
+        float4 v = *reinterpret_cast<const float4 *>(a.x + i);
+        if (PRO == PRO_RMS) ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        *reinterpret_cast<float4 *>(xs + i) = v;
+    }
+    if (PRO == PRO_RMS) {
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        const float inv = 1.0f / sqrtf(tot / (float)K + a.eps);   // voxtral_kernels.c:356-357
+        for (int i = tid * 4; i < K; i += 256 * 4) {
+            float4 v = *reinterpret_cast<float4 *>(xs + i);
+            const float4 w = *reinterpret_cast<const float4 *>(a.norm_w + i);
+            v.x = v.x * inv * w.x; v.y = v.y * inv * w.y; v.z = v.z * inv * w.z; v.w = v.w * inv * w.w;
+            if (a.ada) {
+                const float4 s = *reinterpret_cast<const float4 *>(a.ada + i);
+                v.x *= (1.0f + s.x); v.y *= (1.0f + s.y); v.z *= (1.0f + s.z); v.w *= (1.0f + s.w);
+            }
+            *reinterpret_cast<float4 *>(xs + i) = v;
+        }
+    }
+    __syncthreads();
+
+    const int nchunks = K >> 3;
+    constexpr int NMAT = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int RPB = 4 * RPW;      // rows per block iteration
+    float best_v = -3.0e38f;
+    int best_i = 0x7fffffff;
+
+    for (int r0 = (blockIdx.x * 4 + wave) * RPW; r0 < N; r0 += gridDim.x * RPB) {
+        float acc[NMAT][RPW];
+        const uint4 *wp[NMAT][RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const int row = min(r0 + r, N - 1);   // clamp: duplicates are discarded below
+            wp[0][r] = reinterpret_cast<const uint4 *>(a.W + (size_t)row * K);
+            if constexpr (NMAT == 2) wp[1][r] = reinterpret_cast<const uint4 *>(a.W2 + (size_t)row * K);
+#pragma unroll
+            for (int m = 0; m < NMAT; m++) acc[m][r] = 0.f;
+        }
+#pragma unroll 2
+        for (int c = lane; c < nchunks; c += 64) {
+            uint4 w[NMAT][RPW];
+#pragma unroll
+            for (int m = 0; m < NMAT; m++)
+#pragma unroll
+                for (int r = 0; r < RPW; r++) w[m][r] = ld_stream(wp[m][r] + c);
+            const float4 x0 = *reinterpret_cast<const float4 *>(xs + c * 8);
+            const float4 x1 = *reinterpret_cast<const float4 *>(xs + c * 8 + 4);
+#pragma unroll
+            for (int m = 0; m < NMAT; m++)
+#pragma unroll
+                for (int r = 0; r < RPW; r++) acc[m][r] = dot8_bf16(w[m][r], x0, x1, acc[m][r]);
+        }
+#pragma unroll
+        for (int m = 0; m < NMAT; m++)
+#pragma unroll
+            for (int r = 0; r < RPW; r++) acc[m][r] = wave_sum(acc[m][r]);
+
+        // ---- epilogue (lane 0 of the wave owns the RPW results) -------------------
+        if (lane == 0) {
+            if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
+#pragma unroll
+                for (int r = 0; r < RPW; r++) {
+                    const int row = r0 + r;
+                    if (row < N) {
+                        float v = acc[0][r];
+                        if (a.bias) v += a.bias[row];
+                        if (EPI == EPI_RESID) v = a.y[row] + v;    // x += proj (voxtral_decoder.c:676,689)
+                        a.y[row] = v;
+                    }
+                }
+            } else if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+                for (int r = 0; r < RPW; r++) {
+                    const int row = r0 + r;
+                    if (row < N) a.y[row] = silu(acc[0][r]) * acc[1][r];  // voxtral_decoder.c:684-687
+                }
+            } else if constexpr (EPI == EPI_QKV) {
+                // rows come in (even, odd) pairs = one RoPE pair (voxtral_kernels.c:502-526)
+                const int slot = a.st->pos % a.kv_cap;
+                const int qk_rows = a.q_rows + a.k_rows;
+#pragma unroll
+                for (int r = 0; r < RPW; r += 2) {
+                    const int row = r0 + r;
+                    if (row + 1 < N) {
+                        float o0 = acc[0][r], o1 = acc[0][r + 1];
+                        if (row < qk_rows) {
+                            const int d = (row % a.head_dim) >> 1;
+                            const float c = a.rope[2 * d], s = a.rope[2 * d + 1];
+                            const float x0 = o0, x1 = o1;
+                            o0 = x0 * c - x1 * s;
+                            o1 = x0 * s + x1 * c;
+                        }
+                        float *dst;
+                        if (row < a.q_rows) dst = a.y + row;
+                        else if (row < qk_rows) dst = a.kcache + (size_t)slot * a.kv_dim + (row - a.q_rows);
+                        else dst = a.vcache + (size_t)slot * a.kv_dim + (row - qk_rows);
+                        dst[0] = o0;
+                        dst[1] = o1;
+                    }
+                }
+            } else if constexpr (EPI == EPI_LOGITS) {
+#pragma unroll
+                for (int r = 0; r < RPW; r++) {
+                    const int row = r0 + r;
+                    if (row < N) {
+                        const float v = acc[0][r];
+                        a.y[row] = v;
+                        // strict '>' scan => lowest index wins ties (voxtral_decoder.c:697-704)
+                        if (v > best_v || (v == best_v && row < best_i)) { best_v = v; best_i = row; }
+                    }
+                }
+            }
+        }
+    }
+
+    if (EPI == EPI_LOGITS) {
+        __syncthreads();
+        float *rv = red;
+        int *ri = reinterpret_cast<int *>(red + 4);
+        if (lane == 0) { rv[wave] = best_v; ri[wave] = best_i; }
+        __syncthreads();
+        if (tid == 0) {
+            float bv = rv[0]; int bi = ri[0];
+            for (int w = 1; w < 4; w++)
+                if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+            a.blk_val[blockIdx.x] = bv;
+            a.blk_idx[blockIdx.x] = bi;
+        }
+    }
+}
+
+// Final argmax over the per-block partials + decoder cursor advance.
+// One block of 256 threads.
+__global__ __launch_bounds__(256) void k_argmax_finish(const float *blk_val, const int *blk_idx, int nblk,
+                                                       DecState *st, int *tokens_out, int eos_token,
+                                                       int advance) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int tid = threadIdx.x;
+    float bv = -3.0e38f; int bi = 0x7fffffff;
+    for (int i = tid; i < nblk; i += 256) {
+        const float v = blk_val[i]; const int ix = blk_idx[i];
+        if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+    }
+    sv[tid] = bv; si[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float v = sv[tid + s]; const int ix = si[tid + s];
+            if (v > sv[tid] || (v == sv[tid] && ix < si[tid])) { sv[tid] = v; si[tid] = ix; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int tok = si[0];
+        if (!st->stop) {
+            tokens_out[st->n_out] = tok;
+            st->n_out += 1;
+            st->token = tok;
+            if (advance) { st->pos += 1; st->adapter_row += 1; }
+            if (tok == eos_token) st->stop = 1;
+        }
+    }
+}
+
+// Start of a decode step: RoPE row for the current position and (optionally) the
+// step embedding  x = adapter[row] + f32(tok_emb[prev])  (voxtral.c:1057-1061).
+// inv_freq[d] = 1/powf(theta, 2d/dim) is computed on the host exactly like
+// vox_compute_rope_freqs (voxtral_kernels.c:488-500); angle = (float)pos * inv_freq
+// is the same single fp32 multiply, cosf/sinf are the accurate (range-reduced) forms.
+__global__ __launch_bounds__(256) void k_step_begin(const DecState *st, const float *inv_freq, int half_dim,
+                                                    float *rope, float *x, const float *adapter,
+                                                    const uint16_t *tok_emb, int dim, int build_embed) {
+    const int tid = threadIdx.x;
+    const float p = (float)st->pos;
+    for (int d = tid; d < half_dim; d += 256) {
+        const float ang = p * inv_freq[d];
+        rope[2 * d] = cosf(ang);
+        rope[2 * d + 1] = sinf(ang);
+    }
+    if (build_embed) {
+        const float *arow = adapter + (size_t)st->adapter_row * dim;
+        const uint16_t *erow = tok_emb + (size_t)st->token * dim;
+        for (int i = tid; i < dim; i += 256) x[i] = arow[i] + bf16_to_f32(erow[i]);
+    }
+}
+
+}  // namespace vox

@@ -1,0 +1,1197 @@
+// vox_hip_engine.hip — MI355X (gfx950) device engine behind the C-ABI in include/vox_hip.h.
+//
+// One engine = one GPU, one HIP stream, one active transcription stream (the reference is
+// single-stream too: voxtral.c:1227).  All weights stay resident in HBM as the bf16 bytes of
+// the safetensors file (QKV and W1;W3 of a layer are placed back to back so one launch
+// covers them); activations, both KV windows, the mel queue, the conv-stem boundary state
+// and the adapter rows live in HBM for the whole session — the host only moves audio
+// samples in and token ids out.
+//
+// Hot path = three device submissions, exactly where the reference crosses CPU->GPU in
+// its Metal build: encoder chunk, decoder prefill, decoder step.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <limits.h>
+#include <vector>
+#include <string>
+#include <algorithm>
+
+#include "../../include/vox_hip.h"
+#include "vox_common.h"
+#include "vox_gemv.h"
+#include "vox_gemm.h"
+#include "vox_misc.h"
+#include "vox_attn.h"
+
+using namespace vox;
+
+static thread_local std::string g_err;
+static void set_err(const char *what, hipError_t e, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "vox_hip: %s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_err = buf;
+    fprintf(stderr, "%s\n", buf);
+}
+#define HC(call)                                                        \
+    do {                                                                \
+        hipError_t _e = (call);                                         \
+        if (_e != hipSuccess) { set_err(#call, _e, __FILE__, __LINE__); return -1; } \
+    } while (0)
+#define HCV(call)                                                       \
+    do {                                                                \
+        hipError_t _e = (call);                                         \
+        if (_e != hipSuccess) { set_err(#call, _e, __FILE__, __LINE__); } \
+    } while (0)
+
+namespace {
+
+constexpr int DEC_SPLIT_KEYS = 128;     // keys per attention block in the decoder
+constexpr int DEC_RING_EXTRA = 1024;    // ring = window + 1024 rows (reference allocates 8192+seq+1024, voxtral_decoder.c:422)
+constexpr int PREFILL_CHUNK = 512;
+constexpr int MAX_RUN_STEPS = 4096;
+
+struct EncLayer {
+    uint16_t *wqkv = nullptr, *wo = nullptr, *w13 = nullptr, *w2 = nullptr;
+    float *bqkv = nullptr, *bo = nullptr, *b2 = nullptr, *n1 = nullptr, *n2 = nullptr;
+    float *kring = nullptr, *vring = nullptr;
+};
+struct DecLayer {
+    uint16_t *wqkv = nullptr, *wo = nullptr, *w13 = nullptr, *w2 = nullptr;
+    float *n1 = nullptr, *n2 = nullptr, *ada = nullptr;
+    float *kring = nullptr, *vring = nullptr;
+};
+
+struct Buf {   // growable device scratch
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct vox_hip_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    vox_hip_dims_t d{};
+    int enc_qd = 0, dec_qd = 0, dec_kvd = 0;
+    size_t mem_used = 0;
+    bool use_dpp = true, use_mfma = true;
+
+    // weights
+    uint16_t *tok_emb = nullptr, *conv0_w = nullptr, *conv1_w = nullptr, *adapter0 = nullptr, *adapter1 = nullptr;
+    float *conv0_b = nullptr, *conv1_b = nullptr, *enc_final_norm = nullptr, *dec_final_norm = nullptr;
+    std::vector<EncLayer> enc;
+    std::vector<DecLayer> dec;
+    // mel tables
+    float *hann = nullptr, *cosT = nullptr, *sinT = nullptr, *filtT = nullptr;
+    // rope
+    float *enc_inv_freq = nullptr, *dec_inv_freq = nullptr, *dec_rope = nullptr;
+
+    // encoder stream state
+    int enc_ring_cap = 0;
+    int enc_pos = 0;            // logical positions already encoded (= enc_kv_pos_offset + enc_kv_cache_len)
+    int mel_q = 0;              // frames waiting in conv_in0 rows [2, 2+mel_q)
+    int c0_carry = 0;           // 0/1 conv0 frame waiting for its stride-2 partner (voxtral.c:612-656)
+    int enc_res = 0;            // 0..3 encoder rows waiting for 4x alignment (voxtral.c:824-890)
+    Buf conv_in0, conv_in1, enc_out;   // see conv stem / alignment notes below
+    // large-M scratch
+    Buf sx, sxn, sqkv, sattn, sgu, sh, srope, sim2col, ssamples, smid, stmp_in, stmp_out, spart_o, spart_ml;
+
+    // adapter rows (linear buffer; physical row r <-> logical row adapter_row0 + r)
+    float *adapter = nullptr;
+    int64_t adapter_cap = 0, adapter_row0 = 0, adapter_total = 0, adapter_consumed = 0;
+
+    // decoder
+    int dec_ring_cap = 0;
+    int dec_pos = 0;            // logical positions stored (= kv_pos_offset + kv_cache_len)
+    DecState *d_st = nullptr;
+    float *dx = nullptr, *dq = nullptr, *dattn = nullptr, *dh = nullptr, *dlogits = nullptr;
+    float *blk_val = nullptr; int *blk_idx = nullptr; int logits_grid = 0;
+    int *d_tokens = nullptr;
+    float *dpart_o = nullptr, *dpart_ml = nullptr;   // decode-step split-K partials (max splits)
+    int dec_max_split = 0;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    vox_hip_timing_t timing{};
+};
+
+// ------------------------------------------------------------------------------------
+// memory helpers
+// ------------------------------------------------------------------------------------
+static int dmalloc(vox_hip_engine *e, void **p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    HC(hipMalloc(p, bytes));
+    e->mem_used += bytes;
+    return 0;
+}
+template <typename T>
+static int dalloc(vox_hip_engine *e, T **p, size_t n) { return dmalloc(e, (void **)p, n * sizeof(T)); }
+
+static int ensure(vox_hip_engine *e, Buf &b, size_t bytes) {
+    if (b.bytes >= bytes) return 0;
+    size_t nb = std::max(bytes, b.bytes * 3 / 2);
+    void *np = nullptr;
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMalloc(&np, nb));
+    if (b.p) { HC(hipFree(b.p)); e->mem_used -= b.bytes; }
+    b.p = np; b.bytes = nb; e->mem_used += nb;
+    return 0;
+}
+// ensure that keeps the first `keep` bytes (state-carrying buffers)
+static int ensure_keep(vox_hip_engine *e, Buf &b, size_t bytes, size_t keep) {
+    if (b.bytes >= bytes) return 0;
+    size_t nb = std::max(bytes, b.bytes * 3 / 2);
+    void *np = nullptr;
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMalloc(&np, nb));
+    HC(hipMemset(np, 0, nb));
+    if (b.p) {
+        if (keep) HC(hipMemcpy(np, b.p, std::min(keep, b.bytes), hipMemcpyDeviceToDevice));
+        HC(hipFree(b.p)); e->mem_used -= b.bytes;
+    }
+    b.p = np; b.bytes = nb; e->mem_used += nb;
+    return 0;
+}
+
+static inline int grid1d(size_t work, int per_block = 256, int cap = 4096) {
+    size_t g = (work + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > (size_t)cap) g = cap;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------
+// GEMM / GEMV launchers
+// ------------------------------------------------------------------------------------
+static void launch_gemm(vox_hip_engine *e, const float *X, int ldx, const uint16_t *W, float *Y, int ldy,
+                        int M, int N, int K, const float *bias, const float *resid, int ldr, int act,
+                        int force_scalar = 0) {
+    GemmArgs a{X, ldx, W, Y, ldy, M, N, K, bias, resid, ldr, act};
+    if (M <= 0 || N <= 0) return;
+    const bool aligned = (K % GB_K == 0) && (ldx % 4 == 0) && ((size_t)X % 16 == 0);
+    if (e->use_mfma && aligned && !force_scalar) {
+        dim3 grid((N + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M);
+        hipLaunchKernelGGL(k_gemm_mfma_f32, grid, dim3(256), GEMM_LDS_BYTES, e->stream, a);
+    } else {
+        dim3 grid((N + 63) / 64, (M + 3) / 4);
+        hipLaunchKernelGGL(k_gemm_scalar, grid, dim3(256), 0, e->stream, a);
+    }
+}
+
+static int gemv_grid(int N, int rpb) {
+    const int iters = (N + rpb - 1) / rpb;
+    const int maxg = 768;
+    const int per = (iters + maxg - 1) / maxg;
+    return (iters + per - 1) / per;
+}
+
+template <int PRO, int EPI, int RPW>
+static void launch_gemv(vox_hip_engine *e, const GemvArgs &a, int grid_override = 0) {
+    const int rpb = 4 * RPW;
+    const int grid = grid_override ? grid_override : gemv_grid(a.N, rpb);
+    const size_t lds = ((size_t)a.K + 16) * sizeof(float);
+    hipLaunchKernelGGL((k_gemv<PRO, EPI, RPW>), dim3(grid), dim3(256), lds, e->stream, a);
+}
+
+// Generic y = x.W^T (+bias) for M rows on device buffers; M == 1 streams the weights with
+// the GEMV kernel, M > 1 uses the MFMA GEMM.
+static void linear_dev(vox_hip_engine *e, float *y, int ldy, const float *x, int ldx, const uint16_t *W,
+                       const float *bias, int M, int K, int N, int act, const float *resid, int ldr,
+                       int impl) {
+    const bool gemv_ok = (K % 8 == 0) && act == ACT_NONE;
+    if ((impl == 1 || (impl == 0 && M == 1)) && gemv_ok) {
+        for (int m = 0; m < M; m++) {
+            GemvArgs a{};
+            a.W = W; a.x = x + (size_t)m * ldx; a.y = y + (size_t)m * ldy; a.bias = bias; a.N = N; a.K = K;
+            if (resid) {
+                if (resid != y) HCV(hipMemcpyAsync(a.y, resid + (size_t)m * ldr, (size_t)N * 4, hipMemcpyDeviceToDevice, e->stream));
+                launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
+            } else {
+                launch_gemv<PRO_NONE, EPI_STORE, 2>(e, a);
+            }
+        }
+    } else {
+        launch_gemm(e, x, ldx, W, y, ldy, M, N, K, bias, resid, ldr, act, impl == 3);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// engine lifetime
+// ------------------------------------------------------------------------------------
+extern "C" int vox_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" const char *vox_hip_last_error(void) { return g_err.c_str(); }
+extern "C" size_t vox_hip_memory_used(const vox_hip_engine_t *e) { return e ? e->mem_used : 0; }
+
+static int self_test(vox_hip_engine *e);
+
+static void host_inv_freq(std::vector<float> &f, int head_dim, float theta) {
+    // freq = 1 / powf(theta, 2d/dim) (voxtral_kernels.c:494), computed on the host with glibc so
+    // that the fp32 angle p*freq is bit-identical to the reference's.  The reference is built
+    // with -ffast-math, which rewrites 1/powf(t,e) as powf(t,-e): that form reproduces its RoPE
+    // tables bit-for-bit (checked against oracle/_ref), the literal form is 1 ulp off in places
+    // and an ulp of freq is up to 1e-3 in cos/sin at positions ~1e4.
+    f.resize(head_dim / 2);
+    for (int dd = 0; dd < head_dim / 2; dd++) f[dd] = powf(theta, -((float)(2 * dd) / (float)head_dim));
+}
+
+extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dims_t *dims) {
+    if (!dims) return nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_err = "vox_hip: no HIP device available (this library has no CPU fallback)";
+        fprintf(stderr, "%s\n", g_err.c_str());
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { g_err = "vox_hip: bad device index"; return nullptr; }
+    const vox_hip_dims_t &d = *dims;
+    if (d.enc_head_dim != 64 || d.dec_head_dim != 128 || d.dec_heads != 4 * d.dec_kv_heads ||
+        d.enc_dim % 32 || d.dec_dim % 32 || d.enc_hidden % 32 || d.dec_hidden % 32 || d.mel_bins > 256) {
+        g_err = "vox_hip: unsupported model geometry (need enc head_dim 64, dec head_dim 128, 4 q heads per kv head)";
+        fprintf(stderr, "%s\n", g_err.c_str());
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_err = "vox_hip: hipSetDevice failed"; return nullptr; }
+    vox_hip_engine *e = new vox_hip_engine();
+    e->device = device;
+    e->d = d;
+    e->enc_qd = d.enc_heads * d.enc_head_dim;
+    e->dec_qd = d.dec_heads * d.dec_head_dim;
+    e->dec_kvd = d.dec_kv_heads * d.dec_head_dim;
+    auto fail = [&]() -> vox_hip_engine_t * { vox_hip_engine_destroy(e); return nullptr; };
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return fail();
+    if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) return fail();
+
+    const size_t ED = d.enc_dim, EQ = e->enc_qd, EH = d.enc_hidden;
+    const size_t DD = d.dec_dim, DQ = e->dec_qd, DKV = e->dec_kvd, DH = d.dec_hidden;
+    int rc = 0;
+    rc |= dalloc(e, &e->tok_emb, (size_t)d.vocab * DD);
+    rc |= dalloc(e, &e->conv0_w, ED * d.mel_bins * 3);
+    rc |= dalloc(e, &e->conv1_w, ED * ED * 3);
+    rc |= dalloc(e, &e->adapter0, DD * ED * 4);
+    rc |= dalloc(e, &e->adapter1, DD * DD);
+    rc |= dalloc(e, &e->conv0_b, ED); rc |= dalloc(e, &e->conv1_b, ED);
+    rc |= dalloc(e, &e->enc_final_norm, ED); rc |= dalloc(e, &e->dec_final_norm, DD);
+    if (rc) return fail();
+
+    // encoder ring: window rounded up to a multiple of 64 plus slack
+    e->enc_ring_cap = ((d.enc_window + 63) / 64) * 64 + 64;
+    e->enc.resize(d.enc_layers);
+    for (auto &L : e->enc) {
+        rc |= dalloc(e, &L.wqkv, 3 * EQ * ED); rc |= dalloc(e, &L.wo, ED * EQ);
+        rc |= dalloc(e, &L.w13, 2 * EH * ED);  rc |= dalloc(e, &L.w2, ED * EH);
+        rc |= dalloc(e, &L.bqkv, 3 * EQ); rc |= dalloc(e, &L.bo, ED); rc |= dalloc(e, &L.b2, ED);
+        rc |= dalloc(e, &L.n1, ED); rc |= dalloc(e, &L.n2, ED);
+        rc |= dalloc(e, &L.kring, (size_t)e->enc_ring_cap * EQ);
+        rc |= dalloc(e, &L.vring, (size_t)e->enc_ring_cap * EQ);
+        if (rc) return fail();
+        HCV(hipMemsetAsync(L.bqkv, 0, 3 * EQ * 4, e->stream));   // wk has no bias (voxtral.h:63)
+    }
+    e->dec_ring_cap = d.dec_window + DEC_RING_EXTRA;
+    e->dec.resize(d.dec_layers);
+    for (auto &L : e->dec) {
+        rc |= dalloc(e, &L.wqkv, (DQ + 2 * DKV) * DD); rc |= dalloc(e, &L.wo, DD * DQ);
+        rc |= dalloc(e, &L.w13, 2 * DH * DD); rc |= dalloc(e, &L.w2, DD * DH);
+        rc |= dalloc(e, &L.n1, DD); rc |= dalloc(e, &L.n2, DD); rc |= dalloc(e, &L.ada, DD);
+        rc |= dalloc(e, &L.kring, (size_t)e->dec_ring_cap * DKV);
+        rc |= dalloc(e, &L.vring, (size_t)e->dec_ring_cap * DKV);
+        if (rc) return fail();
+        HCV(hipMemsetAsync(L.ada, 0, DD * 4, e->stream));
+    }
+    // mel tables + rope
+    rc |= dalloc(e, &e->hann, MEL_NFFT);
+    rc |= dalloc(e, &e->cosT, (size_t)MEL_NFFT * MEL_NFREQ);
+    rc |= dalloc(e, &e->sinT, (size_t)MEL_NFFT * MEL_NFREQ);
+    rc |= dalloc(e, &e->filtT, (size_t)MEL_NFREQ * d.mel_bins);
+    rc |= dalloc(e, &e->enc_inv_freq, d.enc_head_dim / 2);
+    rc |= dalloc(e, &e->dec_inv_freq, d.dec_head_dim / 2);
+    rc |= dalloc(e, &e->dec_rope, d.dec_head_dim);
+    if (rc) return fail();
+    {
+        std::vector<float> f;
+        host_inv_freq(f, d.enc_head_dim, d.rope_theta);
+        HCV(hipMemcpy(e->enc_inv_freq, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+        host_inv_freq(f, d.dec_head_dim, d.rope_theta);
+        HCV(hipMemcpy(e->dec_inv_freq, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+    }
+    // decoder step buffers
+    rc |= dalloc(e, &e->d_st, 1);
+    rc |= dalloc(e, &e->dx, DD); rc |= dalloc(e, &e->dq, DQ); rc |= dalloc(e, &e->dattn, DQ);
+    rc |= dalloc(e, &e->dh, DH); rc |= dalloc(e, &e->dlogits, (size_t)d.vocab);
+    e->logits_grid = gemv_grid(d.vocab, 16);
+    rc |= dalloc(e, &e->blk_val, e->logits_grid); rc |= dalloc(e, &e->blk_idx, e->logits_grid);
+    rc |= dalloc(e, &e->d_tokens, MAX_RUN_STEPS);
+    e->dec_max_split = (d.dec_window + DEC_SPLIT_KEYS - 1) / DEC_SPLIT_KEYS + 1;
+    rc |= dalloc(e, &e->dpart_o, (size_t)d.dec_heads * e->dec_max_split * d.dec_head_dim);
+    rc |= dalloc(e, &e->dpart_ml, (size_t)d.dec_heads * e->dec_max_split * 2);
+    if (rc) return fail();
+    HCV(hipMemsetAsync(e->d_st, 0, sizeof(DecState), e->stream));
+
+    // adapter buffer: 4096 rows to start with (grows / compacts on demand)
+    e->adapter_cap = 4096;
+    if (dalloc(e, &e->adapter, (size_t)e->adapter_cap * DD)) return fail();
+
+    // state-carrying stream buffers (zero = "start of sequence" left padding)
+    if (ensure_keep(e, e->conv_in0, (size_t)(2 + 1024) * d.mel_bins * 4, 0)) return fail();
+    if (ensure_keep(e, e->conv_in1, (size_t)(2 + 1024) * ED * 4, 0)) return fail();
+    if (ensure_keep(e, e->enc_out, (size_t)(3 + 512) * ED * 4, 0)) return fail();
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail();
+    if (self_test(e) != 0) return fail();
+    return e;
+}
+
+extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    auto F = [](void *p) { if (p) hipFree(p); };
+    F(e->tok_emb); F(e->conv0_w); F(e->conv1_w); F(e->adapter0); F(e->adapter1);
+    F(e->conv0_b); F(e->conv1_b); F(e->enc_final_norm); F(e->dec_final_norm);
+    for (auto &L : e->enc) { F(L.wqkv); F(L.wo); F(L.w13); F(L.w2); F(L.bqkv); F(L.bo); F(L.b2); F(L.n1); F(L.n2); F(L.kring); F(L.vring); }
+    for (auto &L : e->dec) { F(L.wqkv); F(L.wo); F(L.w13); F(L.w2); F(L.n1); F(L.n2); F(L.ada); F(L.kring); F(L.vring); }
+    F(e->hann); F(e->cosT); F(e->sinT); F(e->filtT); F(e->enc_inv_freq); F(e->dec_inv_freq); F(e->dec_rope);
+    F(e->d_st); F(e->dx); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
+    F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter);
+    Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
+                   &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml};
+    for (Buf *b : bufs) F(b->p);
+    if (e->ev0) hipEventDestroy(e->ev0);
+    if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+// ------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------
+extern "C" int vox_hip_upload_bf16(vox_hip_engine_t *e, int tensor, int layer, const uint16_t *src, size_t n) {
+    if (!e || !src) return -1;
+    HC(hipSetDevice(e->device));
+    const vox_hip_dims_t &d = e->d;
+    const size_t ED = d.enc_dim, EQ = e->enc_qd, EH = d.enc_hidden;
+    const size_t DD = d.dec_dim, DQ = e->dec_qd, DKV = e->dec_kvd, DH = d.dec_hidden;
+    uint16_t *dst = nullptr; size_t expect = 0;
+    const bool enc_l = layer >= 0 && layer < d.enc_layers, dec_l = layer >= 0 && layer < d.dec_layers;
+    switch (tensor) {
+        case VOXT_TOK_EMB: dst = e->tok_emb; expect = (size_t)d.vocab * DD; break;
+        case VOXT_CONV0_W: dst = e->conv0_w; expect = ED * d.mel_bins * 3; break;
+        case VOXT_CONV1_W: dst = e->conv1_w; expect = ED * ED * 3; break;
+        case VOXT_ADAPTER0: dst = e->adapter0; expect = DD * ED * 4; break;
+        case VOXT_ADAPTER1: dst = e->adapter1; expect = DD * DD; break;
+        case VOXT_ENC_WQ: if (enc_l) { dst = e->enc[layer].wqkv; expect = EQ * ED; } break;
+        case VOXT_ENC_WK: if (enc_l) { dst = e->enc[layer].wqkv + EQ * ED; expect = EQ * ED; } break;
+        case VOXT_ENC_WV: if (enc_l) { dst = e->enc[layer].wqkv + 2 * EQ * ED; expect = EQ * ED; } break;
+        case VOXT_ENC_WO: if (enc_l) { dst = e->enc[layer].wo; expect = ED * EQ; } break;
+        case VOXT_ENC_W1: if (enc_l) { dst = e->enc[layer].w13; expect = EH * ED; } break;
+        case VOXT_ENC_W3: if (enc_l) { dst = e->enc[layer].w13 + EH * ED; expect = EH * ED; } break;
+        case VOXT_ENC_W2: if (enc_l) { dst = e->enc[layer].w2; expect = ED * EH; } break;
+        case VOXT_DEC_WQ: if (dec_l) { dst = e->dec[layer].wqkv; expect = DQ * DD; } break;
+        case VOXT_DEC_WK: if (dec_l) { dst = e->dec[layer].wqkv + DQ * DD; expect = DKV * DD; } break;
+        case VOXT_DEC_WV: if (dec_l) { dst = e->dec[layer].wqkv + (DQ + DKV) * DD; expect = DKV * DD; } break;
+        case VOXT_DEC_WO: if (dec_l) { dst = e->dec[layer].wo; expect = DD * DQ; } break;
+        case VOXT_DEC_W1: if (dec_l) { dst = e->dec[layer].w13; expect = DH * DD; } break;
+        case VOXT_DEC_W3: if (dec_l) { dst = e->dec[layer].w13 + DH * DD; expect = DH * DD; } break;
+        case VOXT_DEC_W2: if (dec_l) { dst = e->dec[layer].w2; expect = DD * DH; } break;
+        default: break;
+    }
+    if (!dst || expect != n) {
+        char b[160]; snprintf(b, sizeof b, "vox_hip_upload_bf16: tensor %d layer %d: got %zu elems, expected %zu", tensor, layer, n, expect);
+        g_err = b; fprintf(stderr, "%s\n", b);
+        return -1;
+    }
+    HC(hipMemcpy(dst, src, n * 2, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int vox_hip_upload_f32(vox_hip_engine_t *e, int tensor, int layer, const float *src, size_t n) {
+    if (!e || !src) return -1;
+    HC(hipSetDevice(e->device));
+    const vox_hip_dims_t &d = e->d;
+    const size_t ED = d.enc_dim, EQ = e->enc_qd, DD = d.dec_dim;
+    float *dst = nullptr; size_t expect = 0;
+    const bool enc_l = layer >= 0 && layer < d.enc_layers, dec_l = layer >= 0 && layer < d.dec_layers;
+    switch (tensor) {
+        case VOXT_CONV0_B: dst = e->conv0_b; expect = ED; break;
+        case VOXT_CONV1_B: dst = e->conv1_b; expect = ED; break;
+        case VOXT_ENC_FINAL_NORM: dst = e->enc_final_norm; expect = ED; break;
+        case VOXT_DEC_FINAL_NORM: dst = e->dec_final_norm; expect = DD; break;
+        case VOXT_ENC_BQ: if (enc_l) { dst = e->enc[layer].bqkv; expect = EQ; } break;
+        case VOXT_ENC_BV: if (enc_l) { dst = e->enc[layer].bqkv + 2 * EQ; expect = EQ; } break;
+        case VOXT_ENC_BO: if (enc_l) { dst = e->enc[layer].bo; expect = ED; } break;
+        case VOXT_ENC_B2: if (enc_l) { dst = e->enc[layer].b2; expect = ED; } break;
+        case VOXT_ENC_ATTN_NORM: if (enc_l) { dst = e->enc[layer].n1; expect = ED; } break;
+        case VOXT_ENC_FFN_NORM: if (enc_l) { dst = e->enc[layer].n2; expect = ED; } break;
+        case VOXT_DEC_ATTN_NORM: if (dec_l) { dst = e->dec[layer].n1; expect = DD; } break;
+        case VOXT_DEC_FFN_NORM: if (dec_l) { dst = e->dec[layer].n2; expect = DD; } break;
+        case VOXT_DEC_ADA_SCALE: if (dec_l) { dst = e->dec[layer].ada; expect = DD; } break;
+        default: break;
+    }
+    if (!dst || expect != n) {
+        char b[160]; snprintf(b, sizeof b, "vox_hip_upload_f32: tensor %d layer %d: got %zu elems, expected %zu", tensor, layer, n, expect);
+        g_err = b; fprintf(stderr, "%s\n", b);
+        return -1;
+    }
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMemcpy(dst, src, n * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int vox_hip_upload_mel_tables(vox_hip_engine_t *e, const float *filters, const float *hann,
+                                         const float *dft_cos, const float *dft_sin) {
+    if (!e) return -1;
+    HC(hipSetDevice(e->device));
+    const int MB = e->d.mel_bins;
+    std::vector<float> cT((size_t)MEL_NFFT * MEL_NFREQ), sT((size_t)MEL_NFFT * MEL_NFREQ), fT((size_t)MEL_NFREQ * MB);
+    for (int k = 0; k < MEL_NFREQ; k++)
+        for (int n = 0; n < MEL_NFFT; n++) {
+            cT[(size_t)n * MEL_NFREQ + k] = dft_cos[(size_t)k * MEL_NFFT + n];
+            sT[(size_t)n * MEL_NFREQ + k] = dft_sin[(size_t)k * MEL_NFFT + n];
+        }
+    for (int m = 0; m < MB; m++)
+        for (int k = 0; k < MEL_NFREQ; k++) fT[(size_t)k * MB + m] = filters[(size_t)m * MEL_NFREQ + k];
+    HC(hipMemcpy(e->hann, hann, MEL_NFFT * 4, hipMemcpyHostToDevice));
+    HC(hipMemcpy(e->cosT, cT.data(), cT.size() * 4, hipMemcpyHostToDevice));
+    HC(hipMemcpy(e->sinT, sT.data(), sT.size() * 4, hipMemcpyHostToDevice));
+    HC(hipMemcpy(e->filtT, fT.data(), fT.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// large-M transformer layer (encoder chunk rows / decoder prefill rows)
+// ------------------------------------------------------------------------------------
+struct RowsCfg {
+    int D, QD, KVD, H, heads, kv_heads, hd, window;
+    float eps;
+    bool is_enc;
+};
+
+static int ensure_rows_scratch(vox_hip_engine *e, int n, const RowsCfg &c) {
+    const size_t N3 = (size_t)c.QD + 2 * c.KVD;
+    if (ensure(e, e->sxn, (size_t)n * c.D * 4)) return -1;
+    if (ensure(e, e->sqkv, (size_t)n * N3 * 4)) return -1;
+    if (ensure(e, e->sattn, (size_t)n * c.QD * 4)) return -1;
+    if (ensure(e, e->sgu, (size_t)n * 2 * c.H * 4)) return -1;
+    if (ensure(e, e->sh, (size_t)n * c.H * 4)) return -1;
+    if (ensure(e, e->srope, (size_t)n * c.hd * 4)) return -1;
+    return 0;
+}
+
+// x: [n, D] device, updated in place.  pos0 = logical position of row 0.
+static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const RowsCfg &c,
+                          const uint16_t *wqkv, const float *bqkv, const uint16_t *wo, const float *bo,
+                          const uint16_t *w13, const uint16_t *w2, const float *b2,
+                          const float *n1, const float *n2, const float *ada,
+                          float *kring, float *vring, int ring_cap) {
+    float *xn = (float *)e->sxn.p, *qkv = (float *)e->sqkv.p, *attn = (float *)e->sattn.p;
+    float *gu = (float *)e->sgu.p, *h = (float *)e->sh.p, *tab = (float *)e->srope.p;
+    const int N3 = c.QD + 2 * c.KVD;
+    hipStream_t s = e->stream;
+    // 1. attention_norm
+    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, s, xn, c.D, x, c.D, n1, (const float *)nullptr, c.D, c.eps);
+    // 2. merged QKV projection (+ q/v bias on the encoder, voxtral_encoder.c:542-544)
+    launch_gemm(e, xn, c.D, wqkv, qkv, N3, n, N3, c.D, bqkv, nullptr, 0, ACT_NONE);
+    // 3. RoPE on q and k columns (table built once per chunk by the caller)
+    hipLaunchKernelGGL(k_rope_apply, dim3(grid1d((size_t)n * (c.QD + c.KVD) / 2)), dim3(256), 0, s,
+                       qkv, N3, n, c.QD + c.KVD, c.hd, tab);
+    // 4. attention over [window tail in the ring] + [this chunk]
+    const float scale = 1.0f / sqrtf((float)c.hd);
+    if (c.is_enc) {
+        AttnArgs a{};
+        a.out = attn; a.ldo = c.QD; a.q = qkv; a.ldq = N3; a.n_q = n; a.qpos0 = pos0;
+        a.kB = qkv + c.QD; a.vB = qkv + c.QD + c.KVD; a.ldB = N3; a.posB0 = pos0; a.last_key = pos0 + n - 1;
+        a.kA = kring; a.vA = vring; a.capA = ring_cap; a.ldA = c.KVD;
+        a.n_heads = c.heads; a.n_kv_heads = c.kv_heads; a.scale = scale; a.window = c.window; a.st = nullptr;
+        hipLaunchKernelGGL((k_attn_rows<64>), dim3((n + 127) / 128, c.heads), dim3(128), 0, s, a);
+        // keep the last min(n, window) rows for the next chunk
+        const int keep = std::min(n, c.window);
+        hipLaunchKernelGGL(k_ring_append, dim3(grid1d((size_t)keep * c.KVD / 4)), dim3(256), 0, s,
+                           kring, vring, ring_cap, c.KVD, qkv, N3, c.QD, c.QD + c.KVD, n - keep, keep, pos0 + n - keep);
+    } else {
+        hipLaunchKernelGGL(k_ring_append, dim3(grid1d((size_t)n * c.KVD / 4)), dim3(256), 0, s,
+                           kring, vring, ring_cap, c.KVD, qkv, N3, c.QD, c.QD + c.KVD, 0, n, pos0);
+        const int max_len = std::min(pos0 + n, c.window);
+        const int nsplit = (max_len + DEC_SPLIT_KEYS - 1) / DEC_SPLIT_KEYS;
+        AttnArgs a{};
+        a.out = attn; a.ldo = c.QD; a.q = qkv; a.ldq = N3; a.n_q = n; a.qpos0 = pos0;
+        a.kB = nullptr; a.vB = nullptr; a.ldB = 0; a.posB0 = INT_MAX; a.last_key = pos0 + n - 1;
+        a.kA = kring; a.vA = vring; a.capA = ring_cap; a.ldA = c.KVD;
+        a.n_heads = c.heads; a.n_kv_heads = c.kv_heads; a.scale = scale; a.window = c.window; a.st = nullptr;
+        a.split_keys = DEC_SPLIT_KEYS;
+        if (nsplit > 1) {
+            if (ensure(e, e->spart_o, (size_t)n * c.heads * nsplit * c.hd * 4)) return -1;
+            if (ensure(e, e->spart_ml, (size_t)n * c.heads * nsplit * 2 * 4)) return -1;
+            a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
+        }
+        if (e->use_dpp)
+            hipLaunchKernelGGL((k_attn_dec<128, 4, true>), dim3(c.kv_heads, nsplit, n), dim3(256), 0, s, a, nsplit);
+        else
+            hipLaunchKernelGGL((k_attn_dec<128, 4, false>), dim3(c.kv_heads, nsplit, n), dim3(256), 0, s, a, nsplit);
+        if (nsplit > 1)
+            hipLaunchKernelGGL((k_attn_combine<128>), dim3(c.heads, n), dim3(128), 0, s, attn, c.QD,
+                               (const float *)a.part_o, (const float *)a.part_ml, c.heads, nsplit);
+    }
+    // 5. x += attn.Wo^T (+bo)
+    launch_gemm(e, attn, c.QD, wo, x, c.D, n, c.D, c.QD, bo, x, c.D, ACT_NONE);
+    // 6. ffn_norm (+ ada scaling on the decoder)
+    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, s, xn, c.D, x, c.D, n2, ada, c.D, c.eps);
+    // 7. SwiGLU: merged W1;W3 GEMM, gate, W2 (+b2) + residual
+    launch_gemm(e, xn, c.D, w13, gu, 2 * c.H, n, 2 * c.H, c.D, nullptr, nullptr, 0, ACT_NONE);
+    hipLaunchKernelGGL(k_silu_mul, dim3(grid1d((size_t)n * c.H / 4)), dim3(256), 0, s, h, gu, n, c.H);
+    launch_gemm(e, h, c.H, w2, x, c.D, n, c.D, c.H, b2, x, c.D, ACT_NONE);
+    return 0;
+}
+
+static RowsCfg enc_cfg(const vox_hip_engine *e) {
+    const vox_hip_dims_t &d = e->d;
+    return RowsCfg{d.enc_dim, e->enc_qd, e->enc_qd, d.enc_hidden, d.enc_heads, d.enc_heads, d.enc_head_dim,
+                   d.enc_window, d.enc_eps, true};
+}
+static RowsCfg dec_cfg(const vox_hip_engine *e) {
+    const vox_hip_dims_t &d = e->d;
+    return RowsCfg{d.dec_dim, e->dec_qd, e->dec_kvd, d.dec_hidden, d.dec_heads, d.dec_kv_heads, d.dec_head_dim,
+                   d.dec_window, d.dec_eps, false};
+}
+
+// Encoder transformer on device rows x[n, enc_dim] (in place), then final norm into out.
+static int encoder_rows_dev(vox_hip_engine *e, float *x, int n, float *out) {
+    const RowsCfg c = enc_cfg(e);
+    if (ensure_rows_scratch(e, n, c)) return -1;
+    hipLaunchKernelGGL(k_rope_table, dim3(grid1d((size_t)n * c.hd / 2)), dim3(256), 0, e->stream,
+                       (float *)e->srope.p, e->enc_inv_freq, e->enc_pos, n, c.hd / 2);
+    for (int l = 0; l < e->d.enc_layers; l++) {
+        EncLayer &L = e->enc[l];
+        if (run_layer_rows(e, x, n, e->enc_pos, c, L.wqkv, L.bqkv, L.wo, L.bo, L.w13, L.w2, L.b2, L.n1, L.n2,
+                           nullptr, L.kring, L.vring, e->enc_ring_cap)) return -1;
+    }
+    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, e->stream, out, c.D, x, c.D, e->enc_final_norm,
+                       (const float *)nullptr, c.D, c.eps);
+    e->enc_pos += n;
+    return 0;
+}
+
+// Adapter on device: in [m*4, enc_dim] contiguous == [m, 4*enc_dim]; out [m, dec_dim].
+static int adapter_dev(vox_hip_engine *e, const float *in, int m, float *out) {
+    const int DD = e->d.dec_dim, K0 = e->d.enc_dim * 4;
+    if (ensure(e, e->smid, (size_t)m * DD * 4)) return -1;
+    float *mid = (float *)e->smid.p;
+    launch_gemm(e, in, K0, e->adapter0, mid, DD, m, DD, K0, nullptr, nullptr, 0, ACT_GELU);
+    launch_gemm(e, mid, DD, e->adapter1, out, DD, m, DD, DD, nullptr, nullptr, 0, ACT_NONE);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// mel + conv stem (device-resident boundary state)
+//
+// conv_in0: [2 + cap, mel_bins]   rows 0,1 = last two mel frames of the previous chunk
+//                                 (zeros at stream start = causal left pad, voxtral.c:567-575),
+//                                 rows 2.. = queued frames not yet consumed.
+// conv_in1: [2 + cap, enc_dim]    row 0 = c0[2p-1] (last conv0 frame consumed by conv1, zero at
+//                                 start), row 1 = the odd conv0 frame carried over (if c0_carry),
+//                                 then this chunk's conv0 frames.
+// In global indices: c0[f] = gelu(W0.[mel[f-2],mel[f-1],mel[f]] + b0),
+//                    x[p]  = gelu(W1.[c0[2p-1],c0[2p],c0[2p+1]] + b1)   (voxtral.c:537-715)
+// ------------------------------------------------------------------------------------
+extern "C" int vox_hip_mel_frames(vox_hip_engine_t *e, const float *samples, int n_frames, float *out_mel, int to_queue) {
+    if (!e || n_frames <= 0) return e ? 0 : -1;
+    HC(hipSetDevice(e->device));
+    const int MB = e->d.mel_bins;
+    const size_t ns = (size_t)(n_frames - 1) * MEL_HOP + MEL_NFFT;
+    if (ensure(e, e->ssamples, ns * 4)) return -1;
+    HC(hipMemcpyAsync(e->ssamples.p, samples, ns * 4, hipMemcpyHostToDevice, e->stream));
+    float *dst;
+    if (to_queue) {
+        if (ensure_keep(e, e->conv_in0, (size_t)(2 + e->mel_q + n_frames) * MB * 4, (size_t)(2 + e->mel_q) * MB * 4)) return -1;
+        dst = (float *)e->conv_in0.p + (size_t)(2 + e->mel_q) * MB;
+    } else {
+        if (ensure(e, e->stmp_out, (size_t)n_frames * MB * 4)) return -1;
+        dst = (float *)e->stmp_out.p;
+    }
+    hipLaunchKernelGGL(k_mel_frames, dim3(n_frames), dim3(256), 0, e->stream, dst, MB, (const float *)e->ssamples.p,
+                       e->hann, e->cosT, e->sinT, e->filtT);
+    if (out_mel) HC(hipMemcpyAsync(out_mel, dst, (size_t)n_frames * MB * 4, hipMemcpyDeviceToHost, e->stream));
+    HC(hipStreamSynchronize(e->stream));   // the host sample buffer may be reused by the caller
+    if (to_queue) e->mel_q += n_frames;
+    return 0;
+}
+
+// Runs the conv stem over the first n frames of the mel queue. Output rows (device) are
+// written to xout [rows, enc_dim]; returns rows.
+static int conv_stem_dev(vox_hip_engine *e, int n, float **xout) {
+    const vox_hip_dims_t &d = e->d;
+    const int MB = d.mel_bins, ED = d.enc_dim;
+    hipStream_t s = e->stream;
+    *xout = nullptr;
+    if (n <= 0) return 0;
+    float *in0 = (float *)e->conv_in0.p;
+    if (ensure_keep(e, e->conv_in1, (size_t)(2 + n + 1) * ED * 4, (size_t)2 * ED * 4)) return -1;
+    float *in1 = (float *)e->conv_in1.p;
+    // conv0 as GEMM over im2col rows
+    if (ensure(e, e->sim2col, (size_t)n * std::max(MB, ED) * 3 * 4)) return -1;
+    float *col = (float *)e->sim2col.p;
+    hipLaunchKernelGGL(k_im2col3, dim3(grid1d((size_t)n * MB * 3)), dim3(256), 0, s, col, (const float *)in0, n, MB, 1);
+    float *c0_new = in1 + (size_t)(1 + e->c0_carry) * ED;
+    launch_gemm(e, col, MB * 3, e->conv0_w, c0_new, ED, n, ED, MB * 3, e->conv0_b, nullptr, 0, ACT_GELU);
+    // roll the mel history: rows 0,1 <- last two frames seen. n == 1 reproduces the
+    // reference's tail update, which zeroes the older slot (voxtral.c:604-609, tc == 1).
+    if (n >= 2) {
+        HC(hipMemcpyAsync(in0, in0 + (size_t)n * MB, (size_t)2 * MB * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        HC(hipMemsetAsync(in0, 0, (size_t)MB * 4, s));
+        HC(hipMemcpyAsync(in0 + MB, in0 + (size_t)2 * MB, (size_t)MB * 4, hipMemcpyDeviceToDevice, s));
+    }
+    // remaining queued frames (if any) slide to the front of the queue
+    const int left = e->mel_q - n;
+    if (left > 0) {
+        // non-overlapping when left <= n; otherwise go through scratch
+        if (left <= n) {
+            HC(hipMemcpyAsync(in0 + (size_t)2 * MB, in0 + (size_t)(2 + n) * MB, (size_t)left * MB * 4, hipMemcpyDeviceToDevice, s));
+        } else {
+            if (ensure(e, e->stmp_in, (size_t)left * MB * 4)) return -1;
+            HC(hipMemcpyAsync(e->stmp_in.p, in0 + (size_t)(2 + n) * MB, (size_t)left * MB * 4, hipMemcpyDeviceToDevice, s));
+            HC(hipMemcpyAsync(in0 + (size_t)2 * MB, e->stmp_in.p, (size_t)left * MB * 4, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    e->mel_q = left;
+
+    // conv1 (stride 2) over [hist | carry | new]
+    const int pending = e->c0_carry + n;
+    const int nq = pending / 2;
+    if (nq > 0) {
+        hipLaunchKernelGGL(k_im2col3, dim3(grid1d((size_t)nq * ED * 3)), dim3(256), 0, s, col, (const float *)in1, nq, ED, 2);
+        if (ensure(e, e->sx, (size_t)nq * ED * 4)) return -1;
+        float *x = (float *)e->sx.p;
+        launch_gemm(e, col, ED * 3, e->conv1_w, x, ED, nq, ED, ED * 3, e->conv1_b, nullptr, 0, ACT_GELU);
+        *xout = x;
+        // history row <- last consumed conv0 frame; carry row <- odd leftover
+        HC(hipMemcpyAsync(in1, in1 + (size_t)(2 * nq) * ED, (size_t)ED * 4, hipMemcpyDeviceToDevice, s));
+        if (pending & 1)
+            HC(hipMemcpyAsync(in1 + ED, in1 + (size_t)(2 * nq + 1) * ED, (size_t)ED * 4, hipMemcpyDeviceToDevice, s));
+    }
+    // (nq == 0: the single pending frame already sits in the carry slot)
+    e->c0_carry = pending & 1;
+    return nq;
+}
+
+extern "C" int vox_hip_conv_stem(vox_hip_engine_t *e, const float *mel_new, int n_mel, float *out, int out_cap_rows) {
+    if (!e || n_mel <= 0) return e ? 0 : -1;
+    HC(hipSetDevice(e->device));
+    const int MB = e->d.mel_bins, ED = e->d.enc_dim;
+    if (ensure_keep(e, e->conv_in0, (size_t)(2 + e->mel_q + n_mel) * MB * 4, (size_t)(2 + e->mel_q) * MB * 4)) return -1;
+    HC(hipMemcpyAsync((float *)e->conv_in0.p + (size_t)(2 + e->mel_q) * MB, mel_new, (size_t)n_mel * MB * 4,
+                      hipMemcpyHostToDevice, e->stream));
+    e->mel_q += n_mel;
+    float *x = nullptr;
+    const int rows = conv_stem_dev(e, e->mel_q, &x);
+    if (rows < 0) return -1;
+    if (out && rows > 0) {
+        if (rows > out_cap_rows) { g_err = "vox_hip_conv_stem: output buffer too small"; return -1; }
+        HC(hipMemcpyAsync(out, x, (size_t)rows * ED * 4, hipMemcpyDeviceToHost, e->stream));
+    }
+    HC(hipStreamSynchronize(e->stream));
+    return rows;
+}
+
+// ------------------------------------------------------------------------------------
+// stage-level entry points on host buffers
+// ------------------------------------------------------------------------------------
+extern "C" int vox_hip_encoder_chunk(vox_hip_engine_t *e, const float *x_new, int new_len, float *out) {
+    if (!e || new_len <= 0) return -1;
+    HC(hipSetDevice(e->device));
+    const int ED = e->d.enc_dim;
+    if (ensure(e, e->stmp_in, (size_t)new_len * ED * 4)) return -1;
+    if (ensure(e, e->stmp_out, (size_t)new_len * ED * 4)) return -1;
+    HC(hipMemcpyAsync(e->stmp_in.p, x_new, (size_t)new_len * ED * 4, hipMemcpyHostToDevice, e->stream));
+    if (encoder_rows_dev(e, (float *)e->stmp_in.p, new_len, (float *)e->stmp_out.p)) return -1;
+    HC(hipMemcpyAsync(out, e->stmp_out.p, (size_t)new_len * ED * 4, hipMemcpyDeviceToHost, e->stream));
+    HC(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int vox_hip_adapter(vox_hip_engine_t *e, const float *enc_out, int enc_len, float *out) {
+    if (!e) return -1;
+    HC(hipSetDevice(e->device));
+    const int ED = e->d.enc_dim, DD = e->d.dec_dim;
+    const int m = enc_len / 4;
+    if (m <= 0) return 0;
+    if (ensure(e, e->stmp_in, (size_t)m * 4 * ED * 4)) return -1;
+    if (ensure(e, e->stmp_out, (size_t)m * DD * 4)) return -1;
+    HC(hipMemcpyAsync(e->stmp_in.p, enc_out, (size_t)m * 4 * ED * 4, hipMemcpyHostToDevice, e->stream));
+    if (adapter_dev(e, (const float *)e->stmp_in.p, m, (float *)e->stmp_out.p)) return -1;
+    HC(hipMemcpyAsync(out, e->stmp_out.p, (size_t)m * DD * 4, hipMemcpyDeviceToHost, e->stream));
+    HC(hipStreamSynchronize(e->stream));
+    return m;
+}
+
+// ------------------------------------------------------------------------------------
+// adapter buffer management
+// ------------------------------------------------------------------------------------
+static int adapter_reserve(vox_hip_engine *e, int64_t extra_rows) {
+    const int DD = e->d.dec_dim;
+    int64_t phys = e->adapter_total - e->adapter_row0;
+    if (phys + extra_rows <= e->adapter_cap) return 0;
+    // drop rows the decoder has already consumed (stream_adapter_compact, voxtral.c:718-731)
+    const int64_t dead = std::min(e->adapter_consumed - e->adapter_row0, phys);
+    if (dead > 0) {
+        const int64_t live = phys - dead;
+        HC(hipStreamSynchronize(e->stream));
+        if (live > 0) {
+            if (ensure(e, e->stmp_in, (size_t)live * DD * 4)) return -1;
+            HC(hipMemcpy(e->stmp_in.p, e->adapter + (size_t)dead * DD, (size_t)live * DD * 4, hipMemcpyDeviceToDevice));
+            HC(hipMemcpy(e->adapter, e->stmp_in.p, (size_t)live * DD * 4, hipMemcpyDeviceToDevice));
+        }
+        e->adapter_row0 += dead;
+        phys = live;
+        if (phys + extra_rows <= e->adapter_cap) return 0;
+    }
+    int64_t ncap = e->adapter_cap;
+    while (ncap < phys + extra_rows) ncap *= 2;
+    float *np = nullptr;
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMalloc((void **)&np, (size_t)ncap * DD * 4));
+    if (phys > 0) HC(hipMemcpy(np, e->adapter, (size_t)phys * DD * 4, hipMemcpyDeviceToDevice));
+    HC(hipFree(e->adapter));
+    e->mem_used += (size_t)(ncap - e->adapter_cap) * DD * 4;
+    e->adapter = np; e->adapter_cap = ncap;
+    return 0;
+}
+
+extern "C" int64_t vox_hip_adapter_rows(const vox_hip_engine_t *e) { return e ? e->adapter_total : 0; }
+extern "C" void *vox_hip_adapter_devptr(vox_hip_engine_t *e, int64_t *cap_rows) {
+    if (!e) return nullptr;
+    if (cap_rows) *cap_rows = e->adapter_cap;
+    return e->adapter;
+}
+extern "C" int vox_hip_adapter_read(vox_hip_engine_t *e, int64_t first_row, int n_rows, float *out) {
+    if (!e || n_rows <= 0) return -1;
+    HC(hipSetDevice(e->device));
+    if (first_row < e->adapter_row0 || first_row + n_rows > e->adapter_total) { g_err = "vox_hip_adapter_read: rows not resident"; return -1; }
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMemcpy(out, e->adapter + (size_t)(first_row - e->adapter_row0) * e->d.dec_dim,
+                 (size_t)n_rows * e->d.dec_dim * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int vox_hip_adapter_append(vox_hip_engine_t *e, const float *rows, int n_rows) {
+    if (!e || n_rows <= 0) return -1;
+    HC(hipSetDevice(e->device));
+    if (adapter_reserve(e, n_rows)) return -1;
+    HC(hipMemcpy(e->adapter + (size_t)(e->adapter_total - e->adapter_row0) * e->d.dec_dim, rows,
+                 (size_t)n_rows * e->d.dec_dim * 4, hipMemcpyHostToDevice));
+    e->adapter_total += n_rows;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// fused streaming encode: mel queue -> conv stem -> encoder -> 4x alignment -> adapter
+// enc_out buffer: [3 + cap, enc_dim]; rows (3-enc_res)..2 hold the carried rows so that
+// [carried | new] is contiguous (voxtral.c:824-890).
+// ------------------------------------------------------------------------------------
+extern "C" int vox_hip_stream_encode(vox_hip_engine_t *e, int n_mel, int *conv_rows, int *enc_residual) {
+    if (!e) return -1;
+    HC(hipSetDevice(e->device));
+    if (n_mel > e->mel_q) { g_err = "vox_hip_stream_encode: more frames requested than queued"; return -1; }
+    const int ED = e->d.enc_dim, DD = e->d.dec_dim;
+    hipStream_t s = e->stream;
+    HC(hipEventRecord(e->ev0, s));
+    float *x = nullptr;
+    const int nq = conv_stem_dev(e, n_mel, &x);
+    if (nq < 0) return -1;
+    if (conv_rows) *conv_rows = nq;
+    int new_tokens = 0;
+    if (nq > 0) {
+        if (ensure_keep(e, e->enc_out, (size_t)(3 + nq) * ED * 4, (size_t)3 * ED * 4)) return -1;
+        float *eo = (float *)e->enc_out.p;
+        if (encoder_rows_dev(e, x, nq, eo + (size_t)3 * ED)) return -1;
+        const int total = e->enc_res + nq;
+        const int usable = (total / 4) * 4, leftover = total - usable;
+        float *first = eo + (size_t)(3 - e->enc_res) * ED;
+        if (usable > 0) {
+            const int m = usable / 4;
+            if (adapter_reserve(e, m)) return -1;
+            float *dst = e->adapter + (size_t)(e->adapter_total - e->adapter_row0) * DD;
+            if (adapter_dev(e, first, m, dst)) return -1;
+            e->adapter_total += m;
+            new_tokens = m;
+        }
+        // carry the trailing rows: move them to rows (3-leftover)..2, ascending order
+        for (int i = 0; i < leftover; i++) {
+            float *src = first + (size_t)(usable + i) * ED;
+            float *dst = eo + (size_t)(3 - leftover + i) * ED;
+            if (src != dst) HC(hipMemcpyAsync(dst, src, (size_t)ED * 4, hipMemcpyDeviceToDevice, s));
+        }
+        e->enc_res = leftover;
+    }
+    if (enc_residual) *enc_residual = e->enc_res;
+    HC(hipEventRecord(e->ev1, s));
+    HC(hipStreamSynchronize(s));
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    e->timing.encode_ms += ms;
+    return new_tokens;
+}
+
+// ------------------------------------------------------------------------------------
+// decoder
+// ------------------------------------------------------------------------------------
+static int decoder_prefill_dev(vox_hip_engine *e, float *x, int n) {
+    const RowsCfg c = dec_cfg(e);
+    for (int off = 0; off < n; off += PREFILL_CHUNK) {
+        const int m = std::min(PREFILL_CHUNK, n - off);
+        if (ensure_rows_scratch(e, m, c)) return -1;
+        hipLaunchKernelGGL(k_rope_table, dim3(grid1d((size_t)m * c.hd / 2)), dim3(256), 0, e->stream,
+                           (float *)e->srope.p, e->dec_inv_freq, e->dec_pos, m, c.hd / 2);
+        float *xc = x + (size_t)off * c.D;
+        for (int l = 0; l < e->d.dec_layers; l++) {
+            DecLayer &L = e->dec[l];
+            if (run_layer_rows(e, xc, m, e->dec_pos, c, L.wqkv, nullptr, L.wo, nullptr, L.w13, L.w2, nullptr,
+                               L.n1, L.n2, L.ada, L.kring, L.vring, e->dec_ring_cap)) return -1;
+        }
+        e->dec_pos += m;
+    }
+    return 0;
+}
+
+extern "C" int vox_hip_decoder_prefill(vox_hip_engine_t *e, const float *embeds, int seq_len) {
+    if (!e || seq_len <= 0) return -1;
+    HC(hipSetDevice(e->device));
+    const int DD = e->d.dec_dim;
+    if (ensure(e, e->sx, (size_t)seq_len * DD * 4)) return -1;
+    HC(hipMemcpyAsync(e->sx.p, embeds, (size_t)seq_len * DD * 4, hipMemcpyHostToDevice, e->stream));
+    if (decoder_prefill_dev(e, (float *)e->sx.p, seq_len)) return -1;
+    HC(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// Enqueue one decode step. kv_pos = logical position of this token (host mirror of st->pos).
+static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *logits_dst, int eos, int advance) {
+    const vox_hip_dims_t &d = e->d;
+    const int DD = d.dec_dim, DQ = e->dec_qd, DKV = e->dec_kvd, DH = d.dec_hidden, HD = d.dec_head_dim;
+    hipStream_t s = e->stream;
+    const float *adapter_base = e->adapter;
+    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(256), 0, s, (const DecState *)e->d_st, (const float *)e->dec_inv_freq,
+                       HD / 2, e->dec_rope, e->dx, adapter_base, (const uint16_t *)e->tok_emb, DD, build_embed ? 1 : 0);
+    const int kv_len = std::min(kv_pos + 1, d.dec_window);
+    const int nsplit = (kv_len + DEC_SPLIT_KEYS - 1) / DEC_SPLIT_KEYS;
+    const float scale = 1.0f / sqrtf((float)HD);
+    for (int l = 0; l < d.dec_layers; l++) {
+        DecLayer &L = e->dec[l];
+        {   // RMSNorm -> merged QKV GEMV -> RoPE -> KV append   (voxtral_decoder.c:656-665)
+            GemvArgs a{};
+            a.W = L.wqkv; a.x = e->dx; a.norm_w = L.n1; a.ada = nullptr; a.eps = d.dec_eps; a.y = e->dq;
+            a.N = DQ + 2 * DKV; a.K = DD; a.q_rows = DQ; a.k_rows = DKV; a.head_dim = HD; a.rope = e->dec_rope;
+            a.kcache = L.kring; a.vcache = L.vring; a.kv_cap = e->dec_ring_cap; a.kv_dim = DKV; a.st = e->d_st;
+            launch_gemv<PRO_RMS, EPI_QKV, 4>(e, a);
+        }
+        {   // attention over the KV window (voxtral_decoder.c:667-673)
+            AttnArgs a{};
+            a.out = e->dattn; a.ldo = DQ; a.q = e->dq; a.ldq = DQ; a.n_q = 1; a.qpos0 = 0;
+            a.posB0 = INT_MAX; a.last_key = 0; a.kA = L.kring; a.vA = L.vring; a.capA = e->dec_ring_cap; a.ldA = DKV;
+            a.n_heads = d.dec_heads; a.n_kv_heads = d.dec_kv_heads; a.scale = scale; a.window = d.dec_window;
+            a.st = e->d_st; a.split_keys = DEC_SPLIT_KEYS; a.part_o = e->dpart_o; a.part_ml = e->dpart_ml;
+            if (e->use_dpp)
+                hipLaunchKernelGGL((k_attn_dec<128, 4, true>), dim3(d.dec_kv_heads, nsplit, 1), dim3(256), 0, s, a, nsplit);
+            else
+                hipLaunchKernelGGL((k_attn_dec<128, 4, false>), dim3(d.dec_kv_heads, nsplit, 1), dim3(256), 0, s, a, nsplit);
+            if (nsplit > 1)
+                hipLaunchKernelGGL((k_attn_combine<128>), dim3(d.dec_heads, 1), dim3(128), 0, s, e->dattn, DQ,
+                                   (const float *)e->dpart_o, (const float *)e->dpart_ml, d.dec_heads, nsplit);
+        }
+        {   // x += attn.Wo^T
+            GemvArgs a{};
+            a.W = L.wo; a.x = e->dattn; a.y = e->dx; a.N = DD; a.K = DQ;
+            launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
+        }
+        {   // RMSNorm * (1+ada) -> silu(W1 x) * (W3 x)
+            GemvArgs a{};
+            a.W = L.w13; a.W2 = L.w13 + (size_t)DH * DD; a.x = e->dx; a.norm_w = L.n2; a.ada = L.ada; a.eps = d.dec_eps;
+            a.y = e->dh; a.N = DH; a.K = DD;
+            launch_gemv<PRO_RMS, EPI_SWIGLU, 2>(e, a);
+        }
+        {   // x += h.W2^T
+            GemvArgs a{};
+            a.W = L.w2; a.x = e->dh; a.y = e->dx; a.N = DD; a.K = DH;
+            launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
+        }
+    }
+    {   // final norm -> tied-embedding logits -> per-block argmax (voxtral_decoder.c:694-704)
+        GemvArgs a{};
+        a.W = e->tok_emb; a.x = e->dx; a.norm_w = e->dec_final_norm; a.eps = d.dec_eps; a.y = logits_dst;
+        a.N = d.vocab; a.K = DD; a.blk_val = e->blk_val; a.blk_idx = e->blk_idx;
+        launch_gemv<PRO_RMS, EPI_LOGITS, 4>(e, a, e->logits_grid);
+        hipLaunchKernelGGL(k_argmax_finish, dim3(1), dim3(256), 0, s, (const float *)e->blk_val, (const int *)e->blk_idx,
+                           e->logits_grid, e->d_st, e->d_tokens, eos, advance);
+    }
+}
+
+static int set_state(vox_hip_engine *e, int pos, int token, int64_t adapter_phys_row) {
+    DecState st{};
+    st.pos = pos; st.token = token; st.n_out = 0; st.stop = 0; st.adapter_row = adapter_phys_row;
+    HC(hipMemcpyAsync(e->d_st, &st, sizeof st, hipMemcpyHostToDevice, e->stream));
+    HC(hipStreamSynchronize(e->stream));   // st lives on the host stack
+    return 0;
+}
+
+extern "C" int vox_hip_decoder_step(vox_hip_engine_t *e, const float *embed, float *logits) {
+    if (!e || !embed) return -1;
+    HC(hipSetDevice(e->device));
+    HC(hipMemcpyAsync(e->dx, embed, (size_t)e->d.dec_dim * 4, hipMemcpyHostToDevice, e->stream));
+    if (set_state(e, e->dec_pos, 0, 0)) return -1;
+    enqueue_step(e, e->dec_pos, false, e->dlogits, -1, 1);
+    int tok = -1;
+    HC(hipMemcpyAsync(&tok, e->d_tokens, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    if (logits) HC(hipMemcpyAsync(logits, e->dlogits, (size_t)e->d.vocab * 4, hipMemcpyDeviceToHost, e->stream));
+    HC(hipStreamSynchronize(e->stream));
+    e->dec_pos += 1;
+    return tok;
+}
+
+extern "C" int vox_hip_decoder_prefill_stream(vox_hip_engine_t *e, int64_t first_row, int n_prompt, int bos, int pad, float *logits) {
+    if (!e || n_prompt < 1) return -1;
+    HC(hipSetDevice(e->device));
+    if (first_row < e->adapter_row0 || first_row + n_prompt > e->adapter_total) { g_err = "prefill_stream: adapter rows not resident"; return -1; }
+    const int DD = e->d.dec_dim;
+    hipStream_t s = e->stream;
+    HC(hipEventRecord(e->ev0, s));
+    if (ensure(e, e->sx, (size_t)n_prompt * DD * 4)) return -1;
+    float *x = (float *)e->sx.p;
+    const float *arow = e->adapter + (size_t)(first_row - e->adapter_row0) * DD;
+    hipLaunchKernelGGL(k_embed_prompt, dim3(grid1d((size_t)n_prompt * DD)), dim3(256), 0, s, x, arow,
+                       (const uint16_t *)e->tok_emb, n_prompt, DD, bos, pad);
+    // the last prompt row is the first decode step's input (voxtral.c:1005-1012)
+    HC(hipMemcpyAsync(e->dx, x + (size_t)(n_prompt - 1) * DD, (size_t)DD * 4, hipMemcpyDeviceToDevice, s));
+    if (n_prompt > 1 && decoder_prefill_dev(e, x, n_prompt - 1)) return -1;
+    if (set_state(e, e->dec_pos, 0, 0)) return -1;
+    enqueue_step(e, e->dec_pos, false, e->dlogits, -1, 1);
+    int tok = -1;
+    HC(hipMemcpyAsync(&tok, e->d_tokens, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (logits) HC(hipMemcpyAsync(logits, e->dlogits, (size_t)e->d.vocab * 4, hipMemcpyDeviceToHost, s));
+    HC(hipEventRecord(e->ev1, s));
+    HC(hipStreamSynchronize(s));
+    float ms = 0.f; hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    e->timing.prefill_ms += ms;
+    e->dec_pos += 1;
+    e->adapter_consumed = std::max(e->adapter_consumed, first_row + n_prompt);
+    return tok;
+}
+
+extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n_steps, int prev_token, int eos_token,
+                                   int *tokens_out, float *logits_out) {
+    if (!e || n_steps <= 0 || !tokens_out) return -1;
+    HC(hipSetDevice(e->device));
+    if (first_row < e->adapter_row0 || first_row + n_steps > e->adapter_total) { g_err = "decoder_run: adapter rows not resident"; return -1; }
+    hipStream_t s = e->stream;
+    const size_t V = e->d.vocab;
+    int done = 0;
+    HC(hipEventRecord(e->ev0, s));
+    while (done < n_steps) {
+        const int batch = std::min(n_steps - done, logits_out ? 64 : MAX_RUN_STEPS);
+        if (set_state(e, e->dec_pos, prev_token, first_row + done - e->adapter_row0)) return -1;
+        float *lg = e->dlogits;
+        if (logits_out) {
+            if (ensure(e, e->stmp_out, (size_t)batch * V * 4)) return -1;
+            lg = (float *)e->stmp_out.p;
+        }
+        for (int i = 0; i < batch; i++)
+            enqueue_step(e, e->dec_pos + i, true, logits_out ? lg + (size_t)i * V : lg, eos_token, 1);
+        DecState st{};
+        HC(hipMemcpyAsync(&st, e->d_st, sizeof st, hipMemcpyDeviceToHost, s));
+        HC(hipStreamSynchronize(s));
+        const int got = st.n_out;
+        if (got > 0) HC(hipMemcpy(tokens_out + done, e->d_tokens, (size_t)got * sizeof(int), hipMemcpyDeviceToHost));
+        if (logits_out && got > 0)
+            HC(hipMemcpy(logits_out + (size_t)done * V, lg, (size_t)got * V * 4, hipMemcpyDeviceToHost));
+        e->dec_pos += got;
+        done += got;
+        if (got > 0) prev_token = tokens_out[done - 1];
+        if (st.stop || got < batch) break;
+    }
+    HC(hipEventRecord(e->ev1, s));
+    HC(hipStreamSynchronize(s));
+    float ms = 0.f; hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    e->timing.decode_ms += ms;
+    e->timing.decode_steps += done;
+    e->adapter_consumed = std::max(e->adapter_consumed, first_row + done);
+    return done;
+}
+
+// ------------------------------------------------------------------------------------
+// state
+// ------------------------------------------------------------------------------------
+extern "C" void vox_hip_reset_encoder(vox_hip_engine_t *e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    e->enc_pos = 0; e->mel_q = 0; e->c0_carry = 0; e->enc_res = 0;
+    // zero the causal-history rows (start-of-sequence padding)
+    if (e->conv_in0.p) hipMemsetAsync(e->conv_in0.p, 0, (size_t)2 * e->d.mel_bins * 4, e->stream);
+    if (e->conv_in1.p) hipMemsetAsync(e->conv_in1.p, 0, (size_t)2 * e->d.enc_dim * 4, e->stream);
+    hipStreamSynchronize(e->stream);
+}
+extern "C" void vox_hip_reset_decoder(vox_hip_engine_t *e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    e->dec_pos = 0;
+    e->adapter_total = 0; e->adapter_row0 = 0; e->adapter_consumed = 0;
+}
+extern "C" void vox_hip_reset_decoder_kv(vox_hip_engine_t *e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    e->dec_pos = 0;
+}
+extern "C" int vox_hip_decoder_kv_len(const vox_hip_engine_t *e) { return e ? e->dec_pos : 0; }
+extern "C" int vox_hip_mel_queue_len(const vox_hip_engine_t *e) { return e ? e->mel_q : 0; }
+extern "C" void vox_hip_sync(vox_hip_engine_t *e) { if (e) { hipSetDevice(e->device); hipStreamSynchronize(e->stream); } }
+extern "C" void vox_hip_get_timing(const vox_hip_engine_t *e, vox_hip_timing_t *t) { if (e && t) *t = e->timing; }
+extern "C" void vox_hip_reset_timing(vox_hip_engine_t *e) { if (e) e->timing = vox_hip_timing_t{}; }
+
+// ------------------------------------------------------------------------------------
+// kernel-level test / bench surface
+// ------------------------------------------------------------------------------------
+extern "C" int vox_hip_linear_bf16(vox_hip_engine_t *e, float *y, const float *x, const uint16_t *w, const float *bias,
+                                   int M, int K, int N, int impl) {
+    if (!e) return -1;
+    HC(hipSetDevice(e->device));
+    float *dx = nullptr, *dy = nullptr, *db = nullptr; uint16_t *dw = nullptr;
+    HC(hipMalloc((void **)&dx, (size_t)M * K * 4)); HC(hipMalloc((void **)&dy, (size_t)M * N * 4));
+    HC(hipMalloc((void **)&dw, (size_t)N * K * 2));
+    HC(hipMemcpy(dx, x, (size_t)M * K * 4, hipMemcpyHostToDevice));
+    HC(hipMemcpy(dw, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    if (bias) { HC(hipMalloc((void **)&db, (size_t)N * 4)); HC(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice)); }
+    linear_dev(e, dy, N, dx, K, dw, db, M, K, N, ACT_NONE, nullptr, 0, impl);
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipGetLastError());
+    HC(hipMemcpy(y, dy, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(dy); hipFree(dw); if (db) hipFree(db);
+    return 0;
+}
+
+extern "C" int vox_hip_causal_attention(vox_hip_engine_t *e, float *out, const float *q, const float *k, const float *v,
+                                        int seq_q, int seq_k, int n_heads, int n_kv_heads, int head_dim, float scale,
+                                        int window, int q_offset) {
+    if (!e) return -1;
+    HC(hipSetDevice(e->device));
+    const size_t qn = (size_t)seq_q * n_heads * head_dim, kn = (size_t)seq_k * n_kv_heads * head_dim;
+    float *dq, *dk, *dv, *dout;
+    HC(hipMalloc((void **)&dq, qn * 4)); HC(hipMalloc((void **)&dout, qn * 4));
+    HC(hipMalloc((void **)&dk, kn * 4)); HC(hipMalloc((void **)&dv, kn * 4));
+    HC(hipMemcpy(dq, q, qn * 4, hipMemcpyHostToDevice));
+    HC(hipMemcpy(dk, k, kn * 4, hipMemcpyHostToDevice));
+    HC(hipMemcpy(dv, v, kn * 4, hipMemcpyHostToDevice));
+    AttnArgs a{};
+    a.out = dout; a.ldo = n_heads * head_dim; a.q = dq; a.ldq = n_heads * head_dim; a.n_q = seq_q; a.qpos0 = q_offset;
+    a.kB = dk; a.vB = dv; a.ldB = n_kv_heads * head_dim; a.posB0 = 0; a.last_key = seq_k - 1;
+    a.kA = dk; a.vA = dv; a.capA = 1 << 30; a.ldA = n_kv_heads * head_dim;
+    a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.scale = scale; a.window = window > 0 ? window : (1 << 30);
+    a.st = nullptr; a.split_keys = DEC_SPLIT_KEYS;
+    float *po = nullptr, *pml = nullptr;
+    int rc = 0;
+    if (head_dim == 64) {
+        hipLaunchKernelGGL((k_attn_rows<64>), dim3((seq_q + 127) / 128, n_heads), dim3(128), 0, e->stream, a);
+    } else if (head_dim == 128 && n_heads == 4 * n_kv_heads) {
+        const int max_len = std::min(q_offset + seq_q, a.window);
+        const int nsplit = std::max(1, (std::min(max_len, seq_k) + DEC_SPLIT_KEYS - 1) / DEC_SPLIT_KEYS);
+        if (nsplit > 1) {
+            HC(hipMalloc((void **)&po, (size_t)seq_q * n_heads * nsplit * head_dim * 4));
+            HC(hipMalloc((void **)&pml, (size_t)seq_q * n_heads * nsplit * 2 * 4));
+            a.part_o = po; a.part_ml = pml;
+        }
+        if (e->use_dpp)
+            hipLaunchKernelGGL((k_attn_dec<128, 4, true>), dim3(n_kv_heads, nsplit, seq_q), dim3(256), 0, e->stream, a, nsplit);
+        else
+            hipLaunchKernelGGL((k_attn_dec<128, 4, false>), dim3(n_kv_heads, nsplit, seq_q), dim3(256), 0, e->stream, a, nsplit);
+        if (nsplit > 1)
+            hipLaunchKernelGGL((k_attn_combine<128>), dim3(n_heads, seq_q), dim3(128), 0, e->stream, dout, a.ldo,
+                               (const float *)po, (const float *)pml, n_heads, nsplit);
+    } else {
+        g_err = "vox_hip_causal_attention: unsupported head geometry"; rc = -1;
+    }
+    if (!rc) {
+        HC(hipStreamSynchronize(e->stream));
+        HC(hipGetLastError());
+        HC(hipMemcpy(out, dout, qn * 4, hipMemcpyDeviceToHost));
+    }
+    hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout); if (po) hipFree(po); if (pml) hipFree(pml);
+    return rc;
+}
+
+// Times `iters` full decode steps (all layers + logits + argmax) on the resident weights at a
+// given KV length, without touching the stream state seen by the host API. Returns seconds/step.
+extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int kv_len) {
+    if (!e || iters <= 0) return -1.0;
+    if (hipSetDevice(e->device) != hipSuccess) return -1.0;
+    const int saved_pos = e->dec_pos;
+    int pos = std::max(0, kv_len - 1);
+    hipMemsetAsync(e->dx, 0, (size_t)e->d.dec_dim * 4, e->stream);
+    // make sure one adapter row exists for the embedding gather
+    if (e->adapter_total - e->adapter_row0 < 1) {
+        hipMemsetAsync(e->adapter, 0, (size_t)e->d.dec_dim * 4, e->stream);
+    }
+    if (set_state(e, pos, 1, 0)) return -1.0;
+    for (int i = 0; i < 3; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);   // warm-up
+    hipEventRecord(e->ev0, e->stream);
+    for (int i = 0; i < iters; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);
+    hipEventRecord(e->ev1, e->stream);
+    hipStreamSynchronize(e->stream);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    e->dec_pos = saved_pos;
+    return (double)ms * 1e-3 / iters;
+}
+
+// ------------------------------------------------------------------------------------
+// start-up self-tests: DPP row reduction and MFMA fragment layout, each against a plain
+// reference kernel.  A mismatch is loud and switches to the slower-but-plain HIP variant;
+// nothing ever falls back to the CPU.
+// ------------------------------------------------------------------------------------
+static int self_test(vox_hip_engine *e) {
+    // (1) DPP
+    float *d_a = nullptr, *d_b = nullptr;
+    HC(hipMalloc((void **)&d_a, 64 * 4)); HC(hipMalloc((void **)&d_b, 64 * 4));
+    hipLaunchKernelGGL(k_dpp_selftest, dim3(1), dim3(64), 0, e->stream, d_a, d_b);
+    float ha[64], hb[64];
+    HC(hipMemcpyAsync(ha, d_a, sizeof ha, hipMemcpyDeviceToHost, e->stream));
+    HC(hipMemcpyAsync(hb, d_b, sizeof hb, hipMemcpyDeviceToHost, e->stream));
+    HC(hipStreamSynchronize(e->stream));
+    bool ok = true;
+    for (int i = 0; i < 64; i++) if (fabsf(ha[i] - hb[i]) > 1e-3f * fabsf(hb[i])) ok = false;
+    if (!ok) { fprintf(stderr, "vox_hip: WARNING DPP row reduction self-test failed; using __shfl reductions\n"); e->use_dpp = false; }
+    hipFree(d_a); hipFree(d_b);
+    if (getenv("VOX_HIP_NO_DPP")) e->use_dpp = false;
+
+    // (2) MFMA GEMM vs scalar kernel on an asymmetric 160 x 192 x 64 problem
+    const int M = 160, N = 192, K = 64;
+    std::vector<float> hx((size_t)M * K), hy1((size_t)M * N), hy2((size_t)M * N), hbias(N);
+    std::vector<uint16_t> hw((size_t)N * K);
+    for (int m = 0; m < M; m++) for (int k = 0; k < K; k++) hx[(size_t)m * K + k] = 0.01f * (float)((m * 7 + k * 3) % 29 - 14) + 0.001f * m;
+    for (int n = 0; n < N; n++) for (int k = 0; k < K; k++) {
+        float v = 0.02f * (float)((n * 5 + k * 11) % 23 - 11) - 0.0005f * n;
+        uint32_t u; memcpy(&u, &v, 4); hw[(size_t)n * K + k] = (uint16_t)(u >> 16);
+    }
+    for (int n = 0; n < N; n++) hbias[n] = 0.1f * (float)(n % 7);
+    float *dx, *dy1, *dy2, *dbias; uint16_t *dw;
+    HC(hipMalloc((void **)&dx, hx.size() * 4)); HC(hipMalloc((void **)&dy1, hy1.size() * 4)); HC(hipMalloc((void **)&dy2, hy2.size() * 4));
+    HC(hipMalloc((void **)&dw, hw.size() * 2)); HC(hipMalloc((void **)&dbias, N * 4));
+    HC(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    HC(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    HC(hipMemcpy(dbias, hbias.data(), N * 4, hipMemcpyHostToDevice));
+    launch_gemm(e, dx, K, dw, dy1, N, M, N, K, dbias, nullptr, 0, ACT_NONE, 0);
+    launch_gemm(e, dx, K, dw, dy2, N, M, N, K, dbias, nullptr, 0, ACT_NONE, 1);
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMemcpy(hy1.data(), dy1, hy1.size() * 4, hipMemcpyDeviceToHost));
+    HC(hipMemcpy(hy2.data(), dy2, hy2.size() * 4, hipMemcpyDeviceToHost));
+    double maxd = 0;
+    for (size_t i = 0; i < hy1.size(); i++) maxd = std::max(maxd, (double)fabsf(hy1[i] - hy2[i]));
+    if (!(maxd < 1e-4)) {
+        fprintf(stderr, "vox_hip: WARNING MFMA GEMM self-test failed (max diff %g); using the scalar HIP GEMM\n", maxd);
+        e->use_mfma = false;
+    }
+    if (getenv("VOX_HIP_NO_MFMA")) e->use_mfma = false;
+    hipFree(dx); hipFree(dy1); hipFree(dy2); hipFree(dw); hipFree(dbias);
+    return 0;
+}

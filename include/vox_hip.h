@@ -172,6 +172,11 @@ int vox_hip_causal_attention(vox_hip_engine_t *e, float *out, const float *q, co
  * events on the engine stream (used by bench.py's roofline leg). */
 double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int kv_len);
 
+/* Per-kernel breakdown of one decode step: avg_us[9] / launches[9] indexed by
+ * {0 step_begin, 1 qkv gemv, 2 attention, 3 split-K combine, 4 wo gemv, 5 swiglu gemv,
+ *  6 w2 gemv, 7 logits gemv, 8 argmax}; HIP events on the engine stream. Returns s/step. */
+double vox_hip_profile_decode(vox_hip_engine_t *e, int iters, int kv_len, double *avg_us, int *launches);
+
 /* Timing of the last fused calls (HIP events on the engine stream), milliseconds. */
 typedef struct vox_hip_timing {
     double encode_ms, prefill_ms, decode_ms;

@@ -115,7 +115,26 @@ struct vox_hip_engine {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     vox_hip_timing_t timing{};
+    // per-kernel profiling of the decode step (HIP events between launches)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_kind;
+    size_t prof_used = 0;
 };
+
+enum { PK_BEGIN = 0, PK_QKV, PK_ATTN, PK_COMBINE, PK_WO, PK_SWIGLU, PK_W2, PK_LOGITS, PK_ARGMAX, PK_COUNT };
+
+static void prof_mark(vox_hip_engine *e, int kind) {
+    if (!e->prof_on) return;
+    if (e->prof_used == e->prof_ev.size()) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return;
+        e->prof_ev.push_back(ev);
+        e->prof_kind.push_back(kind);
+    }
+    e->prof_kind[e->prof_used] = kind;
+    hipEventRecord(e->prof_ev[e->prof_used++], e->stream);
+}
 
 // ------------------------------------------------------------------------------------
 // memory helpers
@@ -874,6 +893,7 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
     const float *adapter_base = e->adapter;
     hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(256), 0, s, (const DecState *)e->d_st, (const float *)e->dec_inv_freq,
                        HD / 2, e->dec_rope, e->dx, adapter_base, (const uint16_t *)e->tok_emb, DD, build_embed ? 1 : 0);
+    prof_mark(e, PK_BEGIN);
     const int kv_len = std::min(kv_pos + 1, d.dec_window);
     const int nsplit = (kv_len + DEC_SPLIT_KEYS - 1) / DEC_SPLIT_KEYS;
     const float scale = 1.0f / sqrtf((float)HD);
@@ -885,6 +905,7 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             a.N = DQ + 2 * DKV; a.K = DD; a.q_rows = DQ; a.k_rows = DKV; a.head_dim = HD; a.rope = e->dec_rope;
             a.kcache = L.kring; a.vcache = L.vring; a.kv_cap = e->dec_ring_cap; a.kv_dim = DKV; a.st = e->d_st;
             launch_gemv<PRO_RMS, EPI_QKV, 4>(e, a);
+            prof_mark(e, PK_QKV);
         }
         {   // attention over the KV window (voxtral_decoder.c:667-673)
             AttnArgs a{};
@@ -896,25 +917,31 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
                 hipLaunchKernelGGL((k_attn_dec<128, 4, true>), dim3(d.dec_kv_heads, nsplit, 1), dim3(256), 0, s, a, nsplit);
             else
                 hipLaunchKernelGGL((k_attn_dec<128, 4, false>), dim3(d.dec_kv_heads, nsplit, 1), dim3(256), 0, s, a, nsplit);
-            if (nsplit > 1)
+            prof_mark(e, PK_ATTN);
+            if (nsplit > 1) {
                 hipLaunchKernelGGL((k_attn_combine<128>), dim3(d.dec_heads, 1), dim3(128), 0, s, e->dattn, DQ,
                                    (const float *)e->dpart_o, (const float *)e->dpart_ml, d.dec_heads, nsplit);
+                prof_mark(e, PK_COMBINE);
+            }
         }
         {   // x += attn.Wo^T
             GemvArgs a{};
             a.W = L.wo; a.x = e->dattn; a.y = e->dx; a.N = DD; a.K = DQ;
             launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
+            prof_mark(e, PK_WO);
         }
         {   // RMSNorm * (1+ada) -> silu(W1 x) * (W3 x)
             GemvArgs a{};
             a.W = L.w13; a.W2 = L.w13 + (size_t)DH * DD; a.x = e->dx; a.norm_w = L.n2; a.ada = L.ada; a.eps = d.dec_eps;
             a.y = e->dh; a.N = DH; a.K = DD;
             launch_gemv<PRO_RMS, EPI_SWIGLU, 2>(e, a);
+            prof_mark(e, PK_SWIGLU);
         }
         {   // x += h.W2^T
             GemvArgs a{};
             a.W = L.w2; a.x = e->dh; a.y = e->dx; a.N = DD; a.K = DH;
             launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
+            prof_mark(e, PK_W2);
         }
     }
     {   // final norm -> tied-embedding logits -> per-block argmax (voxtral_decoder.c:694-704)
@@ -922,8 +949,10 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
         a.W = e->tok_emb; a.x = e->dx; a.norm_w = e->dec_final_norm; a.eps = d.dec_eps; a.y = logits_dst;
         a.N = d.vocab; a.K = DD; a.blk_val = e->blk_val; a.blk_idx = e->blk_idx;
         launch_gemv<PRO_RMS, EPI_LOGITS, 4>(e, a, e->logits_grid);
+        prof_mark(e, PK_LOGITS);
         hipLaunchKernelGGL(k_argmax_finish, dim3(1), dim3(256), 0, s, (const float *)e->blk_val, (const int *)e->blk_idx,
                            e->logits_grid, e->d_st, e->d_tokens, eos, advance);
+        prof_mark(e, PK_ARGMAX);
     }
 }
 
@@ -1142,6 +1171,45 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
     e->dec_pos = saved_pos;
     return (double)ms * 1e-3 / iters;
+}
+
+// Per-kernel average durations of the decode step, measured with HIP events recorded on the
+// engine stream between consecutive launches (event i+1 - event i is attributed to the kernel
+// launched in between).  avg_us[PK_COUNT], launches[PK_COUNT] (per step).  Returns seconds/step.
+extern "C" double vox_hip_profile_decode(vox_hip_engine_t *e, int iters, int kv_len, double *avg_us, int *launches) {
+    if (!e || iters <= 0) return -1.0;
+    if (hipSetDevice(e->device) != hipSuccess) return -1.0;
+    const int saved_pos = e->dec_pos;
+    const int pos = std::max(0, kv_len - 1);
+    hipMemsetAsync(e->dx, 0, (size_t)e->d.dec_dim * 4, e->stream);
+    if (e->adapter_total - e->adapter_row0 < 1) hipMemsetAsync(e->adapter, 0, (size_t)e->d.dec_dim * 4, e->stream);
+    if (set_state(e, pos, 1, 0)) return -1.0;
+    for (int i = 0; i < 2; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);
+    hipStreamSynchronize(e->stream);
+    double sum_us[PK_COUNT] = {0}; long cnt[PK_COUNT] = {0};
+    double total = 0;
+    for (int it = 0; it < iters; it++) {
+        e->prof_on = true; e->prof_used = 0;
+        prof_mark(e, -1);
+        enqueue_step(e, pos, true, e->dlogits, -1, 0);
+        e->prof_on = false;
+        hipStreamSynchronize(e->stream);
+        for (size_t i = 1; i < e->prof_used; i++) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e->prof_ev[i - 1], e->prof_ev[i]);
+            const int k = e->prof_kind[i];
+            if (k >= 0 && k < PK_COUNT) { sum_us[k] += ms * 1e3; cnt[k]++; }
+        }
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e->prof_ev[0], e->prof_ev[e->prof_used - 1]);
+        total += ms;
+    }
+    for (int k = 0; k < PK_COUNT; k++) {
+        if (avg_us) avg_us[k] = cnt[k] ? sum_us[k] / cnt[k] : 0.0;
+        if (launches) launches[k] = (int)(cnt[k] / iters);
+    }
+    e->dec_pos = saved_pos;
+    return total * 1e-3 / iters;
 }
 
 // ------------------------------------------------------------------------------------

@@ -149,6 +149,20 @@ int64_t vox_hip_adapter_rows(const vox_hip_engine_t *e);
 /* Device pointer of the adapter ring (for RCCL/torch interop) and its row capacity. */
 void *vox_hip_adapter_devptr(vox_hip_engine_t *e, int64_t *cap_rows);
 
+/* ---- multi-GPU encoder sharding (exact context parallelism) ------
+ * A rank owns encoder positions [pos0, pos0+n). Per layer it imports the layer's K/V of the
+ * window-1 positions before pos0 (received from its left neighbour over xGMI), runs the
+ * layer, and exports the K/V tail its right neighbour needs. Pointers are device pointers. */
+int vox_hip_shard_begin(vox_hip_engine_t *e, int n_mel, int discard_rows, int pos0);  /* conv stem on the queue; returns rows */
+int vox_hip_shard_layer(vox_hip_engine_t *e, int layer);
+int vox_hip_shard_kv_export(vox_hip_engine_t *e, int layer, int pos_first, int n, void *dst_dev);       /* [2][n][kv] */
+int vox_hip_shard_kv_import(vox_hip_engine_t *e, int layer, int pos_first, int n, const void *src_dev);
+int vox_hip_shard_end(vox_hip_engine_t *e, void *adapter_rows_dev);                  /* returns adapter rows written */
+int vox_hip_adapter_append_dev(vox_hip_engine_t *e, const void *rows_dev, int n_rows);
+void *vox_hip_device_alloc(vox_hip_engine_t *e, size_t bytes);
+void vox_hip_device_free(vox_hip_engine_t *e, void *p);
+int vox_hip_memcpy(vox_hip_engine_t *e, void *dst, const void *src, size_t bytes, int kind); /* 0 H2D, 1 D2H, 2 D2D */
+
 /* ---- state ---------------------------------------------------------------------- */
 void vox_hip_reset_encoder(vox_hip_engine_t *e);   /* mel queue, conv tails, encoder KV, 4x residual */
 void vox_hip_reset_decoder(vox_hip_engine_t *e);   /* decoder KV + adapter buffer */

@@ -115,6 +115,8 @@ struct vox_hip_engine {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     vox_hip_timing_t timing{};
+    // multi-GPU shard in flight (vox_hip_shard_*)
+    float *shard_x = nullptr; int shard_n = 0;
     // per-kernel profiling of the decode step (HIP events between launches)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -851,6 +853,120 @@ extern "C" int vox_hip_stream_encode(vox_hip_engine_t *e, int n_mel, int *conv_r
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
     e->timing.encode_ms += ms;
     return new_tokens;
+}
+
+// ------------------------------------------------------------------------------------
+// Multi-GPU encoder sharding (option E1: exact context parallelism).
+// Each rank owns a contiguous range of encoder positions.  All ranks walk the 32 layers;
+// before layer l a rank imports the layer-l K/V of the window-1 positions preceding its
+// range (sent by its left neighbour right after that neighbour finished layer l) into its
+// position-indexed ring, so attention sees exactly what a single GPU would.  The exchange
+// itself (RCCL send/recv over xGMI) is done by the caller on device pointers.
+// ------------------------------------------------------------------------------------
+
+extern "C" int vox_hip_shard_begin(vox_hip_engine_t *e, int n_mel, int discard_rows, int pos0) {
+    if (!e) return -1;
+    HC(hipSetDevice(e->device));
+    if (n_mel > e->mel_q) { g_err = "vox_hip_shard_begin: more frames requested than queued"; return -1; }
+    float *x = nullptr;
+    const int nq = conv_stem_dev(e, n_mel, &x);
+    if (nq < 0) return -1;
+    const int n = nq - discard_rows;
+    if (n <= 0) { g_err = "vox_hip_shard_begin: empty shard"; return -1; }
+    e->shard_x = x + (size_t)discard_rows * e->d.enc_dim;
+    e->shard_n = n;
+    e->enc_pos = pos0;
+    const RowsCfg c = enc_cfg(e);
+    if (ensure_rows_scratch(e, n, c)) return -1;
+    hipLaunchKernelGGL(k_rope_table, dim3(grid1d((size_t)n * c.hd / 2)), dim3(256), 0, e->stream,
+                       (float *)e->srope.p, e->enc_inv_freq, pos0, n, c.hd / 2);
+    return n;
+}
+
+extern "C" int vox_hip_shard_layer(vox_hip_engine_t *e, int layer) {
+    if (!e || layer < 0 || layer >= e->d.enc_layers || !e->shard_x) return -1;
+    HC(hipSetDevice(e->device));
+    const RowsCfg c = enc_cfg(e);
+    EncLayer &L = e->enc[layer];
+    return run_layer_rows(e, e->shard_x, e->shard_n, e->enc_pos, c, L.wqkv, L.bqkv, L.wo, L.bo, L.w13, L.w2, L.b2,
+                          L.n1, L.n2, nullptr, L.kring, L.vring, e->enc_ring_cap);
+}
+
+// K then V rows of positions [pos_first, pos_first+n) of `layer`: dst [2][n][kv_dim] (device).
+extern "C" int vox_hip_shard_kv_export(vox_hip_engine_t *e, int layer, int pos_first, int n, void *dst_dev) {
+    if (!e || layer < 0 || layer >= e->d.enc_layers || n <= 0) return -1;
+    HC(hipSetDevice(e->device));
+    const int kvd = e->enc_qd, cap = e->enc_ring_cap;
+    float *dst = (float *)dst_dev;
+    for (int i = 0; i < n;) {            // contiguous runs inside the ring
+        const int slot = (pos_first + i) % cap;
+        const int run = std::min(n - i, cap - slot);
+        HC(hipMemcpyAsync(dst + (size_t)i * kvd, e->enc[layer].kring + (size_t)slot * kvd, (size_t)run * kvd * 4, hipMemcpyDeviceToDevice, e->stream));
+        HC(hipMemcpyAsync(dst + (size_t)(n + i) * kvd, e->enc[layer].vring + (size_t)slot * kvd, (size_t)run * kvd * 4, hipMemcpyDeviceToDevice, e->stream));
+        i += run;
+    }
+    HC(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int vox_hip_shard_kv_import(vox_hip_engine_t *e, int layer, int pos_first, int n, const void *src_dev) {
+    if (!e || layer < 0 || layer >= e->d.enc_layers || n <= 0) return -1;
+    HC(hipSetDevice(e->device));
+    const int kvd = e->enc_qd, cap = e->enc_ring_cap;
+    if (n > cap) { g_err = "vox_hip_shard_kv_import: more rows than the ring holds"; return -1; }
+    const float *src = (const float *)src_dev;
+    for (int i = 0; i < n;) {
+        const int slot = (pos_first + i) % cap;
+        const int run = std::min(n - i, cap - slot);
+        HC(hipMemcpyAsync(e->enc[layer].kring + (size_t)slot * kvd, src + (size_t)i * kvd, (size_t)run * kvd * 4, hipMemcpyDeviceToDevice, e->stream));
+        HC(hipMemcpyAsync(e->enc[layer].vring + (size_t)slot * kvd, src + (size_t)(n + i) * kvd, (size_t)run * kvd * 4, hipMemcpyDeviceToDevice, e->stream));
+        i += run;
+    }
+    return 0;
+}
+
+// Final norm + adapter over the shard rows (shard_n must be a multiple of 4). Writes
+// [shard_n/4, dec_dim] rows to dst_dev (device) and returns the row count.
+extern "C" int vox_hip_shard_end(vox_hip_engine_t *e, void *dst_dev) {
+    if (!e || !e->shard_x || !dst_dev) return -1;
+    HC(hipSetDevice(e->device));
+    const int n = e->shard_n, ED = e->d.enc_dim;
+    if (n % 4) { g_err = "vox_hip_shard_end: shard rows must be a multiple of 4"; return -1; }
+    if (ensure(e, e->stmp_out, (size_t)n * ED * 4)) return -1;
+    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, e->stream, (float *)e->stmp_out.p, ED, e->shard_x, ED,
+                       e->enc_final_norm, (const float *)nullptr, ED, e->d.enc_eps);
+    if (adapter_dev(e, (const float *)e->stmp_out.p, n / 4, (float *)dst_dev)) return -1;
+    HC(hipStreamSynchronize(e->stream));
+    e->shard_x = nullptr; e->shard_n = 0;
+    return n / 4;
+}
+
+// Append adapter rows that already live in device memory (gathered over xGMI).
+extern "C" int vox_hip_adapter_append_dev(vox_hip_engine_t *e, const void *rows_dev, int n_rows) {
+    if (!e || n_rows <= 0) return -1;
+    HC(hipSetDevice(e->device));
+    if (adapter_reserve(e, n_rows)) return -1;
+    HC(hipMemcpyAsync(e->adapter + (size_t)(e->adapter_total - e->adapter_row0) * e->d.dec_dim, rows_dev,
+                      (size_t)n_rows * e->d.dec_dim * 4, hipMemcpyDeviceToDevice, e->stream));
+    HC(hipStreamSynchronize(e->stream));
+    e->adapter_total += n_rows;
+    return 0;
+}
+
+extern "C" void *vox_hip_device_alloc(vox_hip_engine_t *e, size_t bytes) {
+    if (!e) return nullptr;
+    if (hipSetDevice(e->device) != hipSuccess) return nullptr;
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void vox_hip_device_free(vox_hip_engine_t *e, void *p) { if (e && p) { hipSetDevice(e->device); hipFree(p); } }
+extern "C" int vox_hip_memcpy(vox_hip_engine_t *e, void *dst, const void *src, size_t bytes, int kind) {
+    if (!e) return -1;
+    HC(hipSetDevice(e->device));
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMemcpy(dst, src, bytes, kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice));
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------

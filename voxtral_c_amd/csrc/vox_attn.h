@@ -43,6 +43,7 @@ struct AttnArgs {
     // split-K (decoder)
     int split_keys;                 // keys per blockIdx.y
     float *part_o, *part_ml;        // [n_q][n_heads][nsplit][HD], [..][2]
+    int force_partials;             // write partials even when nsplit == 1 (merged by the Wo GEMV prologue)
 };
 
 template <int HD>
@@ -66,6 +67,17 @@ __global__ __launch_bounds__(128) void k_attn_rows(const AttnArgs a) {
     const int q_last = min(q_first + 127, a.n_q - 1);
     int blo = a.qpos0 + q_first - a.window + 1; if (blo < 0) blo = 0;
     int bhi = a.qpos0 + q_last; if (bhi > last_key) bhi = last_key;
+    // optional split of the key range over blockIdx.z (small chunks: too few query tiles to
+    // fill the chip); partial (m, l, o) go to part_* and k_attn_combine<HD> merges them
+    const int nsplit = gridDim.z;
+    if (nsplit > 1) {
+        const int tiles = (bhi - blo + TK) / TK;
+        const int per = (tiles + nsplit - 1) / nsplit;
+        const int lo2 = blo + (int)blockIdx.z * per * TK;
+        const int hi2 = lo2 + per * TK - 1;
+        blo = lo2;
+        if (hi2 < bhi) bhi = hi2;
+    }
 
     float qv[HD], o[HD];
     if (valid) {
@@ -111,14 +123,15 @@ __global__ __launch_bounds__(128) void k_attn_rows(const AttnArgs a) {
         for (int j = 0; j < TK; j++) {
             const int pos = t0 + j;
             const bool in = (pos >= lo_i) && (pos <= hi_i);
-            float s = 0.f;
+            // four independent accumulation chains (a single 64-long fmaf chain is latency bound)
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
             for (int d = 0; d < HD; d += 4) {
                 const float4 kk = *reinterpret_cast<const float4 *>(&Ks[j][d]);
-                s = fmaf(qv[d], kk.x, s); s = fmaf(qv[d + 1], kk.y, s);
-                s = fmaf(qv[d + 2], kk.z, s); s = fmaf(qv[d + 3], kk.w, s);
+                s0 = fmaf(qv[d], kk.x, s0); s1 = fmaf(qv[d + 1], kk.y, s1);
+                s2 = fmaf(qv[d + 2], kk.z, s2); s3 = fmaf(qv[d + 3], kk.w, s3);
             }
-            s *= a.scale;
+            float s = ((s0 + s1) + (s2 + s3)) * a.scale;
             if (in) {
                 // reference recurrence (voxtral_kernels.c:456-470), branch-free form
                 const float mn = fmaxf(m, s);
@@ -135,7 +148,14 @@ __global__ __launch_bounds__(128) void k_attn_rows(const AttnArgs a) {
             }
         }
     }
-    if (valid) {
+    if (valid && nsplit > 1) {
+        const size_t pidx = ((size_t)qi * a.n_heads + h) * nsplit + blockIdx.z;
+        float *po = a.part_o + pidx * HD;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) *reinterpret_cast<float4 *>(po + d) = make_float4(o[d], o[d + 1], o[d + 2], o[d + 3]);
+        a.part_ml[pidx * 2] = m;
+        a.part_ml[pidx * 2 + 1] = l;
+    } else if (valid) {
         float *op = a.out + (size_t)qi * a.ldo + h * HD;
         const float inv = l > 0.f ? 1.0f / l : 0.f;
 #pragma unroll
@@ -183,35 +203,52 @@ __global__ __launch_bounds__(256) void k_attn_dec(const AttnArgs a, const int ns
         for (int d = 0; d < 8; d++) o[h][d] = 0.f;
     }
 
-    for (int t = w_lo + ks; t <= w_hi; t += 4) {
-        const float *kp, *vp;
-        if (t >= a.posB0) {
-            const size_t off = (size_t)(t - a.posB0) * a.ldB + kvh * HD + dc * 8;
-            kp = a.kB + off; vp = a.vB + off;
-        } else {
-            const size_t off = (size_t)(t % a.capA) * a.ldA + kvh * HD + dc * 8;
-            kp = a.kA + off; vp = a.vA + off;
-        }
-        const float4 k0 = *reinterpret_cast<const float4 *>(kp);
-        const float4 k1 = *reinterpret_cast<const float4 *>(kp + 4);
-        const float4 v0 = *reinterpret_cast<const float4 *>(vp);
-        const float4 v1 = *reinterpret_cast<const float4 *>(vp + 4);
+    // 16 keys per trip: the K/V loads of four consecutive 4-key groups are issued together so
+    // that one trip costs one memory latency instead of four (the loop is latency-bound at the
+    // short contexts of real-time decoding).  Out-of-range slots are clamped to the last valid
+    // key for the load and masked with s = -inf (p = 0) for the arithmetic.
+    constexpr int UNR = 4;
+    for (int t = w_lo + ks; t <= w_hi; t += 4 * UNR) {
+        float4 kq0[UNR], kq1[UNR], vq0[UNR], vq1[UNR];
 #pragma unroll
-        for (int h = 0; h < HPK; h++) {
-            float s = qv[h][0] * k0.x;
-            s = fmaf(qv[h][1], k0.y, s); s = fmaf(qv[h][2], k0.z, s); s = fmaf(qv[h][3], k0.w, s);
-            s = fmaf(qv[h][4], k1.x, s); s = fmaf(qv[h][5], k1.y, s); s = fmaf(qv[h][6], k1.z, s);
-            s = fmaf(qv[h][7], k1.w, s);
-            s = row16_sum<USE_DPP>(s) * a.scale;
-            const float mn = fmaxf(m[h], s);
-            const float corr = expf(m[h] - mn);
-            const float p = expf(s - mn);
-            l[h] = l[h] * corr + p;
-            o[h][0] = o[h][0] * corr + p * v0.x; o[h][1] = o[h][1] * corr + p * v0.y;
-            o[h][2] = o[h][2] * corr + p * v0.z; o[h][3] = o[h][3] * corr + p * v0.w;
-            o[h][4] = o[h][4] * corr + p * v1.x; o[h][5] = o[h][5] * corr + p * v1.y;
-            o[h][6] = o[h][6] * corr + p * v1.z; o[h][7] = o[h][7] * corr + p * v1.w;
-            m[h] = mn;
+        for (int u = 0; u < UNR; u++) {
+            int tt = t + 4 * u;
+            if (tt > w_hi) tt = w_hi;
+            const float *kp_, *vp_;
+            if (tt >= a.posB0) {
+                const size_t off = (size_t)(tt - a.posB0) * a.ldB + kvh * HD + dc * 8;
+                kp_ = a.kB + off; vp_ = a.vB + off;
+            } else {
+                const size_t off = (size_t)(tt % a.capA) * a.ldA + kvh * HD + dc * 8;
+                kp_ = a.kA + off; vp_ = a.vA + off;
+            }
+            kq0[u] = *reinterpret_cast<const float4 *>(kp_);
+            kq1[u] = *reinterpret_cast<const float4 *>(kp_ + 4);
+            vq0[u] = *reinterpret_cast<const float4 *>(vp_);
+            vq1[u] = *reinterpret_cast<const float4 *>(vp_ + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const bool ok = (t + 4 * u) <= w_hi;
+            const float4 k0 = kq0[u], k1 = kq1[u], v0 = vq0[u], v1 = vq1[u];
+#pragma unroll
+            for (int h = 0; h < HPK; h++) {
+                float s = qv[h][0] * k0.x;
+                s = fmaf(qv[h][1], k0.y, s); s = fmaf(qv[h][2], k0.z, s); s = fmaf(qv[h][3], k0.w, s);
+                s = fmaf(qv[h][4], k1.x, s); s = fmaf(qv[h][5], k1.y, s); s = fmaf(qv[h][6], k1.z, s);
+                s = fmaf(qv[h][7], k1.w, s);
+                s = row16_sum<USE_DPP>(s) * a.scale;
+                if (!ok) s = -INFINITY;
+                const float mn = fmaxf(m[h], s);
+                const float corr = expf(m[h] - mn);
+                const float p = expf(s - mn);
+                l[h] = l[h] * corr + p;
+                o[h][0] = o[h][0] * corr + p * v0.x; o[h][1] = o[h][1] * corr + p * v0.y;
+                o[h][2] = o[h][2] * corr + p * v0.z; o[h][3] = o[h][3] * corr + p * v0.w;
+                o[h][4] = o[h][4] * corr + p * v1.x; o[h][5] = o[h][5] * corr + p * v1.y;
+                o[h][6] = o[h][6] * corr + p * v1.z; o[h][7] = o[h][7] * corr + p * v1.w;
+                m[h] = mn;
+            }
         }
     }
 
@@ -256,7 +293,7 @@ __global__ __launch_bounds__(256) void k_attn_dec(const AttnArgs a, const int ns
                 o1 += sm_o[w][h][d0 + 1] * f;
             }
             const int head = kvh * HPK + h;
-            if (nsplit == 1) {
+            if (nsplit == 1 && !a.force_partials) {
                 const float inv = ll > 0.f ? 1.0f / ll : 0.f;
                 float *op = a.out + (size_t)qi * a.ldo + head * HD + d0;
                 op[0] = o0 * inv; op[1] = o1 * inv;

@@ -39,6 +39,11 @@ struct GemmArgs {
     const float *bias;             // [N] or null
     const float *resid; int ldr;   // [M, N] or null (may alias Y)
     int act;
+    // split-K (small grids): blockIdx.z owns K-slices [z*kper, (z+1)*kper); raw partial sums go
+    // to partial[z][M][N] and k_splitk_reduce applies the epilogue in a fixed order
+    // (deterministic — no atomics).
+    int ksplit, kper;
+    float *partial;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -102,14 +107,19 @@ __global__ __launch_bounds__(256) void k_gemm_mfma_f32(const GemmArgs a) {
         }
     };
 
-    const int nk = K / GB_K;
-    load_slice(0);
-    store_slice();
+    const int nk_total = K / GB_K;
+    const int kt0 = (a.ksplit > 1) ? blockIdx.z * a.kper : 0;
+    const int kt1 = (a.ksplit > 1) ? min(nk_total, kt0 + a.kper) : nk_total;
+    const int nk = kt1 - kt0;
+    const int li = lane & 31, lg = lane >> 5;
+    if (nk > 0) {
+        load_slice(kt0 * GB_K);
+        store_slice();
+    }
     __syncthreads();
 
-    const int li = lane & 31, lg = lane >> 5;
     for (int kt = 0; kt < nk; kt++) {
-        if (kt + 1 < nk) load_slice((kt + 1) * GB_K);
+        if (kt + 1 < nk) load_slice((kt0 + kt + 1) * GB_K);
 #pragma unroll
         for (int kk = 0; kk < GB_K; kk += 8) {
             float4 av[2], bv[2];
@@ -136,6 +146,22 @@ __global__ __launch_bounds__(256) void k_gemm_mfma_f32(const GemmArgs a) {
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+    if (a.ksplit > 1) {
+        float *P = a.partial + (size_t)blockIdx.z * M * N;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++) {
+                const int col = bn0 + wn * 64 + tn * 32 + li;
+                if (col >= N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = bm0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                    if (row < M) P[(size_t)row * N + col] = acc[tm][tn][r];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
 #pragma unroll
@@ -155,6 +181,20 @@ __global__ __launch_bounds__(256) void k_gemm_mfma_f32(const GemmArgs a) {
                 }
             }
         }
+}
+
+// Sum the split-K partials in split order and apply the fused epilogue.
+__global__ __launch_bounds__(256) void k_splitk_reduce(const GemmArgs a) {
+    const size_t total = (size_t)a.M * a.N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / a.N), n = (int)(i % a.N);
+        float v = 0.f;
+        for (int z = 0; z < a.ksplit; z++) v += a.partial[(size_t)z * total + i];
+        if (a.bias) v += a.bias[n];
+        v = apply_act(v, a.act);
+        if (a.resid) v = a.resid[(size_t)m * a.ldr + n] + v;
+        a.Y[(size_t)m * a.ldy + n] = v;
+    }
 }
 
 // Plain fp32 FMA reference kernel (one thread per output, sequential k like the

@@ -77,7 +77,7 @@ struct vox_hip_engine {
     vox_hip_dims_t d{};
     int enc_qd = 0, dec_qd = 0, dec_kvd = 0;
     size_t mem_used = 0;
-    bool use_dpp = true, use_mfma = true;
+    bool use_dpp = true, use_mfma = true, use_gemv2 = true, use_splitk = true;
 
     // weights
     uint16_t *tok_emb = nullptr, *conv0_w = nullptr, *conv1_w = nullptr, *adapter0 = nullptr, *adapter1 = nullptr;
@@ -97,7 +97,7 @@ struct vox_hip_engine {
     int enc_res = 0;            // 0..3 encoder rows waiting for 4x alignment (voxtral.c:824-890)
     Buf conv_in0, conv_in1, enc_out;   // see conv stem / alignment notes below
     // large-M scratch
-    Buf sx, sxn, sqkv, sattn, sgu, sh, srope, sim2col, ssamples, smid, stmp_in, stmp_out, spart_o, spart_ml;
+    Buf sx, sxn, sqkv, sattn, sgu, sh, srope, sim2col, ssamples, smid, stmp_in, stmp_out, spart_o, spart_ml, ssplitk;
 
     // adapter rows (linear buffer; physical row r <-> logical row adapter_row0 + r)
     float *adapter = nullptr;
@@ -186,15 +186,33 @@ static inline int grid1d(size_t work, int per_block = 256, int cap = 4096) {
 // ------------------------------------------------------------------------------------
 // GEMM / GEMV launchers
 // ------------------------------------------------------------------------------------
+static int ensure(vox_hip_engine *e, Buf &b, size_t bytes);
 static void launch_gemm(vox_hip_engine *e, const float *X, int ldx, const uint16_t *W, float *Y, int ldy,
                         int M, int N, int K, const float *bias, const float *resid, int ldr, int act,
                         int force_scalar = 0) {
-    GemmArgs a{X, ldx, W, Y, ldy, M, N, K, bias, resid, ldr, act};
+    GemmArgs a{X, ldx, W, Y, ldy, M, N, K, bias, resid, ldr, act, 1, 0, nullptr};
     if (M <= 0 || N <= 0) return;
     const bool aligned = (K % GB_K == 0) && (ldx % 4 == 0) && ((size_t)X % 16 == 0);
     if (e->use_mfma && aligned && !force_scalar) {
-        dim3 grid((N + GB_N - 1) / GB_N, (M + GB_M - 1) / GB_M);
-        hipLaunchKernelGGL(k_gemm_mfma_f32, grid, dim3(256), GEMM_LDS_BYTES, e->stream, a);
+        const int tn = (N + GB_N - 1) / GB_N, tm = (M + GB_M - 1) / GB_M, nk = K / GB_K;
+        // Fewer tiles than ~1.5 per CU: split K so that the chip is full (weights are then
+        // streamed by >= 384 blocks instead of a few dozen); partials are reduced in a fixed order.
+        int ksplit = 1;
+        if (e->use_splitk && tm * tn < 384 && nk >= 8) {
+            ksplit = std::min(std::min((512 + tm * tn - 1) / (tm * tn), nk / 4), 16);
+            if (ksplit < 2) ksplit = 1;
+        }
+        if (ksplit > 1 && ensure(e, e->ssplitk, (size_t)ksplit * M * N * 4) == 0) {
+            a.ksplit = ksplit; a.kper = (nk + ksplit - 1) / ksplit; a.partial = (float *)e->ssplitk.p;
+            a.ksplit = (nk + a.kper - 1) / a.kper;          // drop empty trailing splits
+            dim3 grid(tn, tm, a.ksplit);
+            hipLaunchKernelGGL(k_gemm_mfma_f32, grid, dim3(256), GEMM_LDS_BYTES, e->stream, a);
+            hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((size_t)M * N)), dim3(256), 0, e->stream, a);
+        } else {
+            a.ksplit = 1;
+            dim3 grid(tn, tm);
+            hipLaunchKernelGGL(k_gemm_mfma_f32, grid, dim3(256), GEMM_LDS_BYTES, e->stream, a);
+        }
     } else {
         dim3 grid((N + 63) / 64, (M + 3) / 4);
         hipLaunchKernelGGL(k_gemm_scalar, grid, dim3(256), 0, e->stream, a);
@@ -344,10 +362,10 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
     rc |= dalloc(e, &e->d_st, 1);
     rc |= dalloc(e, &e->dx, DD); rc |= dalloc(e, &e->dq, DQ); rc |= dalloc(e, &e->dattn, DQ);
     rc |= dalloc(e, &e->dh, DH); rc |= dalloc(e, &e->dlogits, (size_t)d.vocab);
-    e->logits_grid = gemv_grid(d.vocab, 16);
+    e->logits_grid = (d.vocab % (16 * 1024) == 0) ? 1024 : gemv_grid(d.vocab, 16);   // 131072 rows: 8 even trips
     rc |= dalloc(e, &e->blk_val, e->logits_grid); rc |= dalloc(e, &e->blk_idx, e->logits_grid);
     rc |= dalloc(e, &e->d_tokens, MAX_RUN_STEPS);
-    e->dec_max_split = (d.dec_window + DEC_SPLIT_KEYS - 1) / DEC_SPLIT_KEYS + 1;
+    e->dec_max_split = (d.dec_window + 63) / 64 + 1;
     rc |= dalloc(e, &e->dpart_o, (size_t)d.dec_heads * e->dec_max_split * d.dec_head_dim);
     rc |= dalloc(e, &e->dpart_ml, (size_t)d.dec_heads * e->dec_max_split * 2);
     if (rc) return fail();
@@ -379,7 +397,7 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     F(e->d_st); F(e->dx); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
     F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter);
     Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
-                   &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml};
+                   &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml, &e->ssplitk};
     for (Buf *b : bufs) F(b->p);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
@@ -527,7 +545,21 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
         a.kB = qkv + c.QD; a.vB = qkv + c.QD + c.KVD; a.ldB = N3; a.posB0 = pos0; a.last_key = pos0 + n - 1;
         a.kA = kring; a.vA = vring; a.capA = ring_cap; a.ldA = c.KVD;
         a.n_heads = c.heads; a.n_kv_heads = c.kv_heads; a.scale = scale; a.window = c.window; a.st = nullptr;
-        hipLaunchKernelGGL((k_attn_rows<64>), dim3((n + 127) / 128, c.heads), dim3(128), 0, s, a);
+        {
+            const int qt = (n + 127) / 128, blocks = qt * c.heads;
+            const int span = std::min(pos0 + n, c.window + std::min(n, 128));
+            int ks = 1;
+            if (blocks < 256) ks = std::max(1, std::min((512 + blocks - 1) / blocks, (span + 63) / 64));
+            if (ks > 1) {
+                if (ensure(e, e->spart_o, (size_t)n * c.heads * ks * c.hd * 4)) return -1;
+                if (ensure(e, e->spart_ml, (size_t)n * c.heads * ks * 2 * 4)) return -1;
+                a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
+            }
+            hipLaunchKernelGGL((k_attn_rows<64>), dim3(qt, c.heads, ks), dim3(128), 0, s, a);
+            if (ks > 1)
+                hipLaunchKernelGGL((k_attn_combine<64>), dim3(c.heads, n), dim3(64), 0, s, attn, c.QD,
+                                   (const float *)a.part_o, (const float *)a.part_ml, c.heads, ks);
+        }
         // keep the last min(n, window) rows for the next chunk
         const int keep = std::min(n, c.window);
         hipLaunchKernelGGL(k_ring_append, dim3(grid1d((size_t)keep * c.KVD / 4)), dim3(256), 0, s,
@@ -1001,17 +1033,40 @@ extern "C" int vox_hip_decoder_prefill(vox_hip_engine_t *e, const float *embeds,
     return 0;
 }
 
+// Keys per attention block for a decode step at KV length kv_len: short contexts are latency
+// bound, so they get small slices (64 keys = one 16-key trip per wave); long contexts get
+// bigger ones so that the number of partials stays <= 64.
+static int dec_split_keys(int kv_len) {
+    if (kv_len <= 512) return 64;
+    if (kv_len <= 2048) return 128;
+    if (kv_len <= 8192) return 256;
+    return 512;
+}
+
+template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW>
+static void launch_gemv2(vox_hip_engine *e, const GemvArgs &a) {
+    const int rows_per_block = (4 / KS) * RPW;
+    const int grid = (a.N + rows_per_block - 1) / rows_per_block;
+    const size_t lds = ((size_t)a.K + 512) * sizeof(float);
+    hipLaunchKernelGGL((k_gemv2<PRO, EPI, RPW, CPL, KS, MINW>), dim3(grid), dim3(256), lds, e->stream, a);
+}
+
 // Enqueue one decode step. kv_pos = logical position of this token (host mirror of st->pos).
 static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *logits_dst, int eos, int advance) {
     const vox_hip_dims_t &d = e->d;
     const int DD = d.dec_dim, DQ = e->dec_qd, DKV = e->dec_kvd, DH = d.dec_hidden, HD = d.dec_head_dim;
     hipStream_t s = e->stream;
-    const float *adapter_base = e->adapter;
-    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(256), 0, s, (const DecState *)e->d_st, (const float *)e->dec_inv_freq,
-                       HD / 2, e->dec_rope, e->dx, adapter_base, (const uint16_t *)e->tok_emb, DD, build_embed ? 1 : 0);
-    prof_mark(e, PK_BEGIN);
+    // production kernels are specialised for the 4B shapes; anything else takes the generic ones
+    const bool fast = e->use_gemv2 && DD == 3072 && DQ == 4096 && DKV == 1024 && DH == 9216;
+    if (!fast) {
+        hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(256), 0, s, (const DecState *)e->d_st, (const float *)e->dec_inv_freq,
+                           HD / 2, e->dec_rope, e->dx, (const float *)e->adapter, (const uint16_t *)e->tok_emb, DD, build_embed ? 1 : 0);
+        prof_mark(e, PK_BEGIN);
+    }
     const int kv_len = std::min(kv_pos + 1, d.dec_window);
-    const int nsplit = (kv_len + DEC_SPLIT_KEYS - 1) / DEC_SPLIT_KEYS;
+    const int split_keys = fast ? dec_split_keys(kv_len) : DEC_SPLIT_KEYS;
+    const int nsplit = (kv_len + split_keys - 1) / split_keys;
+    const bool fuse_combine = fast && nsplit <= 8;
     const float scale = 1.0f / sqrtf((float)HD);
     for (int l = 0; l < d.dec_layers; l++) {
         DecLayer &L = e->dec[l];
@@ -1020,7 +1075,10 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             a.W = L.wqkv; a.x = e->dx; a.norm_w = L.n1; a.ada = nullptr; a.eps = d.dec_eps; a.y = e->dq;
             a.N = DQ + 2 * DKV; a.K = DD; a.q_rows = DQ; a.k_rows = DKV; a.head_dim = HD; a.rope = e->dec_rope;
             a.kcache = L.kring; a.vcache = L.vring; a.kv_cap = e->dec_ring_cap; a.kv_dim = DKV; a.st = e->d_st;
-            launch_gemv<PRO_RMS, EPI_QKV, 4>(e, a);
+            a.inv_freq = e->dec_inv_freq; a.adapter = e->adapter; a.tok_emb = e->tok_emb; a.x_out = e->dx;
+            if (!fast) launch_gemv<PRO_RMS, EPI_QKV, 4>(e, a);
+            else if (l == 0 && build_embed) launch_gemv2<PRO_EMBED_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
+            else launch_gemv2<PRO_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
             prof_mark(e, PK_QKV);
         }
         {   // attention over the KV window (voxtral_decoder.c:667-673)
@@ -1028,35 +1086,41 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             a.out = e->dattn; a.ldo = DQ; a.q = e->dq; a.ldq = DQ; a.n_q = 1; a.qpos0 = 0;
             a.posB0 = INT_MAX; a.last_key = 0; a.kA = L.kring; a.vA = L.vring; a.capA = e->dec_ring_cap; a.ldA = DKV;
             a.n_heads = d.dec_heads; a.n_kv_heads = d.dec_kv_heads; a.scale = scale; a.window = d.dec_window;
-            a.st = e->d_st; a.split_keys = DEC_SPLIT_KEYS; a.part_o = e->dpart_o; a.part_ml = e->dpart_ml;
+            a.st = e->d_st; a.split_keys = split_keys; a.part_o = e->dpart_o; a.part_ml = e->dpart_ml;
+            a.force_partials = fuse_combine ? 1 : 0;
             if (e->use_dpp)
                 hipLaunchKernelGGL((k_attn_dec<128, 4, true>), dim3(d.dec_kv_heads, nsplit, 1), dim3(256), 0, s, a, nsplit);
             else
                 hipLaunchKernelGGL((k_attn_dec<128, 4, false>), dim3(d.dec_kv_heads, nsplit, 1), dim3(256), 0, s, a, nsplit);
             prof_mark(e, PK_ATTN);
-            if (nsplit > 1) {
+            if (nsplit > 1 && !fuse_combine) {
                 hipLaunchKernelGGL((k_attn_combine<128>), dim3(d.dec_heads, 1), dim3(128), 0, s, e->dattn, DQ,
                                    (const float *)e->dpart_o, (const float *)e->dpart_ml, d.dec_heads, nsplit);
                 prof_mark(e, PK_COMBINE);
             }
         }
-        {   // x += attn.Wo^T
+        {   // x += attn.Wo^T   (fast path: the split-K partials are merged in the prologue)
             GemvArgs a{};
             a.W = L.wo; a.x = e->dattn; a.y = e->dx; a.N = DD; a.K = DQ;
-            launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
+            a.part_o = e->dpart_o; a.part_ml = e->dpart_ml; a.nsplit = nsplit; a.attn_hd = HD;
+            if (!fast) launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
+            else if (fuse_combine) launch_gemv2<PRO_ATTN, EPI_RESID, 3, 8, 1, 1>(e, a);
+            else launch_gemv2<PRO_NONE, EPI_RESID, 3, 8, 1, 1>(e, a);
             prof_mark(e, PK_WO);
         }
         {   // RMSNorm * (1+ada) -> silu(W1 x) * (W3 x)
             GemvArgs a{};
             a.W = L.w13; a.W2 = L.w13 + (size_t)DH * DD; a.x = e->dx; a.norm_w = L.n2; a.ada = L.ada; a.eps = d.dec_eps;
             a.y = e->dh; a.N = DH; a.K = DD;
-            launch_gemv<PRO_RMS, EPI_SWIGLU, 2>(e, a);
+            if (!fast) launch_gemv<PRO_RMS, EPI_SWIGLU, 2>(e, a);
+            else launch_gemv2<PRO_RMS, EPI_SWIGLU, 3, 6, 1, 3>(e, a);
             prof_mark(e, PK_SWIGLU);
         }
         {   // x += h.W2^T
             GemvArgs a{};
             a.W = L.w2; a.x = e->dh; a.y = e->dx; a.N = DD; a.K = DH;
-            launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
+            if (!fast) launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
+            else launch_gemv2<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
             prof_mark(e, PK_W2);
         }
     }
@@ -1376,6 +1440,8 @@ static int self_test(vox_hip_engine *e) {
         e->use_mfma = false;
     }
     if (getenv("VOX_HIP_NO_MFMA")) e->use_mfma = false;
+    if (getenv("VOX_HIP_NO_GEMV2")) e->use_gemv2 = false;
+    if (getenv("VOX_HIP_NO_SPLITK")) e->use_splitk = false;
     hipFree(dx); hipFree(dy1); hipFree(dy2); hipFree(dw); hipFree(dbias);
     return 0;
 }

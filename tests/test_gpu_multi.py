@@ -1,0 +1,42 @@
+"""GPU: the real HIP shard path (vox_hip_shard_*) under torch.distributed with 2 and 3 ranks.
+A single-GPU box cannot host an RCCL communicator with several ranks on one device, so the
+ranks share GPU 0 and exchange through gloo (host tensors mirrored by device buffers); the
+engine calls, the K/V wavefront, the gather and the rank-0 decode are exactly those of the
+RCCL run.  The tokens must equal the single-process transcription of the same clip."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from audio_util import synth_speech
+from conftest import ROOT, model_dir
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize("preset,seconds,world", [("tiny", 14.0, 3), ("small", 70.0, 2)])
+def test_sharded_transcription_equals_single_gpu(tmp_path, preset, seconds, world):
+    import voxtral_c_amd as v
+    if v.device_count() < 1:
+        pytest.fail("no HIP device")
+    out = str(tmp_path / "toks.npy")
+    env = dict(os.environ, VOX_DIST_BACKEND="gloo", VOX_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "mgpu_worker.py"), preset, str(seconds), "77", out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    sharded = np.load(out)
+    win = {} if preset != "tiny" else dict(enc_window=48, dec_window=64)
+    with v.Model(model_dir(preset), **win) as m:
+        single = m.transcribe(synth_speech(seconds, 77))["tokens"]
+    assert len(sharded) == len(single), (len(sharded), len(single))
+    assert np.array_equal(sharded, single)

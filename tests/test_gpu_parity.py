@@ -283,6 +283,36 @@ def test_stream_small_matches_reference_golden(small):
     assert res["first_mismatch"] is None and res["steps"] == res["ref_steps"], res
 
 
+def test_stream_small_long_context_matches_reference_golden(small):
+    """95 s clip: > 1024 decoder positions, so the decode attention runs with > 8 key slices and
+    the separate combine kernel, and the encoder window (750) rolls over inside one chunk."""
+    g = gold("stream_small_long.npz")
+    meta = g["meta"]
+    audio = synth_speech(float(meta[1]), int(meta[2]))
+    got = small.transcribe(audio, record_logits=2048)
+    res = compare_stream("small_long", got, g)
+    assert res.get("logit_err", 0.0) < LOGIT_TOL, res
+    if res["first_mismatch"] is not None:
+        assert res["ref_margin_at_mismatch"] < 2 * LOGIT_TOL, res
+    else:
+        assert res["steps"] == res["ref_steps"], res
+
+
+def test_stream_full_size_matches_reference_golden(vox):
+    """The real 4B geometry (32+26 layers, vocab 131072) on the seeded synthetic checkpoint."""
+    g = gold("stream_full_batch.npz")
+    meta = g["meta"]
+    audio = synth_speech(float(meta[1]), int(meta[2]))
+    with vox.Model(model_dir("full")) as m:
+        got = m.transcribe(audio, record_logits=512)
+    res = compare_stream("full_batch", got, g)
+    assert res.get("logit_err", 0.0) < LOGIT_TOL, res
+    if res["first_mismatch"] is not None:
+        assert res["ref_margin_at_mismatch"] < 2 * LOGIT_TOL, res
+    else:
+        assert res["steps"] == res["ref_steps"], res
+
+
 def test_batch_and_streaming_feeds_agree(tiny):
     """Reference property: one feed == 1 s feeds == 4096-sample feeds at -I 0.1."""
     audio = synth_speech(9.0, 21)

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 echo "== rocminfo"; /opt/rocm/bin/rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9" | head -4
 echo "== pytest -m gpu"
-timeout 1200 python -m pytest tests -m gpu -q -rf --tb=short -p no:cacheprovider > gpurun_out/pytest.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q -rf --tb=short --durations=8 -p no:cacheprovider > gpurun_out/pytest.log 2>&1
 echo "pytest rc=$?"; tail -25 gpurun_out/pytest.log
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1

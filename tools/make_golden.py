@@ -39,6 +39,7 @@ CASES = [
     ("tiny_long", "tiny", 100.0, 2, None, None, False),        # > 1126 steps: decoder window roll-over
     ("tiny_continuous", "tiny", 200.0, 3, 4096, 0.5, True),    # restarts at kv > 2000
     ("small_batch", "small", 8.0, 4, None, None, False),
+    ("small_long", "small", 95.0, 6, None, None, False),       # > 1024 decoder positions: split-K attention + combine kernel
 ]
 
 

@@ -169,9 +169,30 @@ class TorchComm:
             self.torch.cuda.synchronize()
 
 
+class Staging:
+    """A buffer the engine writes/reads (by pointer) and the communicator sends/receives (as a
+    torch tensor).  RCCL: one GPU tensor, pointer = data_ptr.  gloo next to the HIP engine: a
+    host tensor mirrored by a device buffer (copied around each transfer).  CPU oracle engine:
+    the tensor itself."""
+
+    def __init__(self, tensor, ptr=None, to_host=None, to_dev=None):
+        self.tensor, self._ptr, self._to_host, self._to_dev = tensor, ptr, to_host, to_dev
+
+    def ptr(self):
+        return self.tensor if self._ptr is None else self._ptr
+
+    def after_engine_write(self):
+        if self._to_host:
+            self._to_host()
+
+    def before_engine_read(self):
+        if self._to_dev:
+            self._to_dev()
+
+
 def encode_sharded(eng, comm, padded, n_frames, staging):
-    """Wavefront context-parallel encode. `staging(nbytes)` returns (tensor, device_ptr) pairs the
-    engine can read/write and the communicator can send. Returns this rank's adapter rows tensor."""
+    """Wavefront context-parallel encode. `staging(shape)` returns a Staging buffer.
+    Returns (gathered adapter rows on rank 0 | None, per-rank row counts)."""
     rank, world = comm.rank, comm.world
     plan = shard_plan(n_frames, world)
     pos0, pos1 = plan[rank]
@@ -181,22 +202,26 @@ def encode_sharded(eng, comm, padded, n_frames, staging):
     assert n == pos1 - pos0, (n, pos0, pos1)
     tail = min(eng.window - 1, pos0)                       # positions we need from the left
     send_tail = min(eng.window - 1, pos1) if rank + 1 < world else 0
-    t_in, p_in = staging((2, max(tail, 1), eng.kv_dim))
-    t_out, p_out = staging((2, max(send_tail, 1), eng.kv_dim))
+    s_in = staging((2, max(tail, 1), eng.kv_dim))
+    s_out = staging((2, max(send_tail, 1), eng.kv_dim))
     for l in range(eng.n_layers):
         if rank > 0 and tail > 0:
-            comm.recv(t_in, rank - 1)
+            comm.recv(s_in.tensor, rank - 1)
             comm.sync()
-            eng.kv_import(l, pos0 - tail, tail, p_in(t_in))
+            s_in.before_engine_read()
+            eng.kv_import(l, pos0 - tail, tail, s_in.ptr())
         eng.layer(l)
         if send_tail > 0:
-            eng.kv_export(l, pos1 - send_tail, send_tail, p_out(t_out))    # synchronises the engine stream
-            comm.send(t_out, rank + 1)
-    t_ad, p_ad = staging(((pos1 - pos0) // 4, eng.dec_dim))
-    m = eng.end(p_ad(t_ad))
+            comm.sync()            # the previous layer's send has left the staging buffer
+            eng.kv_export(l, pos1 - send_tail, send_tail, s_out.ptr())    # synchronises the engine stream
+            s_out.after_engine_write()
+            comm.send(s_out.tensor, rank + 1)
+    s_ad = staging(((pos1 - pos0) // 4, eng.dec_dim))
+    m = eng.end(s_ad.ptr())
+    s_ad.after_engine_write()
     assert m == (pos1 - pos0) // 4
     counts = [(b - a) // 4 for a, b in plan]
-    return comm.gather_rows(t_ad, counts), counts
+    return comm.gather_rows(s_ad.tensor, counts), counts
 
 
 # ---------------------------------------------------------------------------------------
@@ -210,47 +235,18 @@ def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
 
     backend = os.environ.get("VOX_DIST_BACKEND", "nccl")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
+    share = os.environ.get("VOX_SHARE_GPU") == "1"          # several ranks on one GPU (gloo only; tests)
+    dev = 0 if share else local_rank
+    torch.cuda.set_device(dev)
     dist.init_process_group(backend=backend)
-    comm = TorchComm(device=f"cuda:{local_rank}")
-    model = v.Model(mdir, device=local_rank)
-    eng = HipShardEngine(model)
-    h = v.hip
-
-    def staging(shape):
-        t = comm.empty(shape)
-        if comm.on_gpu:
-            return t, (lambda tt: C.c_void_p(tt.data_ptr()))
-        # gloo: host tensor + device mirror owned by the engine
-        nbytes = t.numel() * 4
-        h.vox_hip_device_alloc.restype = C.c_void_p
-        h.vox_hip_device_alloc.argtypes = [C.c_void_p, C.c_size_t]
-        h.vox_hip_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        dev = h.vox_hip_device_alloc(model.engine, nbytes)
-        t._vox_dev = dev
-        return t, (lambda tt: _HostMirror(h, model.engine, tt))
-
+    comm = TorchComm(device=f"cuda:{dev}")
+    win = {} if args.preset != "tiny" else dict(enc_window=48, dec_window=64)
+    model = v.Model(mdir, device=dev, **win)
+    session = DistributedSession(model, comm)
     audio = synth_speech(args.seconds * world, 1234)
-    padded, n_frames = padded_stream(audio)
-    prompt_len = 1 + 32 + 6
 
     def one_pass():
-        eng.reset()
-        rows, counts = encode_sharded(eng, comm, padded, n_frames, staging)
-        toks = None
-        if rank == 0:
-            total = int(rows.shape[0])
-            if comm.on_gpu:
-                h.vox_hip_adapter_append_dev(model.engine, C.c_void_p(rows.data_ptr()), total)
-            else:
-                arr = np.ascontiguousarray(rows.numpy())
-                h.vox_hip_adapter_append(model.engine, arr.ctypes.data_as(v.f32p), total)
-            h.vox_hip_reset_decoder_kv(model.engine)
-            first = h.vox_hip_decoder_prefill_stream(model.engine, 0, prompt_len, 1, 32, None)
-            n_steps = total - prompt_len
-            out = np.zeros(max(n_steps, 1), np.int32)
-            got = h.vox_hip_decoder_run(model.engine, prompt_len, n_steps, first, 2, out.ctypes.data_as(v.i32p), None) if n_steps > 0 else 0
-            toks = np.concatenate([[first], out[:got]])
+        toks = session.transcribe(audio)
         comm.barrier()
         return toks
 
@@ -287,12 +283,61 @@ def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
     dist.destroy_process_group()
 
 
-class _HostMirror:
-    """gloo path: pairs a host torch tensor with a device buffer of the same size."""
+class DistributedSession:
+    """One rank's view of a multi-GPU transcription (used by bench.py and the tests)."""
 
-    def __init__(self, h, engine, t):
-        self.h, self.e, self.t = h, engine, t
+    def __init__(self, model, comm):
+        import voxtral_c_amd as v
+        self.v, self.model, self.comm = v, model, comm
+        self.eng = HipShardEngine(model)
+        h = v.hip
+        h.vox_hip_device_alloc.restype = C.c_void_p
+        h.vox_hip_device_alloc.argtypes = [C.c_void_p, C.c_size_t]
+        h.vox_hip_device_free.argtypes = [C.c_void_p, C.c_void_p]
+        h.vox_hip_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self._dev_bufs = []
 
-    @property
-    def value(self):
-        return self.t._vox_dev
+    def staging(self, shape):
+        comm, h, eng = self.comm, self.v.hip, self.model.engine
+        t = comm.empty(shape)
+        if comm.on_gpu:
+            return Staging(t, C.c_void_p(t.data_ptr()), to_host=comm.sync, to_dev=None)
+        nbytes = t.numel() * 4
+        dev = h.vox_hip_device_alloc(eng, nbytes)
+        self._dev_bufs.append(dev)
+        host = C.c_void_p(t.data_ptr())
+        return Staging(t, C.c_void_p(dev),
+                       to_host=lambda: h.vox_hip_memcpy(eng, host, C.c_void_p(dev), nbytes, 1),
+                       to_dev=lambda: h.vox_hip_memcpy(eng, C.c_void_p(dev), host, nbytes, 0))
+
+    def _free_staging(self):
+        for d in self._dev_bufs:
+            self.v.hip.vox_hip_device_free(self.model.engine, C.c_void_p(d))
+        self._dev_bufs = []
+
+    def transcribe(self, audio, delay_tokens=6):
+        """Sharded encode on all ranks, greedy decode on rank 0. Returns token ids on rank 0."""
+        v, h, comm, model = self.v, self.v.hip, self.comm, self.model
+        padded, n_frames = padded_stream(audio, delay_tokens)
+        prompt_len = 1 + LEFT_PAD_TOKENS + delay_tokens
+        self.eng.reset()
+        rows, counts = encode_sharded(self.eng, comm, padded, n_frames, self.staging)
+        self._free_staging()
+        toks = None
+        if comm.rank == 0:
+            total = int(rows.shape[0])
+            if comm.on_gpu:
+                comm.sync()
+                h.vox_hip_adapter_append_dev(model.engine, C.c_void_p(rows.data_ptr()), total)
+            else:
+                arr = np.ascontiguousarray(rows.numpy())
+                h.vox_hip_adapter_append(model.engine, arr.ctypes.data_as(v.f32p), total)
+            h.vox_hip_reset_decoder_kv(model.engine)
+            first = h.vox_hip_decoder_prefill_stream(model.engine, 0, prompt_len, 1, 32, None)
+            n_steps = total - prompt_len
+            out = np.zeros(max(n_steps, 1), np.int32)
+            got = 0
+            if n_steps > 0 and first != 2:
+                got = h.vox_hip_decoder_run(model.engine, prompt_len, n_steps, first, 2, out.ctypes.data_as(v.i32p), None)
+            toks = np.concatenate([[first], out[:got]]).astype(np.int32)
+        return toks

@@ -96,7 +96,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
+        if world == 1 and args.gpus > 1 and os.environ.get("VOX_FORCE_DIST") != "1":
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
 
     import voxtral_c_amd as v
@@ -109,7 +109,7 @@ def main():
     dims = PRESETS[args.preset]
     mdir = model_dir(args.preset)
 
-    if world > 1:
+    if world > 1 or os.environ.get("VOX_FORCE_DIST") == "1":
         from voxtral_c_amd.multi_gpu import run_distributed_bench
         return run_distributed_bench(args, rank, world, local_rank, mdir, dims)
 

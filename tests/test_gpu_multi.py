@@ -40,3 +40,20 @@ def test_sharded_transcription_equals_single_gpu(tmp_path, preset, seconds, worl
         single = m.transcribe(synth_speech(seconds, 77))["tokens"]
     assert len(sharded) == len(single), (len(sharded), len(single))
     assert np.array_equal(sharded, single)
+
+
+def test_rccl_backend_single_rank_bench_path(tmp_path):
+    """The RCCL ("nccl") code path of bench.py --gpus N (GPU-resident staging tensors handed to
+    the engine by data_ptr, device-side adapter append, all_reduce of the timing) with the only
+    world size a 1-GPU box allows."""
+    import json
+    env = dict(os.environ, VOX_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--preset", "small", "--seconds", "20"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["decoder_steps_per_pass"] > 100
+    assert out["config"]["backend"] == "nccl"

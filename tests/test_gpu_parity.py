@@ -313,6 +313,26 @@ def test_stream_full_size_matches_reference_golden(vox):
         assert res["steps"] == res["ref_steps"], res
 
 
+def test_persistent_decode_kernel_matches_multi_launch_path(vox):
+    """vox_persist.h (one cooperative launch for the whole greedy loop) against the per-GEMV
+    launch path on the full-size model: same token ids, logits equal to float rounding."""
+    audio = synth_speech(10.0, 55)
+    with vox.Model(model_dir("full")) as m:
+        a = m.transcribe(audio, record_logits=256)
+        b = m.transcribe(audio)               # no logits recording: one launch for all steps
+    os.environ["VOX_HIP_NO_PERSIST"] = "1"
+    try:
+        with vox.Model(model_dir("full")) as m2:
+            c = m2.transcribe(audio, record_logits=256)
+    finally:
+        del os.environ["VOX_HIP_NO_PERSIST"]
+    diag("persist_vs_launch", steps=int(len(a["tokens"])), max_logit_diff=float(np.abs(a["logits"] - c["logits"]).max()),
+         equal_tokens=bool(np.array_equal(a["tokens"], c["tokens"])))
+    assert len(a["tokens"]) > 100
+    assert np.array_equal(a["tokens"], c["tokens"]) and np.array_equal(b["tokens"], c["tokens"])
+    assert np.abs(a["logits"] - c["logits"]).max() < 1e-4
+
+
 def test_batch_and_streaming_feeds_agree(tiny):
     """Reference property: one feed == 1 s feeds == 4096-sample feeds at -I 0.1."""
     audio = synth_speech(9.0, 21)

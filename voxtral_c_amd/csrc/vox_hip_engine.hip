@@ -25,6 +25,7 @@
 #include "vox_gemm.h"
 #include "vox_misc.h"
 #include "vox_attn.h"
+#include "vox_persist.h"
 
 using namespace vox;
 
@@ -115,6 +116,11 @@ struct vox_hip_engine {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     vox_hip_timing_t timing{};
+    // persistent decode kernel (vox_persist.h)
+    bool use_persist = false;
+    PersistLayer *d_players = nullptr;
+    unsigned *d_bar = nullptr;
+    int persist_runs = 0, persist_failures = 0;
     // multi-GPU shard in flight (vox_hip_shard_*)
     float *shard_x = nullptr; int shard_n = 0;
     // per-kernel profiling of the decode step (HIP events between launches)
@@ -375,6 +381,28 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
     e->adapter_cap = 4096;
     if (dalloc(e, &e->adapter, (size_t)e->adapter_cap * DD)) return fail();
 
+    // persistent decode kernel: only for the exact 4B decoder geometry on a 256-CU part
+    {
+        hipDeviceProp_t prop;
+        int coop = 0;
+        hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device);
+        const bool geom = d.dec_dim == pk::D && e->dec_qd == pk::DQ && e->dec_kvd == pk::DKV && d.dec_hidden == pk::DH &&
+                          d.dec_head_dim == pk::HD && d.vocab == pk::VOCAB && d.dec_window <= 8192;
+        if (geom && coop && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount == pk::NB &&
+            !getenv("VOX_HIP_NO_PERSIST")) {
+            std::vector<PersistLayer> pl(d.dec_layers);
+            for (int l = 0; l < d.dec_layers; l++) {
+                DecLayer &L = e->dec[l];
+                pl[l] = PersistLayer{L.wqkv, L.wo, L.w13, L.w2, L.n1, L.n2, L.ada, L.kring, L.vring};
+            }
+            if (dalloc(e, &e->d_players, pl.size()) == 0 && dalloc(e, &e->d_bar, 16) == 0 &&
+                hipMemcpy(e->d_players, pl.data(), pl.size() * sizeof(PersistLayer), hipMemcpyHostToDevice) == hipSuccess &&
+                hipFuncSetAttribute((const void *)k_decode_persist, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    pk::LDS_FLOATS * 4) == hipSuccess)
+                e->use_persist = true;
+        }
+    }
+
     // state-carrying stream buffers (zero = "start of sequence" left padding)
     if (ensure_keep(e, e->conv_in0, (size_t)(2 + 1024) * d.mel_bins * 4, 0)) return fail();
     if (ensure_keep(e, e->conv_in1, (size_t)(2 + 1024) * ED * 4, 0)) return fail();
@@ -395,7 +423,7 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     for (auto &L : e->dec) { F(L.wqkv); F(L.wo); F(L.w13); F(L.w2); F(L.n1); F(L.n2); F(L.ada); F(L.kring); F(L.vring); }
     F(e->hann); F(e->cosT); F(e->sinT); F(e->filtT); F(e->enc_inv_freq); F(e->dec_inv_freq); F(e->dec_rope);
     F(e->d_st); F(e->dx); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
-    F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter);
+    F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_players); F(e->d_bar);
     Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
                    &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml, &e->ssplitk};
     for (Buf *b : bufs) F(b->p);
@@ -1204,8 +1232,40 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
             if (ensure(e, e->stmp_out, (size_t)batch * V * 4)) return -1;
             lg = (float *)e->stmp_out.p;
         }
-        for (int i = 0; i < batch; i++)
-            enqueue_step(e, e->dec_pos + i, true, logits_out ? lg + (size_t)i * V : lg, eos_token, 1);
+        bool launched = false;
+        if (e->use_persist) {
+            // one cooperative launch for the whole batch (vox_persist.h)
+            PersistArgs pa{};
+            pa.layers = e->d_players; pa.n_layers = e->d.dec_layers; pa.tok_emb = e->tok_emb;
+            pa.final_norm = e->dec_final_norm; pa.inv_freq = e->dec_inv_freq; pa.adapter = e->adapter;
+            pa.st = e->d_st; pa.x = e->dx; pa.q = e->dq; pa.h = e->dh; pa.part_o = e->dpart_o; pa.part_ml = e->dpart_ml;
+            pa.logits = lg; pa.blk_val = e->blk_val; pa.blk_idx = e->blk_idx; pa.tokens_out = e->d_tokens; pa.bar = e->d_bar;
+            pa.n_steps = batch; pa.eos = eos_token; pa.kv_cap = e->dec_ring_cap; pa.window = e->d.dec_window; pa.eps = e->d.dec_eps;
+            pa.logits_stride = logits_out ? (long long)V : 0; pa.spin_limit = 5000000ull;   // 50 ms @ 100 MHz
+            HC(hipMemsetAsync(e->d_bar, 0, 16 * sizeof(unsigned), s));
+            void *kargs[] = {&pa};
+            hipError_t le = hipLaunchCooperativeKernel((const void *)k_decode_persist, dim3(pk::NB), dim3(pk::THREADS), kargs,
+                                                       pk::LDS_FLOATS * 4, s);
+            if (le == hipSuccess) {
+                unsigned errw = 0;
+                HC(hipMemcpyAsync(&errw, e->d_bar + 9, sizeof errw, hipMemcpyDeviceToHost, s));
+                HC(hipStreamSynchronize(s));
+                e->persist_runs++;
+                if (errw == 0) launched = true;
+                else {
+                    fprintf(stderr, "vox_hip: WARNING persistent decode kernel timed out at barrier %u; falling back to the multi-launch path\n", errw);
+                    e->use_persist = false; e->persist_failures++;
+                    if (set_state(e, e->dec_pos, prev_token, first_row + done - e->adapter_row0)) return -1;
+                }
+            } else {
+                (void)hipGetLastError();
+                fprintf(stderr, "vox_hip: WARNING cooperative launch refused (%s); using the multi-launch decode path\n", hipGetErrorString(le));
+                e->use_persist = false; e->persist_failures++;
+            }
+        }
+        if (!launched)
+            for (int i = 0; i < batch; i++)
+                enqueue_step(e, e->dec_pos + i, true, logits_out ? lg + (size_t)i * V : lg, eos_token, 1);
         DecState st{};
         HC(hipMemcpyAsync(&st, e->d_st, sizeof st, hipMemcpyDeviceToHost, s));
         HC(hipStreamSynchronize(s));

@@ -191,6 +191,10 @@ double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int kv_len);
  *  6 w2 gemv, 7 logits gemv, 8 argmax}; HIP events on the engine stream. Returns s/step. */
 double vox_hip_profile_decode(vox_hip_engine_t *e, int iters, int kv_len, double *avg_us, int *launches);
 
+/* Experiment: seconds per pass over ONE decoder layer's five kernels run back to back (weights
+ * stay in the 256 MB Infinity Cache), for comparison with the streamed per-layer time. */
+double vox_hip_time_layer_repeat(vox_hip_engine_t *e, int iters, int kv_len, double *avg_us, int *launches);
+
 /* Timing of the last fused calls (HIP events on the engine stream), milliseconds. */
 typedef struct vox_hip_timing {
     double encode_ms, prefill_ms, decode_ms;

@@ -388,8 +388,12 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
         hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device);
         const bool geom = d.dec_dim == pk::D && e->dec_qd == pk::DQ && e->dec_kvd == pk::DKV && d.dec_hidden == pk::DH &&
                           d.dec_head_dim == pk::HD && d.vocab == pk::VOCAB && d.dec_window <= 8192;
+        // Measured on MI355X (profiles/r01_run3_persistent_*): 4.4 ms/token vs 1.87 ms for the
+        // multi-launch path — every control-plane access (result stores, release, arrive, poll,
+        // acquire, activation staging) queues behind the CU's own in-flight weight stream, so a
+        // phase costs ~6 queue drains.  Kept as an opt-in experiment (VOX_HIP_PERSIST=1).
         if (geom && coop && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount == pk::NB &&
-            !getenv("VOX_HIP_NO_PERSIST")) {
+            getenv("VOX_HIP_PERSIST") && !getenv("VOX_HIP_NO_PERSIST")) {
             std::vector<PersistLayer> pl(d.dec_layers);
             for (int l = 0; l < d.dec_layers; l++) {
                 DecLayer &L = e->dec[l];
@@ -1450,6 +1454,19 @@ extern "C" double vox_hip_profile_decode(vox_hip_engine_t *e, int iters, int kv_
     }
     e->dec_pos = saved_pos;
     return total * 1e-3 / iters;
+}
+
+// Experiment hook: time `iters` passes over the five decode kernels of ONE layer (233 MB of
+// weights, which fit the 256 MB Infinity Cache) to see what the same launches cost when the
+// weights are cache-resident instead of streamed from HBM.  Returns seconds per layer pass.
+extern "C" double vox_hip_time_layer_repeat(vox_hip_engine_t *e, int iters, int kv_len, double *avg_us, int *launches) {
+    if (!e || iters <= 0 || e->d.dec_layers < 1) return -1.0;
+    const int saved_layers = e->d.dec_layers, saved_vocab = e->d.vocab, saved_grid = e->logits_grid;
+    e->d.dec_layers = 1;                       // enqueue_step walks layers [0, dec_layers)
+    e->d.vocab = 16; e->logits_grid = 1;       // shrink the logits pass to a stub (805 MB would flush the cache)
+    const double r = vox_hip_profile_decode(e, iters, kv_len, avg_us, launches);
+    e->d.dec_layers = saved_layers; e->d.vocab = saved_vocab; e->logits_grid = saved_grid;
+    return r;
 }
 
 // ------------------------------------------------------------------------------------

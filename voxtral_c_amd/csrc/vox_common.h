@@ -78,6 +78,19 @@ __device__ __forceinline__ uint4 ld_stream(const uint4 *p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// Async global -> LDS copy of 16 bytes per lane (gfx950 LDS-DMA): the wave's 64 pieces land at
+// lds_base (wave-uniform LDS byte address) + lane*16; no VGPR is used for the data.  hipcc does
+// not count asm memory operations: the caller waits with an explicit s_waitcnt vmcnt(N), N =
+// the number of YOUNGER loads it allows to stay in flight (loads return in order).
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) {     // generic pointer into LDS -> LDS byte offset
+    return (unsigned)(unsigned long long)p;
+}
+
 __device__ __forceinline__ float dot8_bf16(const uint4 w, const float4 x0, const float4 x1, float acc) {
     acc = fmaf(bf16_lo(w.x), x0.x, acc);
     acc = fmaf(bf16_hi(w.x), x0.y, acc);

@@ -438,4 +438,284 @@ __global__ __launch_bounds__(256) void k_step_begin(const DecState *st, const fl
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// k_gemv3 — k_gemv2 with the memory queue in the right order.
+//
+// Measured on MI355X (profiles/r01_run2_*): every k_gemv2 launch pays ~6 us on top of
+// bytes / 6.3 TB/s.  A CU's vector-memory path returns loads in issue order, so the x / norm /
+// partial loads that k_gemv2 issues AFTER its 24-36 weight loads per lane come back last: the
+// whole prologue (RMSNorm, attention merge) and every FMA then run after the weight stream has
+// drained instead of under it.  Here the order is
+//   1. epilogue operands (residual rows, position, RoPE frequencies)          [registers]
+//   2. the activation vector, norm weights, ada scale                          [LDS-DMA, no VGPRs]
+//      (attention partials of the Wo prologue: registers, issued in step 1)
+//   3. all weight loads, piece-major so that consumption order = arrival order [registers, nt]
+//   4. s_waitcnt vmcnt(#weight loads): (1) and (2) are in, the weights still stream
+//   5. prologue math in LDS, then the dot products piece by piece as the weights land.
+// K is a template constant (CPL * KS * 512).
+// ---------------------------------------------------------------------------------------
+template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int K = CPL * KS * 512;
+    constexpr int NX = K / 1024;      // 16-byte pieces of a K-float vector per thread
+    constexpr int NMAT = (EPI == EPI_SWIGLU) ? 2 : 1;
+    constexpr int RG = 4 / KS;        // row groups (waves along rows) per block
+    constexpr int NW = NMAT * RPW * CPL;
+    float *xs = smem;                 // [K]
+    float *red = smem + K;            // [64]: wave sums, KS partials
+    float *aux = smem + K + 64;       // PRO_RMS: norm_w [K], ada [K];  PRO_ATTN: scl [heads][8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave / KS, kp = wave % KS;
+    const int N = a.N;
+    const int row0 = (blockIdx.x * RG + rg) * RPW;
+
+    // ---- 1. epilogue operands ---------------------------------------------------------------
+    float yv[RPW];
+    float fr[(RPW + 1) / 2];
+    int pos = 0;
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int r = 0; r < RPW; r++) yv[r] = a.y[min(row0 + r, N - 1)];
+    }
+    if constexpr (EPI == EPI_QKV) {
+        pos = a.st->pos;
+#pragma unroll
+        for (int r = 0; r < RPW; r += 2) fr[r / 2] = a.inv_freq[((row0 + r) % a.head_dim) >> 1];
+    }
+    float4 ev[PRO == PRO_EMBED_RMS ? NX : 1];
+    uint2 eb[PRO == PRO_EMBED_RMS ? NX : 1];
+    if constexpr (PRO == PRO_EMBED_RMS) {
+        const float *arow = a.adapter + (size_t)a.st->adapter_row * K;
+        const uint16_t *erow = a.tok_emb + (size_t)a.st->token * K;
+#pragma unroll
+        for (int j = 0; j < NX; j++) {
+            ev[j] = *reinterpret_cast<const float4 *>(arow + j * 1024 + tid * 4);
+            eb[j] = *reinterpret_cast<const uint2 *>(erow + j * 1024 + tid * 4);
+        }
+    }
+    // PRO_ATTN: the split-K attention partials this thread merges, [NX pieces][<= 8 slices], and the
+    // (max, sum) pairs of head `tid`.  Predicated on the slice count; registers, not LDS, so that
+    // the 8-slice case does not need 128 KB of it.
+    const int ns = (PRO == PRO_ATTN) ? a.nsplit : 0;
+    float4 po[PRO == PRO_ATTN ? NX : 1][PRO == PRO_ATTN ? 8 : 1];
+    float2 pml[PRO == PRO_ATTN ? 8 : 1];
+    if constexpr (PRO == PRO_ATTN) {
+        const int HD = a.attn_hd;
+#pragma unroll
+        for (int sidx = 0; sidx < 8; sidx++) {
+            if (sidx < ns) {
+                if (tid < K / HD) pml[sidx] = *reinterpret_cast<const float2 *>(a.part_ml + ((size_t)tid * ns + sidx) * 2);
+#pragma unroll
+                for (int j = 0; j < NX; j++) {
+                    const int i = j * 1024 + tid * 4;
+                    const int h = i / HD, d = i - h * HD;
+                    po[j][sidx] = *reinterpret_cast<const float4 *>(a.part_o + ((size_t)h * ns + sidx) * HD + d);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 2. activation-side vectors straight into LDS ----------------------------------------
+    {
+        const unsigned wofs = (unsigned)wave * 1024u;            // this wave's 1 KiB of every 4 KiB slab
+        if constexpr (PRO == PRO_RMS || PRO == PRO_NONE) {
+#pragma unroll
+            for (int j = 0; j < NX; j++) glds16(a.x + j * 1024 + tid * 4, lds_addr(xs) + j * 4096u + wofs);
+        }
+        if constexpr (PRO == PRO_RMS || PRO == PRO_EMBED_RMS) {
+#pragma unroll
+            for (int j = 0; j < NX; j++) glds16(a.norm_w + j * 1024 + tid * 4, lds_addr(aux) + j * 4096u + wofs);
+            if (a.ada) {
+#pragma unroll
+                for (int j = 0; j < NX; j++) glds16(a.ada + j * 1024 + tid * 4, lds_addr(aux + K) + j * 4096u + wofs);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 3. every weight byte this wave needs, piece-major --------------------------------------
+    uint4 w[NMAT][RPW][CPL];
+    {
+        const uint4 *p0[RPW];
+        const uint4 *p1[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const int row = min(row0 + r, N - 1);
+            p0[r] = reinterpret_cast<const uint4 *>(a.W + (size_t)row * K) + kp * (CPL * 64) + lane;
+            if constexpr (NMAT == 2) p1[r] = reinterpret_cast<const uint4 *>(a.W2 + (size_t)row * K) + kp * (CPL * 64) + lane;
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+#pragma unroll
+            for (int r = 0; r < RPW; r++) w[0][r][c] = ld_stream(p0[r] + c * 64);
+            if constexpr (NMAT == 2) {
+#pragma unroll
+                for (int r = 0; r < RPW; r++) w[1][r][c] = ld_stream(p1[r] + c * 64);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 4. steps 1-2 have landed once at most NW loads are outstanding ------------------------
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+
+    // ---- 5. prologue math under the weight stream ------------------------------------------------
+    if constexpr (PRO == PRO_EMBED_RMS) {
+#pragma unroll
+        for (int j = 0; j < NX; j++) {
+            float4 v = ev[j];
+            v.x += bf16_lo(eb[j].x); v.y += bf16_hi(eb[j].x); v.z += bf16_lo(eb[j].y); v.w += bf16_hi(eb[j].y);
+            *reinterpret_cast<float4 *>(xs + j * 1024 + tid * 4) = v;
+            if (blockIdx.x == 0) *reinterpret_cast<float4 *>(a.x_out + j * 1024 + tid * 4) = v;
+        }
+    }
+    __syncthreads();
+    if constexpr (PRO == PRO_RMS || PRO == PRO_EMBED_RMS) {
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NX; j++) {
+            const float4 v = *reinterpret_cast<const float4 *>(xs + j * 1024 + tid * 4);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + a.eps);
+#pragma unroll
+        for (int j = 0; j < NX; j++) {
+            const float4 g = *reinterpret_cast<const float4 *>(aux + j * 1024 + tid * 4);
+            float4 o = *reinterpret_cast<const float4 *>(xs + j * 1024 + tid * 4);   // own elements: no hazard
+            o.x = o.x * inv * g.x; o.y = o.y * inv * g.y; o.z = o.z * inv * g.z; o.w = o.w * inv * g.w;
+            if (a.ada) {
+                const float4 sc = *reinterpret_cast<const float4 *>(aux + K + j * 1024 + tid * 4);
+                o.x *= (1.0f + sc.x); o.y *= (1.0f + sc.y); o.z *= (1.0f + sc.z); o.w *= (1.0f + sc.w);
+            }
+            *reinterpret_cast<float4 *>(xs + j * 1024 + tid * 4) = o;
+        }
+        __syncthreads();
+    }
+    if constexpr (PRO == PRO_ATTN) {
+        // x[h*HD + d] = sum_s o[h][s][d] * exp(m_s - m) / sum_s l_s exp(m_s - m)
+        float *scl = aux;                               // [heads][8]
+        const int HD = a.attn_hd, heads = K / HD;
+        if (tid < heads) {
+            float mm = -1e30f;
+#pragma unroll
+            for (int sidx = 0; sidx < 8; sidx++) if (sidx < ns) mm = fmaxf(mm, pml[sidx].x);
+            float ll = 0.f;
+#pragma unroll
+            for (int sidx = 0; sidx < 8; sidx++) if (sidx < ns) ll += pml[sidx].y * expf(pml[sidx].x - mm);
+            const float inv = ll > 0.f ? 1.0f / ll : 0.f;
+#pragma unroll
+            for (int sidx = 0; sidx < 8; sidx++) if (sidx < ns) scl[tid * 8 + sidx] = expf(pml[sidx].x - mm) * inv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NX; j++) {
+            const int i = j * 1024 + tid * 4;
+            const int h = i / HD;
+            float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int sidx = 0; sidx < 8; sidx++) {
+                if (sidx < ns) {
+                    const float f = scl[h * 8 + sidx];
+                    const float4 o = po[j][sidx];
+                    acc4.x += o.x * f; acc4.y += o.y * f; acc4.z += o.z * f; acc4.w += o.w * f;
+                }
+            }
+            *reinterpret_cast<float4 *>(xs + i) = acc4;
+        }
+        __syncthreads();
+    }
+    float cs[(RPW + 1) / 2], sn[(RPW + 1) / 2];
+    if constexpr (EPI == EPI_QKV) {
+        const float fpos = (float)pos;
+#pragma unroll
+        for (int r = 0; r < RPW; r += 2) {
+            const float ang = fpos * fr[r / 2];
+            cs[r / 2] = cosf(ang);
+            sn[r / 2] = sinf(ang);
+        }
+    }
+
+    // ---- 6. dot products, in arrival order ----------------------------------------------------
+    float acc[NMAT][RPW];
+#pragma unroll
+    for (int m = 0; m < NMAT; m++)
+#pragma unroll
+        for (int r = 0; r < RPW; r++) acc[m][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const float *xp = xs + ((kp * CPL + c) * 64 + lane) * 8;
+        const float4 x0 = *reinterpret_cast<const float4 *>(xp);
+        const float4 x1 = *reinterpret_cast<const float4 *>(xp + 4);
+#pragma unroll
+        for (int m = 0; m < NMAT; m++)
+#pragma unroll
+            for (int r = 0; r < RPW; r++) acc[m][r] = dot8_bf16(w[m][r][c], x0, x1, acc[m][r]);
+    }
+#pragma unroll
+    for (int m = 0; m < NMAT; m++)
+#pragma unroll
+        for (int r = 0; r < RPW; r++) acc[m][r] = wave_sum(acc[m][r]);
+    if constexpr (KS == 2) {
+        float *part = red + 16;                        // [RG][NMAT*RPW]
+        if (kp == 1 && lane == 0) {
+#pragma unroll
+            for (int m = 0; m < NMAT; m++)
+#pragma unroll
+                for (int r = 0; r < RPW; r++) part[rg * (NMAT * RPW) + m * RPW + r] = acc[m][r];
+        }
+        __syncthreads();
+        if (kp == 0) {
+#pragma unroll
+            for (int m = 0; m < NMAT; m++)
+#pragma unroll
+                for (int r = 0; r < RPW; r++) acc[m][r] += part[rg * (NMAT * RPW) + m * RPW + r];
+        }
+    }
+
+    // ---- 7. epilogue (no loads left) ------------------------------------------------------------
+    if (lane == 0 && kp == 0) {
+        if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+            for (int r = 0; r < RPW; r++) {
+                const int row = row0 + r;
+                if (row < N) a.y[row] = yv[r] + acc[0][r];
+            }
+        } else if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int r = 0; r < RPW; r++) {
+                const int row = row0 + r;
+                if (row < N) a.y[row] = silu(acc[0][r]) * acc[1][r];
+            }
+        } else if constexpr (EPI == EPI_QKV) {
+            const int slot = pos % a.kv_cap;
+            const int qk_rows = a.q_rows + a.k_rows;
+#pragma unroll
+            for (int r = 0; r < RPW; r += 2) {
+                const int row = row0 + r;
+                if (row + 1 < N) {
+                    float o0 = acc[0][r], o1 = acc[0][r + 1];
+                    if (row < qk_rows) {
+                        const float x0 = o0, x1 = o1;
+                        o0 = x0 * cs[r / 2] - x1 * sn[r / 2];
+                        o1 = x0 * sn[r / 2] + x1 * cs[r / 2];
+                    }
+                    float *dst;
+                    if (row < a.q_rows) dst = a.y + row;
+                    else if (row < qk_rows) dst = a.kcache + (size_t)slot * a.kv_dim + (row - a.q_rows);
+                    else dst = a.vcache + (size_t)slot * a.kv_dim + (row - qk_rows);
+                    dst[0] = o0;
+                    dst[1] = o1;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace vox

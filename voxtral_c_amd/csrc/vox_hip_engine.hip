@@ -78,7 +78,7 @@ struct vox_hip_engine {
     vox_hip_dims_t d{};
     int enc_qd = 0, dec_qd = 0, dec_kvd = 0;
     size_t mem_used = 0;
-    bool use_dpp = true, use_mfma = true, use_gemv2 = true, use_splitk = true;
+    bool use_dpp = true, use_mfma = true, use_gemv2 = true, use_gemv3 = true, use_splitk = true;
 
     // weights
     uint16_t *tok_emb = nullptr, *conv0_w = nullptr, *conv1_w = nullptr, *adapter0 = nullptr, *adapter1 = nullptr;
@@ -110,6 +110,7 @@ struct vox_hip_engine {
     DecState *d_st = nullptr;
     float *dx = nullptr, *dq = nullptr, *dattn = nullptr, *dh = nullptr, *dlogits = nullptr;
     float *blk_val = nullptr; int *blk_idx = nullptr; int logits_grid = 0;
+    unsigned long long *d_trace = nullptr;
     int *d_tokens = nullptr;
     float *dpart_o = nullptr, *dpart_ml = nullptr;   // decode-step split-K partials (max splits)
     int dec_max_split = 0;
@@ -1083,6 +1084,17 @@ static void launch_gemv2(vox_hip_engine *e, const GemvArgs &a) {
     hipLaunchKernelGGL((k_gemv2<PRO, EPI, RPW, CPL, KS, MINW>), dim3(grid), dim3(256), lds, e->stream, a);
 }
 
+template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW>
+static void launch_gemv3(vox_hip_engine *e, const GemvArgs &a) {
+    constexpr int K = CPL * KS * 512;
+    const int rows_per_block = (4 / KS) * RPW;
+    const int grid = (a.N + rows_per_block - 1) / rows_per_block;
+    size_t fl = K + 64;
+    if (PRO == PRO_RMS || PRO == PRO_EMBED_RMS) fl += 2 * (size_t)K;
+    if (PRO == PRO_ATTN) fl += 256;
+    hipLaunchKernelGGL((k_gemv3<PRO, EPI, RPW, CPL, KS, MINW>), dim3(grid), dim3(256), fl * sizeof(float), e->stream, a);
+}
+
 // Enqueue one decode step. kv_pos = logical position of this token (host mirror of st->pos).
 static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *logits_dst, int eos, int advance) {
     const vox_hip_dims_t &d = e->d;
@@ -1109,6 +1121,8 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             a.kcache = L.kring; a.vcache = L.vring; a.kv_cap = e->dec_ring_cap; a.kv_dim = DKV; a.st = e->d_st;
             a.inv_freq = e->dec_inv_freq; a.adapter = e->adapter; a.tok_emb = e->tok_emb; a.x_out = e->dx;
             if (!fast) launch_gemv<PRO_RMS, EPI_QKV, 4>(e, a);
+            else if (e->use_gemv3 && l == 0 && build_embed) launch_gemv3<PRO_EMBED_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
+            else if (e->use_gemv3) launch_gemv3<PRO_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
             else if (l == 0 && build_embed) launch_gemv2<PRO_EMBED_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
             else launch_gemv2<PRO_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
             prof_mark(e, PK_QKV);
@@ -1136,6 +1150,8 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             a.W = L.wo; a.x = e->dattn; a.y = e->dx; a.N = DD; a.K = DQ;
             a.part_o = e->dpart_o; a.part_ml = e->dpart_ml; a.nsplit = nsplit; a.attn_hd = HD;
             if (!fast) launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
+            else if (e->use_gemv3 && fuse_combine) launch_gemv3<PRO_ATTN, EPI_RESID, 3, 8, 1, 1>(e, a);
+            else if (e->use_gemv3) launch_gemv3<PRO_NONE, EPI_RESID, 3, 8, 1, 1>(e, a);
             else if (fuse_combine) launch_gemv2<PRO_ATTN, EPI_RESID, 3, 8, 1, 1>(e, a);
             else launch_gemv2<PRO_NONE, EPI_RESID, 3, 8, 1, 1>(e, a);
             prof_mark(e, PK_WO);
@@ -1145,6 +1161,7 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             a.W = L.w13; a.W2 = L.w13 + (size_t)DH * DD; a.x = e->dx; a.norm_w = L.n2; a.ada = L.ada; a.eps = d.dec_eps;
             a.y = e->dh; a.N = DH; a.K = DD;
             if (!fast) launch_gemv<PRO_RMS, EPI_SWIGLU, 2>(e, a);
+            else if (e->use_gemv3) launch_gemv3<PRO_RMS, EPI_SWIGLU, 3, 6, 1, 3>(e, a);
             else launch_gemv2<PRO_RMS, EPI_SWIGLU, 3, 6, 1, 3>(e, a);
             prof_mark(e, PK_SWIGLU);
         }
@@ -1152,6 +1169,7 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             GemvArgs a{};
             a.W = L.w2; a.x = e->dh; a.y = e->dx; a.N = DD; a.K = DH;
             if (!fast) launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
+            else if (e->use_gemv3) launch_gemv3<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
             else launch_gemv2<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
             prof_mark(e, PK_W2);
         }
@@ -1247,6 +1265,12 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
             pa.n_steps = batch; pa.eos = eos_token; pa.kv_cap = e->dec_ring_cap; pa.window = e->d.dec_window; pa.eps = e->d.dec_eps;
             pa.logits_stride = logits_out ? (long long)V : 0; pa.spin_limit = 5000000ull;   // 50 ms @ 100 MHz
             HC(hipMemsetAsync(e->d_bar, 0, 16 * sizeof(unsigned), s));
+            const char *trace_path = getenv("VOX_HIP_PERSIST_TRACE");
+            if (trace_path) {
+                if (!e->d_trace && hipMalloc(&e->d_trace, 2 * 4096 * 8) != hipSuccess) e->d_trace = nullptr;
+                if (e->d_trace) HC(hipMemsetAsync(e->d_trace, 0, 2 * 4096 * 8, s));
+                pa.trace = e->d_trace;
+            }
             void *kargs[] = {&pa};
             hipError_t le = hipLaunchCooperativeKernel((const void *)k_decode_persist, dim3(pk::NB), dim3(pk::THREADS), kargs,
                                                        pk::LDS_FLOATS * 4, s);
@@ -1255,6 +1279,11 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
                 HC(hipMemcpyAsync(&errw, e->d_bar + 9, sizeof errw, hipMemcpyDeviceToHost, s));
                 HC(hipStreamSynchronize(s));
                 e->persist_runs++;
+                if (trace_path && e->d_trace) {
+                    std::vector<unsigned long long> h(2 * 4096);
+                    HC(hipMemcpy(h.data(), e->d_trace, h.size() * 8, hipMemcpyDeviceToHost));
+                    if (FILE *f = fopen(trace_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+                }
                 if (errw == 0) launched = true;
                 else {
                     fprintf(stderr, "vox_hip: WARNING persistent decode kernel timed out at barrier %u; falling back to the multi-launch path\n", errw);
@@ -1518,6 +1547,7 @@ static int self_test(vox_hip_engine *e) {
     }
     if (getenv("VOX_HIP_NO_MFMA")) e->use_mfma = false;
     if (getenv("VOX_HIP_NO_GEMV2")) e->use_gemv2 = false;
+    if (getenv("VOX_HIP_NO_GEMV3")) e->use_gemv3 = false;
     if (getenv("VOX_HIP_NO_SPLITK")) e->use_splitk = false;
     hipFree(dx); hipFree(dy1); hipFree(dy2); hipFree(dw); hipFree(dbias);
     return 0;

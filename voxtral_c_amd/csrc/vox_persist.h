@@ -61,6 +61,7 @@ struct PersistArgs {
     float eps;
     long long logits_stride;        // 0: every step overwrites `logits`; else step i -> logits + i*stride
     unsigned long long spin_limit;  // wall_clock64 ticks (100 MHz) a barrier may wait
+    unsigned long long *trace;      // optional [2][4096] timestamps of blocks 0 and 131 (VOX_HIP_PERSIST_TRACE)
 };
 
 namespace pk {
@@ -114,15 +115,22 @@ __device__ __forceinline__ void hb_dot(const HB<NR, NC> &b, const float *xs, int
 
 // Control wave: arrive at / wait for grid barrier number `epoch` (1-based since launch).
 // Its own global stores (the phase results) precede this call in program order.
-__device__ __forceinline__ void ctrl_barrier(const PersistArgs &a, unsigned epoch, int lane) {
+struct Trace {
+    unsigned long long *p; int n;
+    __device__ __forceinline__ void mark() { if (p && n < 4096) p[n++] = wall_clock64(); }
+};
+
+__device__ __forceinline__ void ctrl_barrier(const PersistArgs &a, unsigned epoch, int lane, Trace &tr) {
     if (lane == 0) {
         unsigned *grp = a.bar + (blockIdx.x & 7);
         unsigned *top = a.bar + 8;
         unsigned *err = a.bar + 9;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr.mark();                                                                  // released
         const unsigned old = __hip_atomic_fetch_add(grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (((old + 1u) % (NB / 8)) == 0u) __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tr.mark();                                                                  // arrived
         const unsigned target = epoch * 8u;
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
             const unsigned long long t0 = wall_clock64();
@@ -135,7 +143,9 @@ __device__ __forceinline__ void ctrl_barrier(const PersistArgs &a, unsigned epoc
                 if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
             }
         }
+        tr.mark();                                                                  // everyone arrived
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        tr.mark();                                                                  // acquired
     }
 }
 
@@ -413,6 +423,8 @@ __device__ __forceinline__ void persist_control(const PersistArgs &a, const Pers
     using namespace pk;
     const int blk = blockIdx.x;
     unsigned epoch = 0;
+    Trace tr{nullptr, 0};
+    if (a.trace && lane == 0 && (blk == 0 || blk == 131)) tr.p = a.trace + (blk == 0 ? 0 : 4096);
     int pos = a.st->pos, token = a.st->token, stop = a.st->stop;
     long long arow = a.st->adapter_row;
     for (int step = 0; step < a.n_steps && !stop; step++) {
@@ -442,8 +454,10 @@ __device__ __forceinline__ void persist_control(const PersistArgs &a, const Pers
             } else {
                 ctrl_stage_rms(m.xs, a.x, L.n1, nullptr, a.eps, lane);
             }
+            tr.mark();
             __syncthreads();                                                       // S1
             __syncthreads();                                                       // S2
+            tr.mark();
             if (lane < 12) {              // the block's 24 rows = 12 (even, odd) RoPE pairs
                 const int row = blk * 24 + 2 * lane;
                 float o0 = m.outbox[2 * lane], o1 = m.outbox[2 * lane + 1];
@@ -462,15 +476,17 @@ __device__ __forceinline__ void persist_control(const PersistArgs &a, const Pers
                 dst[0] = o0;
                 dst[1] = o1;
             }
-            ctrl_barrier(a, ++epoch, lane);
+            ctrl_barrier(a, ++epoch, lane, tr);
             __syncthreads();                                                       // S3
             // ---- P2 ---------------------------------------------------------------------------
             if (attn_blk) {
                 const int kvh = blk & 7, split = blk >> 3;
                 for (int i = lane * 4; i < 4 * HD; i += 256)
                     *reinterpret_cast<float4 *>(m.qs + i) = *reinterpret_cast<const float4 *>(a.q + kvh * 4 * HD + i);
+                tr.mark();
                 __syncthreads();                                                   // S4a
                 __syncthreads();                                                   // S4b
+                tr.mark();
 #pragma unroll
                 for (int h = 0; h < 4; h++) {
                     float mm = m.at_m[h];
@@ -490,7 +506,7 @@ __device__ __forceinline__ void persist_control(const PersistArgs &a, const Pers
                     if (lane == 0) { a.part_ml[pidx * 2] = mm; a.part_ml[pidx * 2 + 1] = ll; }
                 }
             }
-            ctrl_barrier(a, ++epoch, lane);
+            ctrl_barrier(a, ++epoch, lane, tr);
             __syncthreads();                                                       // S5
             // ---- P3: merge the attention partials into xs --------------------------------------
             if (lane < 32) {
@@ -512,25 +528,31 @@ __device__ __forceinline__ void persist_control(const PersistArgs &a, const Pers
                 }
                 *reinterpret_cast<float4 *>(m.xs + i) = acc4;
             }
+            tr.mark();
             __syncthreads();                                                       // S6
             __syncthreads();                                                       // S7
+            tr.mark();
             if (lane < 12) a.x[blk * 12 + lane] = a.x[blk * 12 + lane] + m.outbox[lane];      // x += proj (voxtral_decoder.c:676)
-            ctrl_barrier(a, ++epoch, lane);
+            ctrl_barrier(a, ++epoch, lane, tr);
             __syncthreads();                                                       // S8
             // ---- P4 ---------------------------------------------------------------------------
             ctrl_stage_rms(m.xs, a.x, L.n2, L.ada, a.eps, lane);
+            tr.mark();
             __syncthreads();                                                       // S9
             __syncthreads();                                                       // S10
+            tr.mark();
             if (lane < 36) a.h[blk * 36 + lane] = m.outbox[lane];
-            ctrl_barrier(a, ++epoch, lane);
+            ctrl_barrier(a, ++epoch, lane, tr);
             __syncthreads();                                                       // S11
             // ---- P5 ---------------------------------------------------------------------------
             for (int i = lane * 4; i < DH; i += 256)
                 *reinterpret_cast<float4 *>(m.xs + i) = *reinterpret_cast<const float4 *>(a.h + i);
+            tr.mark();
             __syncthreads();                                                       // S12
             __syncthreads();                                                       // S13
+            tr.mark();
             if (lane < 12) a.x[blk * 12 + lane] = a.x[blk * 12 + lane] + m.outbox[lane];      // x += ffn (voxtral_decoder.c:689)
-            ctrl_barrier(a, ++epoch, lane);
+            ctrl_barrier(a, ++epoch, lane, tr);
             __syncthreads();                                                       // S14
         }
         // ---- PL ---------------------------------------------------------------------------------
@@ -553,7 +575,7 @@ __device__ __forceinline__ void persist_control(const PersistArgs &a, const Pers
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
         if (lane == 0) { a.blk_val[blk] = bv; a.blk_idx[blk] = bi; }
-        ctrl_barrier(a, ++epoch, lane);
+        ctrl_barrier(a, ++epoch, lane, tr);
         // every block reduces the 256 partials itself (same order everywhere => same token)
         bv = -3.0e38f; bi = 0x7fffffff;
 #pragma unroll

@@ -167,7 +167,7 @@ def main():
     dom = "gemv_swiglu"
     dom_ach = kernels.get(dom, {}).get("GBps", 0.0)
     roofline = {
-        "bound": "hbm", "kernel": "k_gemv2<PRO_RMS,EPI_SWIGLU,3,6,1,3> (decoder W1;W3 GEMV, 43% of the weight bytes of a token)",
+        "bound": "hbm", "kernel": "k_gemv3<PRO_RMS,EPI_SWIGLU,3,6,1,3> (decoder W1;W3 GEMV, 43% of the weight bytes of a token)",
         "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_ach / HBM_PEAK_GBS, 4),
         "bytes_per_launch": kern_bytes[dom], "avg_us_per_launch": kernels.get(dom, {}).get("avg_us"),
         "traffic": None,

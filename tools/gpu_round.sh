@@ -19,7 +19,7 @@ echo "== rocprofv3"
 echo "rocprof rc=$?"; ls gpurun_out/prof 2>/dev/null | head; 
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -24 "$f"
 echo "== rocprofv3 --pmc FETCH_SIZE (own pass, kernel-trace only)"
-( cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc" -o r1 -- \
-    python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --seconds 6 > "$GRAFT_REPO_ROOT/gpurun_out/pmc_bench.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/pmc.err" )
+( cd /tmp && timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc" -o r1 -- \
+    python "$GRAFT_REPO_ROOT/tools/pmc_decode.py" 4 > "$GRAFT_REPO_ROOT/gpurun_out/pmc_bench.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/pmc.err" )
 echo "pmc rc=$?"; ls gpurun_out/pmc 2>/dev/null | head
 python tools/pmc_summary.py gpurun_out/pmc gpurun_out/pmc_summary.json 2>&1 | tail -20

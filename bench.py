@@ -166,11 +166,22 @@ def main():
             kernels[name] = ent
     dom = "gemv_swiglu"
     dom_ach = kernels.get(dom, {}).get("GBps", 0.0)
+    # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in
+    # its own run, tools/run_pmc.sh; x1024 x2 correction of MI355X_MICROARCH.md, HBM section)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_decode_summary.json")) as fh:
+            pm = json.load(fh)["kernels"]
+        for name, ent in pm.items():
+            if "k_gemv3<1, 3, 3, 6, 1, 3>" in name:
+                traffic = round(ent["hbm_read_bytes_per_launch_corrected"])
+    except Exception:
+        traffic = None
     roofline = {
         "bound": "hbm", "kernel": "k_gemv3<PRO_RMS,EPI_SWIGLU,3,6,1,3> (decoder W1;W3 GEMV, 43% of the weight bytes of a token)",
         "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_ach / HBM_PEAK_GBS, 4),
         "bytes_per_launch": kern_bytes[dom], "avg_us_per_launch": kernels.get(dom, {}).get("avg_us"),
-        "traffic": None,
+        "traffic": traffic, "traffic_source": "profiles/r01_pmc_decode_summary.json (FETCH_SIZE, read bytes per launch)",
         "decode_step": {"algorithmic_bytes": wbytes + kvbytes, "ms": round(s_per_step * 1e3, 4),
                         "GBps": round((wbytes + kvbytes) / s_per_step / 1e9, 1),
                         "frac_of_peak": round((wbytes + kvbytes) / s_per_step / 1e9 / HBM_PEAK_GBS, 4),

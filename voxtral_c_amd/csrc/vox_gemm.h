@@ -52,6 +52,49 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// Fused epilogue shared by the MFMA kernels (C/D layout of every 32x32 MFMA: col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[2][2], int bm0, int bn0, int wm, int wn,
+                                              int li, int lg) {
+    const int M = a.M, N = a.N;
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+    if (a.ksplit > 1) {
+        float *P = a.partial + (size_t)blockIdx.z * M * N;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++) {
+                const int col = bn0 + wn * 64 + tn * 32 + li;
+                if (col >= N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = bm0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                    if (row < M) P[(size_t)row * N + col] = acc[tm][tn][r];
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++) {
+            const int col = bn0 + wn * 64 + tn * 32 + li;
+            if (col >= N) continue;
+            const float b = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = bm0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                if (row < M) {
+                    float v = acc[tm][tn][r];
+                    if (a.bias) v += b;
+                    v = apply_act(v, a.act);
+                    if (a.resid) v = a.resid[(size_t)row * a.ldr + col] + v;
+                    a.Y[(size_t)row * a.ldy + col] = v;
+                }
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void k_gemm_mfma_f32(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                     // [GB_M][GB_LD]
@@ -145,42 +188,141 @@ __global__ __launch_bounds__(256) void k_gemm_mfma_f32(const GemmArgs a) {
         }
     }
 
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
-    if (a.ksplit > 1) {
-        float *P = a.partial + (size_t)blockIdx.z * M * N;
+    gemm_epilogue(a, acc, bm0, bn0, wm, wn, li, lg);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_gemm_mfma_bf16x3 — the same product on the bf16 matrix pipe, still exact in the inputs.
+//
+// W is bf16 already.  An f32 activation x splits EXACTLY into three bf16 terms
+//     x = hi + mid + lo,   hi = trunc16(x), mid = trunc16(x - hi), lo = x - hi - mid
+// (24 significand bits = 3 x 8; every remainder is exactly representable), so
+//     sum_k W[n,k] x[m,k] = sum_k W hi + sum_k W mid + sum_k W lo
+// is three bf16 x bf16 MFMA passes whose products are exact and whose accumulation is f32 —
+// the oracle's arithmetic up to summation order, at 3/16 of the f32-MFMA instruction cost
+// (v_mfma_f32_32x32x16_bf16: 16 k per instruction at 16x the f32 rate).
+//
+// Tiling: 128x128 tile / 256 threads / 2x2 waves of 64x64 (2x2 MFMA tiles), K slices of 64.
+// LDS per slice: three A planes + one B plane, rows of 64 bf16 padded to 72 (144 B: the 16
+// lanes of a ds_read_b128 service group hit 16 distinct 16-byte slots).  A lane's fragment is
+// 8 consecutive k of its row (one ds_read_b128); A and B use the same k <-> (lane>>5, element)
+// map, which is all the dot product needs.  Global loads of slice t+1 are issued before the
+// MFMAs of slice t; the f32 -> 3 x bf16 split happens on the way into LDS.
+// ---------------------------------------------------------------------------------------
+constexpr int GX_K = 64, GX_LD = GX_K + 8;                    // bf16 elements per LDS row
+constexpr int GEMM_X3_LDS_BYTES = 4 * GB_M * GX_LD * 2;       // 3 A planes + B
+
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float x, uint32_t &h, uint32_t &m, uint32_t &l) {
+    const uint32_t xb = __float_as_uint(x);
+    h = xb & 0xffff0000u;
+    const float r1 = x - __uint_as_float(h);
+    const uint32_t rb = __float_as_uint(r1);
+    m = rb & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(m);
+    l = __float_as_uint(r2);                      // <= 8 significant bits: exact in the top half
+}
+
+__global__ __launch_bounds__(256) void k_gemm_mfma_bf16x3(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t *Ap = reinterpret_cast<uint16_t *>(smem);            // [3][GB_M][GX_LD]
+    uint16_t *Bs = Ap + 3 * GB_M * GX_LD;                         // [GB_N][GX_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bm0 = blockIdx.y * GB_M, bn0 = blockIdx.x * GB_N;
+    const int M = a.M, N = a.N, K = a.K;
+
+    f32x16 acc[2][2];
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++)
+    for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int tn = 0; tn < 2; tn++) {
-                const int col = bn0 + wn * 64 + tn * 32 + li;
-                if (col >= N) continue;
+        for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int row = bm0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-                    if (row < M) P[(size_t)row * N + col] = acc[tm][tn][r];
-                }
-            }
-        return;
-    }
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // staging: A slice 128 x 64 f32 = 2048 float4 -> 8 per thread (row = idx>>4, c4 = idx&15)
+    //          B slice 128 x 64 bf16 = 1024 uint4 -> 4 per thread (row = idx>>3, c8 = idx&7)
+    float4 ra[8];
+    uint4 rb[4];
+    auto load_slice = [&](int k0) {
 #pragma unroll
-    for (int tm = 0; tm < 2; tm++)
-#pragma unroll
-        for (int tn = 0; tn < 2; tn++) {
-            const int col = bn0 + wn * 64 + tn * 32 + li;
-            if (col >= N) continue;
-            const float b = a.bias ? a.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = bm0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-                if (row < M) {
-                    float v = acc[tm][tn][r];
-                    if (a.bias) v += b;
-                    v = apply_act(v, a.act);
-                    if (a.resid) v = a.resid[(size_t)row * a.ldr + col] + v;
-                    a.Y[(size_t)row * a.ldy + col] = v;
-                }
-            }
+        for (int i = 0; i < 8; i++) {
+            const int idx = tid + i * 256, row = idx >> 4, c4 = idx & 15;
+            const int gm = bm0 + row;
+            ra[i] = (gm < M) ? *reinterpret_cast<const float4 *>(a.X + (size_t)gm * a.ldx + k0 + c4 * 4)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = tid + i * 256, row = idx >> 3, c8 = idx & 7;
+            const int gn = bn0 + row;
+            rb[i] = (gn < N) ? *reinterpret_cast<const uint4 *>(a.W + (size_t)gn * K + k0 + c8 * 8)
+                             : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int idx = tid + i * 256, row = idx >> 4, c4 = idx & 15;
+            uint32_t h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+            split3(ra[i].x, h0, m0, l0); split3(ra[i].y, h1, m1, l1);
+            split3(ra[i].z, h2, m2, l2); split3(ra[i].w, h3, m3, l3);
+            // element k at the lower address: pack (k, k+1) as (hi16 of k) | (hi16 of k+1) << 16
+            uint2 ph, pm, pl;
+            ph.x = (h0 >> 16) | h1; ph.y = (h2 >> 16) | h3;
+            pm.x = (m0 >> 16) | m1; pm.y = (m2 >> 16) | m3;
+            pl.x = (l0 >> 16) | (l1 & 0xffff0000u); pl.y = (l2 >> 16) | (l3 & 0xffff0000u);
+            uint16_t *dst = Ap + row * GX_LD + c4 * 4;
+            *reinterpret_cast<uint2 *>(dst) = ph;
+            *reinterpret_cast<uint2 *>(dst + GB_M * GX_LD) = pm;
+            *reinterpret_cast<uint2 *>(dst + 2 * GB_M * GX_LD) = pl;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = tid + i * 256, row = idx >> 3, c8 = idx & 7;
+            *reinterpret_cast<uint4 *>(Bs + row * GX_LD + c8 * 8) = rb[i];
+        }
+    };
+
+    const int nk_total = K / GX_K;
+    const int kt0 = (a.ksplit > 1) ? blockIdx.z * a.kper : 0;
+    const int kt1 = (a.ksplit > 1) ? min(nk_total, kt0 + a.kper) : nk_total;
+    const int nk = kt1 - kt0;
+    const int li = lane & 31, lg = lane >> 5;
+    if (nk > 0) {
+        load_slice(kt0 * GX_K);
+        store_slice();
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; kt++) {
+        if (kt + 1 < nk) load_slice((kt0 + kt + 1) * GX_K);
+#pragma unroll
+        for (int kk = 0; kk < GX_K; kk += 16) {
+            bf16x8_t af[2][3], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const uint16_t *ap = Ap + (wm * 64 + t * 32 + li) * GX_LD + kk + lg * 8;
+#pragma unroll
+                for (int p = 0; p < 3; p++) af[t][p] = *reinterpret_cast<const bf16x8_t *>(ap + p * GB_M * GX_LD);
+                bf[t] = *reinterpret_cast<const bf16x8_t *>(Bs + (wn * 64 + t * 32 + li) * GX_LD + kk + lg * 8);
+            }
+#pragma unroll
+            for (int p = 2; p >= 0; p--)                       // small terms first
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                    for (int tn = 0; tn < 2; tn++)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][p], bf[tn], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_slice();
+            __syncthreads();
+        }
+    }
+    gemm_epilogue(a, acc, bm0, bn0, wm, wn, li, lg);
 }
 
 // Sum the split-K partials in split order and apply the fused epilogue.

@@ -78,7 +78,7 @@ struct vox_hip_engine {
     vox_hip_dims_t d{};
     int enc_qd = 0, dec_qd = 0, dec_kvd = 0;
     size_t mem_used = 0;
-    bool use_dpp = true, use_mfma = true, use_gemv2 = true, use_gemv3 = true, use_splitk = true;
+    bool use_dpp = true, use_mfma = true, use_gemv2 = true, use_gemv3 = true, use_splitk = true, use_bf16x3 = true;
 
     // weights
     uint16_t *tok_emb = nullptr, *conv0_w = nullptr, *conv1_w = nullptr, *adapter0 = nullptr, *adapter1 = nullptr;
@@ -194,31 +194,38 @@ static inline int grid1d(size_t work, int per_block = 256, int cap = 4096) {
 // GEMM / GEMV launchers
 // ------------------------------------------------------------------------------------
 static int ensure(vox_hip_engine *e, Buf &b, size_t bytes);
+// mode: 0 = best available, 1 = scalar reference kernel, 2 = f32-input MFMA kernel
 static void launch_gemm(vox_hip_engine *e, const float *X, int ldx, const uint16_t *W, float *Y, int ldy,
                         int M, int N, int K, const float *bias, const float *resid, int ldr, int act,
-                        int force_scalar = 0) {
+                        int mode = 0) {
     GemmArgs a{X, ldx, W, Y, ldy, M, N, K, bias, resid, ldr, act, 1, 0, nullptr};
     if (M <= 0 || N <= 0) return;
     const bool aligned = (K % GB_K == 0) && (ldx % 4 == 0) && ((size_t)X % 16 == 0);
-    if (e->use_mfma && aligned && !force_scalar) {
-        const int tn = (N + GB_N - 1) / GB_N, tm = (M + GB_M - 1) / GB_M, nk = K / GB_K;
+    if (e->use_mfma && aligned && mode != 1) {
+        // bf16 matrix pipe (3 exact bf16 terms per f32 activation) when K allows 64-wide slices
+        const bool x3 = e->use_bf16x3 && mode == 0 && (K % GX_K == 0);
+        const int slice = x3 ? GX_K : GB_K;
+        const size_t lds = x3 ? GEMM_X3_LDS_BYTES : GEMM_LDS_BYTES;
+        auto kern = x3 ? k_gemm_mfma_bf16x3 : k_gemm_mfma_f32;
+        const int tn = (N + GB_N - 1) / GB_N, tm = (M + GB_M - 1) / GB_M, nk = K / slice;
         // Fewer tiles than ~1.5 per CU: split K so that the chip is full (weights are then
         // streamed by >= 384 blocks instead of a few dozen); partials are reduced in a fixed order.
         int ksplit = 1;
-        if (e->use_splitk && tm * tn < 384 && nk >= 8) {
-            ksplit = std::min(std::min((512 + tm * tn - 1) / (tm * tn), nk / 4), 16);
+        const int min_slices = x3 ? 2 : 4;            // keep >= 128 k per split
+        if (e->use_splitk && tm * tn < 384 && nk >= 2 * min_slices) {
+            ksplit = std::min(std::min((512 + tm * tn - 1) / (tm * tn), nk / min_slices), 16);
             if (ksplit < 2) ksplit = 1;
         }
         if (ksplit > 1 && ensure(e, e->ssplitk, (size_t)ksplit * M * N * 4) == 0) {
             a.ksplit = ksplit; a.kper = (nk + ksplit - 1) / ksplit; a.partial = (float *)e->ssplitk.p;
             a.ksplit = (nk + a.kper - 1) / a.kper;          // drop empty trailing splits
             dim3 grid(tn, tm, a.ksplit);
-            hipLaunchKernelGGL(k_gemm_mfma_f32, grid, dim3(256), GEMM_LDS_BYTES, e->stream, a);
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, e->stream, a);
             hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((size_t)M * N)), dim3(256), 0, e->stream, a);
         } else {
             a.ksplit = 1;
             dim3 grid(tn, tm);
-            hipLaunchKernelGGL(k_gemm_mfma_f32, grid, dim3(256), GEMM_LDS_BYTES, e->stream, a);
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, e->stream, a);
         }
     } else {
         dim3 grid((N + 63) / 64, (M + 3) / 4);
@@ -1504,6 +1511,11 @@ extern "C" double vox_hip_time_layer_repeat(vox_hip_engine_t *e, int iters, int 
 // nothing ever falls back to the CPU.
 // ------------------------------------------------------------------------------------
 static int self_test(vox_hip_engine *e) {
+    if (hipFuncSetAttribute((const void *)k_gemm_mfma_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GEMM_X3_LDS_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        e->use_bf16x3 = false;
+    }
     // (1) DPP
     float *d_a = nullptr, *d_b = nullptr;
     HC(hipMalloc((void **)&d_a, 64 * 4)); HC(hipMalloc((void **)&d_b, 64 * 4));
@@ -1518,9 +1530,9 @@ static int self_test(vox_hip_engine *e) {
     hipFree(d_a); hipFree(d_b);
     if (getenv("VOX_HIP_NO_DPP")) e->use_dpp = false;
 
-    // (2) MFMA GEMM vs scalar kernel on an asymmetric 160 x 192 x 64 problem
-    const int M = 160, N = 192, K = 64;
-    std::vector<float> hx((size_t)M * K), hy1((size_t)M * N), hy2((size_t)M * N), hbias(N);
+    // (2) MFMA GEMMs (bf16x3 and f32-input) vs the scalar kernel on an asymmetric 160 x 192 x 128 problem
+    const int M = 160, N = 192, K = 128;
+    std::vector<float> hx((size_t)M * K), hy0((size_t)M * N), hy1((size_t)M * N), hy2((size_t)M * N), hbias(N);
     std::vector<uint16_t> hw((size_t)N * K);
     for (int m = 0; m < M; m++) for (int k = 0; k < K; k++) hx[(size_t)m * K + k] = 0.01f * (float)((m * 7 + k * 3) % 29 - 14) + 0.001f * m;
     for (int n = 0; n < N; n++) for (int k = 0; k < K; k++) {
@@ -1528,27 +1540,38 @@ static int self_test(vox_hip_engine *e) {
         uint32_t u; memcpy(&u, &v, 4); hw[(size_t)n * K + k] = (uint16_t)(u >> 16);
     }
     for (int n = 0; n < N; n++) hbias[n] = 0.1f * (float)(n % 7);
-    float *dx, *dy1, *dy2, *dbias; uint16_t *dw;
-    HC(hipMalloc((void **)&dx, hx.size() * 4)); HC(hipMalloc((void **)&dy1, hy1.size() * 4)); HC(hipMalloc((void **)&dy2, hy2.size() * 4));
+    float *dx, *dy0, *dy1, *dy2, *dbias; uint16_t *dw;
+    HC(hipMalloc((void **)&dx, hx.size() * 4)); HC(hipMalloc((void **)&dy0, hy0.size() * 4));
+    HC(hipMalloc((void **)&dy1, hy1.size() * 4)); HC(hipMalloc((void **)&dy2, hy2.size() * 4));
     HC(hipMalloc((void **)&dw, hw.size() * 2)); HC(hipMalloc((void **)&dbias, N * 4));
     HC(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
     HC(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     HC(hipMemcpy(dbias, hbias.data(), N * 4, hipMemcpyHostToDevice));
-    launch_gemm(e, dx, K, dw, dy1, N, M, N, K, dbias, nullptr, 0, ACT_NONE, 0);
+    launch_gemm(e, dx, K, dw, dy0, N, M, N, K, dbias, nullptr, 0, ACT_NONE, 0);
+    launch_gemm(e, dx, K, dw, dy1, N, M, N, K, dbias, nullptr, 0, ACT_NONE, 2);
     launch_gemm(e, dx, K, dw, dy2, N, M, N, K, dbias, nullptr, 0, ACT_NONE, 1);
     HC(hipStreamSynchronize(e->stream));
+    HC(hipMemcpy(hy0.data(), dy0, hy0.size() * 4, hipMemcpyDeviceToHost));
     HC(hipMemcpy(hy1.data(), dy1, hy1.size() * 4, hipMemcpyDeviceToHost));
     HC(hipMemcpy(hy2.data(), dy2, hy2.size() * 4, hipMemcpyDeviceToHost));
-    double maxd = 0;
-    for (size_t i = 0; i < hy1.size(); i++) maxd = std::max(maxd, (double)fabsf(hy1[i] - hy2[i]));
-    if (!(maxd < 1e-4)) {
+    double maxd0 = 0, maxd = 0;
+    for (size_t i = 0; i < hy1.size(); i++) {
+        maxd0 = std::max(maxd0, (double)fabsf(hy0[i] - hy2[i]));
+        maxd = std::max(maxd, (double)fabsf(hy1[i] - hy2[i]));
+    }
+    if (!(maxd0 < 2e-5)) {
+        fprintf(stderr, "vox_hip: WARNING bf16x3 MFMA GEMM self-test failed (max diff %g); using the f32-input MFMA GEMM\n", maxd0);
+        e->use_bf16x3 = false;
+    }
+    if (!(maxd < 2e-5)) {
         fprintf(stderr, "vox_hip: WARNING MFMA GEMM self-test failed (max diff %g); using the scalar HIP GEMM\n", maxd);
         e->use_mfma = false;
     }
+    if (getenv("VOX_HIP_NO_BF16X3")) e->use_bf16x3 = false;
     if (getenv("VOX_HIP_NO_MFMA")) e->use_mfma = false;
     if (getenv("VOX_HIP_NO_GEMV2")) e->use_gemv2 = false;
     if (getenv("VOX_HIP_NO_GEMV3")) e->use_gemv3 = false;
     if (getenv("VOX_HIP_NO_SPLITK")) e->use_splitk = false;
-    hipFree(dx); hipFree(dy1); hipFree(dy2); hipFree(dw); hipFree(dbias);
+    hipFree(dx); hipFree(dy0); hipFree(dy1); hipFree(dy2); hipFree(dw); hipFree(dbias);
     return 0;
 }

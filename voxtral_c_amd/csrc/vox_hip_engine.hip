@@ -78,7 +78,7 @@ struct vox_hip_engine {
     vox_hip_dims_t d{};
     int enc_qd = 0, dec_qd = 0, dec_kvd = 0;
     size_t mem_used = 0;
-    bool use_dpp = true, use_mfma = true, use_gemv2 = true, use_gemv3 = true, use_splitk = true, use_bf16x3 = true;
+    bool use_dpp = true, use_mfma = true, use_gemv2 = true, use_gemv3 = true, use_splitk = true, use_bf16x3 = true, use_attn_mfma = true;
 
     // weights
     uint16_t *tok_emb = nullptr, *conv0_w = nullptr, *conv1_w = nullptr, *adapter0 = nullptr, *adapter1 = nullptr;
@@ -595,7 +595,10 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
                 if (ensure(e, e->spart_ml, (size_t)n * c.heads * ks * 2 * 4)) return -1;
                 a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
             }
-            hipLaunchKernelGGL((k_attn_rows<64>), dim3(qt, c.heads, ks), dim3(128), 0, s, a);
+            if (e->use_attn_mfma && c.hd == 64 && c.heads == c.kv_heads)
+                hipLaunchKernelGGL(k_attn_enc_mfma, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((k_attn_rows<64>), dim3(qt, c.heads, ks), dim3(128), 0, s, a);
             if (ks > 1)
                 hipLaunchKernelGGL((k_attn_combine<64>), dim3(c.heads, n), dim3(64), 0, s, attn, c.QD,
                                    (const float *)a.part_o, (const float *)a.part_ml, c.heads, ks);
@@ -1400,7 +1403,9 @@ extern "C" int vox_hip_causal_attention(vox_hip_engine_t *e, float *out, const f
     a.st = nullptr; a.split_keys = DEC_SPLIT_KEYS;
     float *po = nullptr, *pml = nullptr;
     int rc = 0;
-    if (head_dim == 64) {
+    if (head_dim == 64 && e->use_attn_mfma && n_heads == n_kv_heads) {
+        hipLaunchKernelGGL(k_attn_enc_mfma, dim3((seq_q + 127) / 128, n_heads), dim3(256), 0, e->stream, a);
+    } else if (head_dim == 64) {
         hipLaunchKernelGGL((k_attn_rows<64>), dim3((seq_q + 127) / 128, n_heads), dim3(128), 0, e->stream, a);
     } else if (head_dim == 128 && n_heads == 4 * n_kv_heads) {
         const int max_len = std::min(q_offset + seq_q, a.window);
@@ -1568,6 +1573,42 @@ static int self_test(vox_hip_engine *e) {
         e->use_mfma = false;
     }
     if (getenv("VOX_HIP_NO_BF16X3")) e->use_bf16x3 = false;
+
+    // (3) MFMA encoder attention vs the thread-per-query kernel: 200 queries, 2 heads, window 90
+    {
+        const int nq = 200, nh = 2, hd = 64, ld = nh * hd, win = 90;
+        std::vector<float> hq((size_t)nq * ld), hk((size_t)nq * ld), hv((size_t)nq * ld), r1((size_t)nq * ld), r2((size_t)nq * ld);
+        for (size_t i = 0; i < hq.size(); i++) {
+            hq[i] = 0.05f * (float)((int)((i * 2654435761u) >> 20 & 63) - 31);
+            hk[i] = 0.04f * (float)((int)((i * 40503u + 77u) >> 7 & 63) - 30);
+            hv[i] = 0.03f * (float)((int)((i * 9973u + 5u) >> 3 & 127) - 64);
+        }
+        float *dq, *dk, *dv, *do1, *do2;
+        HC(hipMalloc((void **)&dq, hq.size() * 4)); HC(hipMalloc((void **)&dk, hq.size() * 4)); HC(hipMalloc((void **)&dv, hq.size() * 4));
+        HC(hipMalloc((void **)&do1, hq.size() * 4)); HC(hipMalloc((void **)&do2, hq.size() * 4));
+        HC(hipMemcpy(dq, hq.data(), hq.size() * 4, hipMemcpyHostToDevice));
+        HC(hipMemcpy(dk, hk.data(), hq.size() * 4, hipMemcpyHostToDevice));
+        HC(hipMemcpy(dv, hv.data(), hq.size() * 4, hipMemcpyHostToDevice));
+        AttnArgs a{};
+        a.ldo = ld; a.q = dq; a.ldq = ld; a.n_q = nq; a.qpos0 = 0; a.kB = dk; a.vB = dv; a.ldB = ld; a.posB0 = 0;
+        a.last_key = nq - 1; a.kA = dk; a.vA = dv; a.capA = 1 << 30; a.ldA = ld; a.n_heads = nh; a.n_kv_heads = nh;
+        a.scale = 0.125f; a.window = win; a.st = nullptr;
+        a.out = do1;
+        hipLaunchKernelGGL(k_attn_enc_mfma, dim3((nq + 127) / 128, nh), dim3(256), 0, e->stream, a);
+        a.out = do2;
+        hipLaunchKernelGGL((k_attn_rows<64>), dim3((nq + 127) / 128, nh), dim3(128), 0, e->stream, a);
+        HC(hipStreamSynchronize(e->stream));
+        HC(hipMemcpy(r1.data(), do1, r1.size() * 4, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(r2.data(), do2, r2.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0;
+        for (size_t i = 0; i < r1.size(); i++) md = std::max(md, (double)fabsf(r1[i] - r2[i]));
+        if (!(md < 1e-4)) {
+            fprintf(stderr, "vox_hip: WARNING MFMA attention self-test failed (max diff %g); using the VALU attention kernel\n", md);
+            e->use_attn_mfma = false;
+        }
+        hipFree(dq); hipFree(dk); hipFree(dv); hipFree(do1); hipFree(do2);
+        if (getenv("VOX_HIP_NO_ATTN_MFMA")) e->use_attn_mfma = false;
+    }
     if (getenv("VOX_HIP_NO_MFMA")) e->use_mfma = false;
     if (getenv("VOX_HIP_NO_GEMV2")) e->use_gemv2 = false;
     if (getenv("VOX_HIP_NO_GEMV3")) e->use_gemv3 = false;

@@ -44,6 +44,7 @@ struct AttnArgs {
     int split_keys;                 // keys per blockIdx.y
     float *part_o, *part_ml;        // [n_q][n_heads][nsplit][HD], [..][2]
     int force_partials;             // write partials even when nsplit == 1 (merged by the Wo GEMV prologue)
+    PdlArgs pdl;                    // overlapped launches (vox_common.h); st must be null then
 };
 
 template <int HD>
@@ -366,9 +367,10 @@ __global__ __launch_bounds__(256) void k_attn_enc_mfma(const AttnArgs a) {
 // ---------------------------------------------------------------------------------
 // Decoder attention.  grid = (n_kv_heads, nsplit, n_q); block = 256 (4 waves).
 // ---------------------------------------------------------------------------------
-template <int HD, int HPK, bool USE_DPP>
+template <int HD, int HPK, bool USE_DPP, bool PDL = false>
 __global__ __launch_bounds__(256) void k_attn_dec(const AttnArgs a, const int nsplit) {
     static_assert(HD == 128, "16 lanes x 8 dims");
+    if constexpr (PDL) pdl_wait(a.pdl);          // q and this position's K/V row come from the predecessor
     __shared__ float sm_m[4][HPK], sm_l[4][HPK];
     __shared__ __attribute__((aligned(16))) float sm_o[4][HPK][HD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -489,18 +491,22 @@ __global__ __launch_bounds__(256) void k_attn_dec(const AttnArgs a, const int ns
                 o1 += sm_o[w][h][d0 + 1] * f;
             }
             const int head = kvh * HPK + h;
+            auto put = [&](float *p, float v) {
+                if constexpr (PDL) pdl_store(p, v); else *p = v;
+            };
             if (nsplit == 1 && !a.force_partials) {
                 const float inv = ll > 0.f ? 1.0f / ll : 0.f;
                 float *op = a.out + (size_t)qi * a.ldo + head * HD + d0;
-                op[0] = o0 * inv; op[1] = o1 * inv;
+                put(op, o0 * inv); put(op + 1, o1 * inv);
             } else {
                 const size_t pidx = ((size_t)qi * a.n_heads + head) * nsplit + split;
-                a.part_o[pidx * HD + d0] = o0;
-                a.part_o[pidx * HD + d0 + 1] = o1;
-                if (d0 == 0) { a.part_ml[pidx * 2] = mm; a.part_ml[pidx * 2 + 1] = ll; }
+                put(a.part_o + pidx * HD + d0, o0);
+                put(a.part_o + pidx * HD + d0 + 1, o1);
+                if (d0 == 0) { put(a.part_ml + pidx * 2, mm); put(a.part_ml + pidx * 2 + 1, ll); }
             }
         }
     }
+    if constexpr (PDL) pdl_signal(a.pdl);
 }
 
 // Merge split-K partials.  grid = (n_heads, n_q), block = HD threads.

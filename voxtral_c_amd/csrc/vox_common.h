@@ -19,6 +19,64 @@ struct DecState {
     long long adapter_row;  // physical adapter row of this step
 };
 
+// ---------------------------------------------------------------------------------------
+// Overlapped dependent launches ("software PDL").  The decode step is a chain of ~130 short
+// HBM-streaming kernels; each pays ~3 us of ramp-up / drain during which HBM idles.  The chain
+// is therefore issued alternately on two HIP streams whose CU masks split the chip in halves:
+// kernel g+1 starts on its half while kernel g is still running on the other half, issues its
+// weight loads (they depend on nothing), and only then waits for kernel g's completion counter
+// before touching kernel g's output.  Disjoint CU sets matter: a CU's vector-memory path is a
+// FIFO, so on a shared CU the producer's result stores would queue behind the consumer's
+// prefetch (measured: profiles/r01_run3_persistent_*).
+//   producer: payload stores are agent-scope relaxed atomic stores (sc1, write-through), then
+//             s_waitcnt vmcnt(0), then one relaxed agent-scope add per block on its counter;
+//   consumer: thread 0 polls the counter (bounded), agent-scope acquire fence, __syncthreads.
+// Counters grow monotonically; the host passes the cumulative value to wait for (wrap-safe).
+// ---------------------------------------------------------------------------------------
+struct PdlArgs {
+    unsigned *flags;        // [2] completion counters (slot = launch parity); null = plain launch
+    unsigned *err;          // set to a non-zero code when a wait times out
+    int wait_slot;          // < 0: nothing to wait for
+    unsigned wait_val;
+    int sig_slot;           // < 0: nothing to signal
+    unsigned long long spin_limit;   // wall_clock64 ticks (100 MHz)
+};
+
+// All threads of the block call this (contains a __syncthreads()).
+__device__ __forceinline__ void pdl_wait(const PdlArgs &p) {
+    if (p.flags && p.wait_slot >= 0) {
+        if (threadIdx.x == 0) {
+            const unsigned *f = p.flags + p.wait_slot;
+            const unsigned long long t0 = wall_clock64();
+            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.wait_val) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // chain already broken
+                if (wall_clock64() - t0 > p.spin_limit) {
+                    __hip_atomic_store(p.err, 1u + (unsigned)p.wait_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+}
+// Payload store that is visible to other CUs once vmcnt has drained (write-through).
+__device__ __forceinline__ void pdl_store(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pdl_store(int *p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// All threads of the block call this after their pdl_store()s (contains a __syncthreads()).
+__device__ __forceinline__ void pdl_signal(const PdlArgs &p) {
+    if (p.flags && p.sig_slot >= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(p.flags + p.sig_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

@@ -48,15 +48,20 @@ struct GemvArgs {
     float *x_out;              // PRO_EMBED_RMS: residual stream (written by block 0)
     const float *part_o, *part_ml;   // PRO_ATTN: split-K attention partials [heads][nsplit][HD], [..][2]
     int nsplit, attn_hd;
+    // overlapped launches (vox_common.h, PdlArgs): pos_host replaces st->pos (the host knows it)
+    PdlArgs pdl;
+    int pos_host;
+    int row_base;              // EPI_LOGITS: added to the row index reported in blk_idx (vocabulary halves)
 };
 
-template <int PRO, int EPI, int RPW>
+template <int PRO, int EPI, int RPW, bool PDL = false>
 __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *xs = smem;                 // [K]
     float *red = smem + a.K;          // [16] scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, N = a.N;
+    if constexpr (PDL) pdl_wait(a.pdl);
 
     // ---- prologue: stage x in LDS, optionally RMS-normalised --------------------
     float ss = 0.f;
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
                         const float v = acc[0][r];
                         a.y[row] = v;
                         // strict '>' scan => lowest index wins ties (voxtral_decoder.c:697-704)
-                        if (v > best_v || (v == best_v && row < best_i)) { best_v = v; best_i = row; }
+                        if (v > best_v || (v == best_v && row + a.row_base < best_i)) { best_v = v; best_i = row + a.row_base; }
                     }
                 }
             }
@@ -188,10 +193,11 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
             float bv = rv[0]; int bi = ri[0];
             for (int w = 1; w < 4; w++)
                 if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
-            a.blk_val[blockIdx.x] = bv;
-            a.blk_idx[blockIdx.x] = bi;
+            if constexpr (PDL) { pdl_store(a.blk_val + blockIdx.x, bv); pdl_store(a.blk_idx + blockIdx.x, bi); }
+            else { a.blk_val[blockIdx.x] = bv; a.blk_idx[blockIdx.x] = bi; }
         }
     }
+    if constexpr (PDL) pdl_signal(a.pdl);
 }
 
 
@@ -386,10 +392,11 @@ __global__ __launch_bounds__(256, MINW) void k_gemv2(const GemvArgs a) {
 // One block of 256 threads.
 __global__ __launch_bounds__(256) void k_argmax_finish(const float *blk_val, const int *blk_idx, int nblk,
                                                        DecState *st, int *tokens_out, int eos_token,
-                                                       int advance) {
+                                                       int advance, const PdlArgs pdl) {
     __shared__ float sv[256];
     __shared__ int si[256];
     const int tid = threadIdx.x;
+    pdl_wait(pdl);
     float bv = -3.0e38f; int bi = 0x7fffffff;
     for (int i = tid; i < nblk; i += 256) {
         const float v = blk_val[i]; const int ix = blk_idx[i];
@@ -407,13 +414,19 @@ __global__ __launch_bounds__(256) void k_argmax_finish(const float *blk_val, con
     if (tid == 0) {
         const int tok = si[0];
         if (!st->stop) {
-            tokens_out[st->n_out] = tok;
-            st->n_out += 1;
-            st->token = tok;
-            if (advance) { st->pos += 1; st->adapter_row += 1; }
-            if (tok == eos_token) st->stop = 1;
+            // write-through stores: under overlapped launches the next step's first kernel may
+            // already be resident on the other half of the chip
+            pdl_store(tokens_out + st->n_out, tok);
+            pdl_store(&st->n_out, st->n_out + 1);
+            pdl_store(&st->token, tok);
+            if (advance) {
+                pdl_store(&st->pos, st->pos + 1);
+                __hip_atomic_store(&st->adapter_row, st->adapter_row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tok == eos_token) pdl_store(&st->stop, 1);
         }
     }
+    pdl_signal(pdl);
 }
 
 // Start of a decode step: RoPE row for the current position and (optionally) the
@@ -455,7 +468,7 @@ __global__ __launch_bounds__(256) void k_step_begin(const DecState *st, const fl
 //   5. prologue math in LDS, then the dot products piece by piece as the weights land.
 // K is a template constant (CPL * KS * 512).
 // ---------------------------------------------------------------------------------------
-template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW>
+template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW, bool PDL>
 __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = CPL * KS * 512;
@@ -471,56 +484,57 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
     const int rg = wave / KS, kp = wave % KS;
     const int N = a.N;
     const int row0 = (blockIdx.x * RG + rg) * RPW;
+    const int ns = (PRO == PRO_ATTN) ? a.nsplit : 0;
 
-    // ---- 1. epilogue operands ---------------------------------------------------------------
+    // ---- operand loads, as lambdas so that the two launch modes can order them ----------------
     float yv[RPW];
     float fr[(RPW + 1) / 2];
     int pos = 0;
-    if constexpr (EPI == EPI_RESID) {
+    auto load_epilogue_operands = [&]() {      // never produced by the immediate predecessor
+        if constexpr (EPI == EPI_RESID) {
 #pragma unroll
-        for (int r = 0; r < RPW; r++) yv[r] = a.y[min(row0 + r, N - 1)];
-    }
-    if constexpr (EPI == EPI_QKV) {
-        pos = a.st->pos;
+            for (int r = 0; r < RPW; r++) yv[r] = a.y[min(row0 + r, N - 1)];
+        }
+        if constexpr (EPI == EPI_QKV) {
+            pos = PDL ? a.pos_host : a.st->pos;
 #pragma unroll
-        for (int r = 0; r < RPW; r += 2) fr[r / 2] = a.inv_freq[((row0 + r) % a.head_dim) >> 1];
-    }
+            for (int r = 0; r < RPW; r += 2) fr[r / 2] = a.inv_freq[((row0 + r) % a.head_dim) >> 1];
+        }
+    };
     float4 ev[PRO == PRO_EMBED_RMS ? NX : 1];
     uint2 eb[PRO == PRO_EMBED_RMS ? NX : 1];
-    if constexpr (PRO == PRO_EMBED_RMS) {
-        const float *arow = a.adapter + (size_t)a.st->adapter_row * K;
-        const uint16_t *erow = a.tok_emb + (size_t)a.st->token * K;
-#pragma unroll
-        for (int j = 0; j < NX; j++) {
-            ev[j] = *reinterpret_cast<const float4 *>(arow + j * 1024 + tid * 4);
-            eb[j] = *reinterpret_cast<const uint2 *>(erow + j * 1024 + tid * 4);
-        }
-    }
-    // PRO_ATTN: the split-K attention partials this thread merges, [NX pieces][<= 8 slices], and the
-    // (max, sum) pairs of head `tid`.  Predicated on the slice count; registers, not LDS, so that
-    // the 8-slice case does not need 128 KB of it.
-    const int ns = (PRO == PRO_ATTN) ? a.nsplit : 0;
     float4 po[PRO == PRO_ATTN ? NX : 1][PRO == PRO_ATTN ? 8 : 1];
     float2 pml[PRO == PRO_ATTN ? 8 : 1];
-    if constexpr (PRO == PRO_ATTN) {
-        const int HD = a.attn_hd;
+    auto load_activation_registers = [&]() {   // step embedding / attention partials -> registers
+        if constexpr (PRO == PRO_EMBED_RMS) {
+            const float *arow = a.adapter + (size_t)a.st->adapter_row * K;
+            const uint16_t *erow = a.tok_emb + (size_t)a.st->token * K;
 #pragma unroll
-        for (int sidx = 0; sidx < 8; sidx++) {
-            if (sidx < ns) {
-                if (tid < K / HD) pml[sidx] = *reinterpret_cast<const float2 *>(a.part_ml + ((size_t)tid * ns + sidx) * 2);
+            for (int j = 0; j < NX; j++) {
+                ev[j] = *reinterpret_cast<const float4 *>(arow + j * 1024 + tid * 4);
+                eb[j] = *reinterpret_cast<const uint2 *>(erow + j * 1024 + tid * 4);
+            }
+        }
+        if constexpr (PRO == PRO_ATTN) {
+            // [NX pieces][<= 8 slices] of the split-K partials this thread merges and the (max, sum)
+            // pairs of head `tid`; predicated on the slice count; registers, not LDS, so that the
+            // 8-slice case does not need 128 KB of it.
+            const int HD = a.attn_hd;
 #pragma unroll
-                for (int j = 0; j < NX; j++) {
-                    const int i = j * 1024 + tid * 4;
-                    const int h = i / HD, d = i - h * HD;
-                    po[j][sidx] = *reinterpret_cast<const float4 *>(a.part_o + ((size_t)h * ns + sidx) * HD + d);
+            for (int sidx = 0; sidx < 8; sidx++) {
+                if (sidx < ns) {
+                    if (tid < K / HD) pml[sidx] = *reinterpret_cast<const float2 *>(a.part_ml + ((size_t)tid * ns + sidx) * 2);
+#pragma unroll
+                    for (int j = 0; j < NX; j++) {
+                        const int i = j * 1024 + tid * 4;
+                        const int h = i / HD, d = i - h * HD;
+                        po[j][sidx] = *reinterpret_cast<const float4 *>(a.part_o + ((size_t)h * ns + sidx) * HD + d);
+                    }
                 }
             }
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- 2. activation-side vectors straight into LDS ----------------------------------------
-    {
+    };
+    auto issue_lds_dma = [&]() {               // activation vector, norm weights, ada -> LDS
         const unsigned wofs = (unsigned)wave * 1024u;            // this wave's 1 KiB of every 4 KiB slab
         if constexpr (PRO == PRO_RMS || PRO == PRO_NONE) {
 #pragma unroll
@@ -534,12 +548,9 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
                 for (int j = 0; j < NX; j++) glds16(a.ada + j * 1024 + tid * 4, lds_addr(aux + K) + j * 4096u + wofs);
             }
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- 3. every weight byte this wave needs, piece-major --------------------------------------
+    };
     uint4 w[NMAT][RPW][CPL];
-    {
+    auto issue_weight_loads = [&]() {          // every weight byte of this wave, piece-major
         const uint4 *p0[RPW];
         const uint4 *p1[RPW];
 #pragma unroll
@@ -557,13 +568,35 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
                 for (int r = 0; r < RPW; r++) w[1][r][c] = ld_stream(p1[r] + c * 64);
             }
         }
+    };
+
+    if constexpr (!PDL) {
+        // plain launch: everything this kernel reads is final.  Activation side first (it is
+        // needed first and a CU's memory path is in-order), then the weight stream.
+        load_epilogue_operands();
+        load_activation_registers();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_lds_dma();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_weight_loads();
+        __builtin_amdgcn_sched_barrier(0);
+        // the older loads have landed once at most NW (the weights) are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+    } else {
+        // overlapped launch: the predecessor may still be running.  Its output is the activation
+        // side, so the weight stream goes first and the wait sits between the two.
+        load_epilogue_operands();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_weight_loads();
+        __builtin_amdgcn_sched_barrier(0);
+        pdl_wait(a.pdl);
+        load_activation_registers();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_lds_dma();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- 4. steps 1-2 have landed once at most NW loads are outstanding ------------------------
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
-
-    // ---- 5. prologue math under the weight stream ------------------------------------------------
+    // ---- prologue math (plain launch: under the weight stream) ---------------------------------
     if constexpr (PRO == PRO_EMBED_RMS) {
 #pragma unroll
         for (int j = 0; j < NX; j++) {
@@ -642,7 +675,7 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
         }
     }
 
-    // ---- 6. dot products, in arrival order ----------------------------------------------------
+    // ---- dot products, in arrival order ----------------------------------------------------------
     float acc[NMAT][RPW];
 #pragma unroll
     for (int m = 0; m < NMAT; m++)
@@ -679,19 +712,22 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
         }
     }
 
-    // ---- 7. epilogue (no loads left) ------------------------------------------------------------
+    // ---- epilogue (no loads left).  Overlapped launches publish with write-through stores ------
+    auto put = [&](float *p, float v) {
+        if constexpr (PDL) pdl_store(p, v); else *p = v;
+    };
     if (lane == 0 && kp == 0) {
         if constexpr (EPI == EPI_RESID) {
 #pragma unroll
             for (int r = 0; r < RPW; r++) {
                 const int row = row0 + r;
-                if (row < N) a.y[row] = yv[r] + acc[0][r];
+                if (row < N) put(a.y + row, yv[r] + acc[0][r]);
             }
         } else if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
             for (int r = 0; r < RPW; r++) {
                 const int row = row0 + r;
-                if (row < N) a.y[row] = silu(acc[0][r]) * acc[1][r];
+                if (row < N) put(a.y + row, silu(acc[0][r]) * acc[1][r]);
             }
         } else if constexpr (EPI == EPI_QKV) {
             const int slot = pos % a.kv_cap;
@@ -710,12 +746,13 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
                     if (row < a.q_rows) dst = a.y + row;
                     else if (row < qk_rows) dst = a.kcache + (size_t)slot * a.kv_dim + (row - a.q_rows);
                     else dst = a.vcache + (size_t)slot * a.kv_dim + (row - qk_rows);
-                    dst[0] = o0;
-                    dst[1] = o1;
+                    put(dst, o0);
+                    put(dst + 1, o1);
                 }
             }
         }
     }
+    if constexpr (PDL) pdl_signal(a.pdl);
 }
 
 }  // namespace vox

@@ -111,6 +111,13 @@ struct vox_hip_engine {
     float *dx = nullptr, *dq = nullptr, *dattn = nullptr, *dh = nullptr, *dlogits = nullptr;
     float *blk_val = nullptr; int *blk_idx = nullptr; int logits_grid = 0;
     unsigned long long *d_trace = nullptr;
+    // overlapped decode chain
+    bool use_pdl = false, pdl_first = true;
+    hipStream_t pdl_stream[2] = {nullptr, nullptr};
+    hipEvent_t pdl_ev[3] = {nullptr, nullptr, nullptr};
+    unsigned *d_pdl = nullptr;          // [0..1] completion counters, [2] error word
+    unsigned pdl_g = 0, pdl_cum[2] = {0, 0};
+    int pdl_runs = 0, pdl_failures = 0;
     int *d_tokens = nullptr;
     float *dpart_o = nullptr, *dpart_ml = nullptr;   // decode-step split-K partials (max splits)
     int dec_max_split = 0;
@@ -317,7 +324,21 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
     e->dec_qd = d.dec_heads * d.dec_head_dim;
     e->dec_kvd = d.dec_kv_heads * d.dec_head_dim;
     auto fail = [&]() -> vox_hip_engine_t * { vox_hip_engine_destroy(e); return nullptr; };
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return fail();
+    if (const char *cm = getenv("VOX_HIP_CUMASK")) {
+        // experiment: run everything on a CU-masked stream ("lo"/"hi" = bits 0-127 / 128-255,
+        // "even"/"odd" = alternating bits, "q0" = bits 0-63) to see what half the CUs can stream
+        uint32_t mask[8];
+        for (int i = 0; i < 8; i++) {
+            if (!strcmp(cm, "lo")) mask[i] = i < 4 ? 0xffffffffu : 0u;
+            else if (!strcmp(cm, "hi")) mask[i] = i < 4 ? 0u : 0xffffffffu;
+            else if (!strcmp(cm, "even")) mask[i] = 0x55555555u;
+            else if (!strcmp(cm, "odd")) mask[i] = 0xaaaaaaaau;
+            else if (!strcmp(cm, "q0")) mask[i] = i < 2 ? 0xffffffffu : 0u;
+            else mask[i] = 0xffffffffu;
+        }
+        if (hipExtStreamCreateWithCUMask(&e->stream, 8, mask) != hipSuccess) return fail();
+        fprintf(stderr, "vox_hip: CU-masked stream (%s)\n", cm);
+    } else if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return fail();
     if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) return fail();
 
     const size_t ED = d.enc_dim, EQ = e->enc_qd, EH = d.enc_hidden;
@@ -415,6 +436,24 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
         }
     }
 
+    // overlapped decode chain: two streams, each restricted to one half of the CUs
+    {
+        hipDeviceProp_t prop;
+        const bool geom = d.dec_dim == 3072 && e->dec_qd == 4096 && e->dec_kvd == 1024 && d.dec_hidden == 9216 &&
+                          d.dec_head_dim == 128 && d.vocab % 32768 == 0;
+        if (geom && !getenv("VOX_HIP_NO_PDL") && hipGetDeviceProperties(&prop, device) == hipSuccess &&
+            prop.multiProcessorCount == 256) {
+            uint32_t lo[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0, 0};
+            uint32_t hi[8] = {0, 0, 0, 0, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            bool ok = hipExtStreamCreateWithCUMask(&e->pdl_stream[0], 8, lo) == hipSuccess &&
+                      hipExtStreamCreateWithCUMask(&e->pdl_stream[1], 8, hi) == hipSuccess;
+            for (int i = 0; i < 3 && ok; i++) ok = hipEventCreateWithFlags(&e->pdl_ev[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && dalloc(e, &e->d_pdl, 4) == 0 && hipMemset(e->d_pdl, 0, 16) == hipSuccess;
+            if (ok) e->use_pdl = true;
+            else { (void)hipGetLastError(); fprintf(stderr, "vox_hip: CU-masked streams unavailable; plain decode launches\n"); }
+        }
+    }
+
     // state-carrying stream buffers (zero = "start of sequence" left padding)
     if (ensure_keep(e, e->conv_in0, (size_t)(2 + 1024) * d.mel_bins * 4, 0)) return fail();
     if (ensure_keep(e, e->conv_in1, (size_t)(2 + 1024) * ED * 4, 0)) return fail();
@@ -435,12 +474,14 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     for (auto &L : e->dec) { F(L.wqkv); F(L.wo); F(L.w13); F(L.w2); F(L.n1); F(L.n2); F(L.ada); F(L.kring); F(L.vring); }
     F(e->hann); F(e->cosT); F(e->sinT); F(e->filtT); F(e->enc_inv_freq); F(e->dec_inv_freq); F(e->dec_rope);
     F(e->d_st); F(e->dx); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
-    F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_players); F(e->d_bar);
+    F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_players); F(e->d_bar); F(e->d_pdl);
     Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
                    &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml, &e->ssplitk};
     for (Buf *b : bufs) F(b->p);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
+    for (int i = 0; i < 3; i++) if (e->pdl_ev[i]) hipEventDestroy(e->pdl_ev[i]);
+    for (int i = 0; i < 2; i++) if (e->pdl_stream[i]) hipStreamDestroy(e->pdl_stream[i]);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1102,7 +1143,7 @@ static void launch_gemv3(vox_hip_engine *e, const GemvArgs &a) {
     size_t fl = K + 64;
     if (PRO == PRO_RMS || PRO == PRO_EMBED_RMS) fl += 2 * (size_t)K;
     if (PRO == PRO_ATTN) fl += 256;
-    hipLaunchKernelGGL((k_gemv3<PRO, EPI, RPW, CPL, KS, MINW>), dim3(grid), dim3(256), fl * sizeof(float), e->stream, a);
+    hipLaunchKernelGGL((k_gemv3<PRO, EPI, RPW, CPL, KS, MINW, false>), dim3(grid), dim3(256), fl * sizeof(float), e->stream, a);
 }
 
 // Enqueue one decode step. kv_pos = logical position of this token (host mirror of st->pos).
@@ -1191,8 +1232,122 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
         launch_gemv<PRO_RMS, EPI_LOGITS, 4>(e, a, e->logits_grid);
         prof_mark(e, PK_LOGITS);
         hipLaunchKernelGGL(k_argmax_finish, dim3(1), dim3(256), 0, s, (const float *)e->blk_val, (const int *)e->blk_idx,
-                           e->logits_grid, e->d_st, e->d_tokens, eos, advance);
+                           e->logits_grid, e->d_st, e->d_tokens, eos, advance, PdlArgs{});
         prof_mark(e, PK_ARGMAX);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Overlapped decode chain (vox_common.h, PdlArgs): kernels alternate between two CU-masked
+// streams (one half of the chip each); kernel g waits in-kernel for kernel g-1's completion
+// counter after it has issued its own weight loads.
+// ------------------------------------------------------------------------------------
+static hipStream_t pdl_next(vox_hip_engine *e, int blocks, PdlArgs &p) {
+    const unsigned g = e->pdl_g++;
+    p.flags = e->d_pdl; p.err = e->d_pdl + 2; p.spin_limit = 2000000ull;       // 20 ms @ 100 MHz
+    if (e->pdl_first) { p.wait_slot = -1; p.wait_val = 0; e->pdl_first = false; }
+    else { p.wait_slot = (int)((g - 1) & 1u); p.wait_val = e->pdl_cum[(g - 1) & 1u]; }
+    p.sig_slot = (int)(g & 1u);
+    e->pdl_cum[g & 1u] += (unsigned)blocks;
+    return e->pdl_stream[g & 1u];
+}
+static int pdl_begin(vox_hip_engine *e) {            // fork: both halves wait for the engine stream
+    HC(hipEventRecord(e->pdl_ev[2], e->stream));
+    HC(hipStreamWaitEvent(e->pdl_stream[0], e->pdl_ev[2], 0));
+    HC(hipStreamWaitEvent(e->pdl_stream[1], e->pdl_ev[2], 0));
+    e->pdl_first = true;
+    return 0;
+}
+static int pdl_end(vox_hip_engine *e) {              // join: the engine stream waits for both halves
+    HC(hipEventRecord(e->pdl_ev[0], e->pdl_stream[0]));
+    HC(hipEventRecord(e->pdl_ev[1], e->pdl_stream[1]));
+    HC(hipStreamWaitEvent(e->stream, e->pdl_ev[0], 0));
+    HC(hipStreamWaitEvent(e->stream, e->pdl_ev[1], 0));
+    return 0;
+}
+
+template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW>
+static void launch_gemv3_pdl(vox_hip_engine *e, GemvArgs &a) {
+    constexpr int K = CPL * KS * 512;
+    const int rows_per_block = (4 / KS) * RPW;
+    const int grid = (a.N + rows_per_block - 1) / rows_per_block;
+    size_t fl = K + 64;
+    if (PRO == PRO_RMS || PRO == PRO_EMBED_RMS) fl += 2 * (size_t)K;
+    if (PRO == PRO_ATTN) fl += 256;
+    hipStream_t s = pdl_next(e, grid, a.pdl);
+    hipLaunchKernelGGL((k_gemv3<PRO, EPI, RPW, CPL, KS, MINW, true>), dim3(grid), dim3(256), fl * sizeof(float), s, a);
+}
+
+// One decode step of the 4B geometry as an overlapped chain (between pdl_begin / pdl_end).
+static void enqueue_step_pdl(vox_hip_engine *e, int kv_pos, float *logits_dst, int eos, int advance) {
+    const vox_hip_dims_t &d = e->d;
+    const int DD = d.dec_dim, DQ = e->dec_qd, DKV = e->dec_kvd, DH = d.dec_hidden, HD = d.dec_head_dim;
+    const int kv_len = std::min(kv_pos + 1, d.dec_window);
+    int split_keys = dec_split_keys(kv_len);
+    while ((kv_len + split_keys - 1) / split_keys > 8) split_keys *= 2;     // the Wo prologue merges <= 8 slices
+    const int nsplit = (kv_len + split_keys - 1) / split_keys;
+    const float scale = 1.0f / sqrtf((float)HD);
+    for (int l = 0; l < d.dec_layers; l++) {
+        DecLayer &L = e->dec[l];
+        {
+            GemvArgs a{};
+            a.W = L.wqkv; a.x = e->dx; a.norm_w = L.n1; a.ada = nullptr; a.eps = d.dec_eps; a.y = e->dq;
+            a.N = DQ + 2 * DKV; a.K = DD; a.q_rows = DQ; a.k_rows = DKV; a.head_dim = HD; a.rope = e->dec_rope;
+            a.kcache = L.kring; a.vcache = L.vring; a.kv_cap = e->dec_ring_cap; a.kv_dim = DKV; a.st = e->d_st;
+            a.inv_freq = e->dec_inv_freq; a.adapter = e->adapter; a.tok_emb = e->tok_emb; a.x_out = e->dx;
+            a.pos_host = kv_pos;
+            if (l == 0) launch_gemv3_pdl<PRO_EMBED_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
+            else launch_gemv3_pdl<PRO_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
+        }
+        {
+            AttnArgs a{};
+            a.out = e->dattn; a.ldo = DQ; a.q = e->dq; a.ldq = DQ; a.n_q = 1; a.qpos0 = kv_pos;
+            a.posB0 = INT_MAX; a.last_key = kv_pos; a.kA = L.kring; a.vA = L.vring; a.capA = e->dec_ring_cap; a.ldA = DKV;
+            a.n_heads = d.dec_heads; a.n_kv_heads = d.dec_kv_heads; a.scale = scale; a.window = d.dec_window;
+            a.st = nullptr; a.split_keys = split_keys; a.part_o = e->dpart_o; a.part_ml = e->dpart_ml;
+            a.force_partials = 1;
+            hipStream_t s = pdl_next(e, d.dec_kv_heads * nsplit, a.pdl);
+            if (e->use_dpp)
+                hipLaunchKernelGGL((k_attn_dec<128, 4, true, true>), dim3(d.dec_kv_heads, nsplit, 1), dim3(256), 0, s, a, nsplit);
+            else
+                hipLaunchKernelGGL((k_attn_dec<128, 4, false, true>), dim3(d.dec_kv_heads, nsplit, 1), dim3(256), 0, s, a, nsplit);
+        }
+        {
+            GemvArgs a{};
+            a.W = L.wo; a.x = e->dattn; a.y = e->dx; a.N = DD; a.K = DQ;
+            a.part_o = e->dpart_o; a.part_ml = e->dpart_ml; a.nsplit = nsplit; a.attn_hd = HD;
+            launch_gemv3_pdl<PRO_ATTN, EPI_RESID, 3, 8, 1, 1>(e, a);
+        }
+        {
+            GemvArgs a{};
+            a.W = L.w13; a.W2 = L.w13 + (size_t)DH * DD; a.x = e->dx; a.norm_w = L.n2; a.ada = L.ada; a.eps = d.dec_eps;
+            a.y = e->dh; a.N = DH; a.K = DD;
+            launch_gemv3_pdl<PRO_RMS, EPI_SWIGLU, 3, 6, 1, 3>(e, a);
+        }
+        {
+            GemvArgs a{};
+            a.W = L.w2; a.x = e->dh; a.y = e->dx; a.N = DD; a.K = DH;
+            launch_gemv3_pdl<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
+        }
+    }
+    // tied-embedding logits: one vocabulary half per CU half, then the argmax over all partials
+    const int half_rows = d.vocab / 2, half_grid = e->logits_grid / 2;
+    for (int hf = 0; hf < 2; hf++) {
+        GemvArgs a{};
+        a.W = e->tok_emb + (size_t)hf * half_rows * DD; a.x = e->dx; a.norm_w = e->dec_final_norm; a.eps = d.dec_eps;
+        a.y = logits_dst + (size_t)hf * half_rows; a.N = half_rows; a.K = DD;
+        a.blk_val = e->blk_val + hf * half_grid; a.blk_idx = e->blk_idx + hf * half_grid; a.row_base = hf * half_rows;
+        hipStream_t s = pdl_next(e, half_grid, a.pdl);
+        if (hf == 1) {                               // both halves depend on the last w2 launch (g-2 for this one):
+            a.pdl.wait_slot = -1;                    // it precedes this launch on the same stream
+        }
+        hipLaunchKernelGGL((k_gemv<PRO_RMS, EPI_LOGITS, 4, true>), dim3(half_grid), dim3(256), ((size_t)DD + 16) * sizeof(float), s, a);
+    }
+    {
+        PdlArgs p{};
+        hipStream_t s = pdl_next(e, 1, p);
+        hipLaunchKernelGGL(k_argmax_finish, dim3(1), dim3(256), 0, s, (const float *)e->blk_val, (const int *)e->blk_idx,
+                           e->logits_grid, e->d_st, e->d_tokens, eos, advance, p);
     }
 }
 
@@ -1304,6 +1459,23 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
                 (void)hipGetLastError();
                 fprintf(stderr, "vox_hip: WARNING cooperative launch refused (%s); using the multi-launch decode path\n", hipGetErrorString(le));
                 e->use_persist = false; e->persist_failures++;
+            }
+        }
+        if (!launched && e->use_pdl) {
+            HC(hipMemsetAsync(e->d_pdl + 2, 0, sizeof(unsigned), s));
+            if (pdl_begin(e)) return -1;
+            for (int i = 0; i < batch; i++)
+                enqueue_step_pdl(e, e->dec_pos + i, logits_out ? lg + (size_t)i * V : lg, eos_token, 1);
+            if (pdl_end(e)) return -1;
+            unsigned errw = 0;
+            HC(hipMemcpyAsync(&errw, e->d_pdl + 2, sizeof errw, hipMemcpyDeviceToHost, s));
+            HC(hipStreamSynchronize(s));
+            e->pdl_runs++;
+            if (errw == 0) launched = true;
+            else {
+                fprintf(stderr, "vox_hip: WARNING overlapped decode chain timed out (code %u); falling back to plain launches\n", errw);
+                e->use_pdl = false; e->pdl_failures++;
+                if (set_state(e, e->dec_pos, prev_token, first_row + done - e->adapter_row0)) return -1;
             }
         }
         if (!launched)
@@ -1447,10 +1619,21 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
         hipMemsetAsync(e->adapter, 0, (size_t)e->d.dec_dim * 4, e->stream);
     }
     if (set_state(e, pos, 1, 0)) return -1.0;
-    for (int i = 0; i < 3; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);   // warm-up
-    hipEventRecord(e->ev0, e->stream);
-    for (int i = 0; i < iters; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);
-    hipEventRecord(e->ev1, e->stream);
+    if (e->use_pdl) {
+        pdl_begin(e);
+        for (int i = 0; i < 3; i++) enqueue_step_pdl(e, pos, e->dlogits, -1, 0);  // warm-up
+        pdl_end(e);
+        hipEventRecord(e->ev0, e->stream);
+        pdl_begin(e);
+        for (int i = 0; i < iters; i++) enqueue_step_pdl(e, pos, e->dlogits, -1, 0);
+        pdl_end(e);
+        hipEventRecord(e->ev1, e->stream);
+    } else {
+        for (int i = 0; i < 3; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);   // warm-up
+        hipEventRecord(e->ev0, e->stream);
+        for (int i = 0; i < iters; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);
+        hipEventRecord(e->ev1, e->stream);
+    }
     hipStreamSynchronize(e->stream);
     float ms = 0.f;
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
@@ -1495,6 +1678,13 @@ extern "C" double vox_hip_profile_decode(vox_hip_engine_t *e, int iters, int kv_
     }
     e->dec_pos = saved_pos;
     return total * 1e-3 / iters;
+}
+
+// Which decode path vox_hip_decoder_run uses: 0 = plain launches, 1 = overlapped chain on two
+// CU-masked streams, 2 = persistent kernel (opt-in experiment).
+extern "C" int vox_hip_decode_path(vox_hip_engine_t *e) {
+    if (!e) return -1;
+    return e->use_persist ? 2 : (e->use_pdl ? 1 : 0);
 }
 
 // Experiment hook: time `iters` passes over the five decode kernels of ONE layer (233 MB of

@@ -192,8 +192,8 @@ double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int kv_len);
 double vox_hip_profile_decode(vox_hip_engine_t *e, int iters, int kv_len, double *avg_us, int *launches);
 
 /* Decode path used by vox_hip_decoder_run: 0 plain launches, 1 overlapped chain on two CU-masked
- * streams (default on a 256-CU part with the 4B geometry; VOX_HIP_NO_PDL=1 disables), 2 persistent
- * kernel (VOX_HIP_PERSIST=1, experiment). */
+ * streams (VOX_HIP_PDL=1, experiment: slower than plain launches), 2 persistent kernel
+ * (VOX_HIP_PERSIST=1, experiment). */
 int vox_hip_decode_path(vox_hip_engine_t *e);
 
 /* Experiment: seconds per pass over ONE decoder layer's five kernels run back to back (weights

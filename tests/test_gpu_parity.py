@@ -313,6 +313,25 @@ def test_stream_full_size_matches_reference_golden(vox):
         assert res["steps"] == res["ref_steps"], res
 
 
+def test_overlapped_decode_chain_matches_plain_launches(vox):
+    """Opt-in experiment (VOX_HIP_PDL=1): decode kernels alternate between two CU-masked streams
+    and wait in-kernel for their predecessor.  Same kernels, same arithmetic: tokens must equal
+    those of plain in-order launches."""
+    audio = synth_speech(12.0, 77)
+    os.environ["VOX_HIP_PDL"] = "1"
+    try:
+        with vox.Model(model_dir("full")) as m:
+            path = vox.hip.vox_hip_decode_path(m.engine)
+            b = m.transcribe(audio)
+    finally:
+        del os.environ["VOX_HIP_PDL"]
+    with vox.Model(model_dir("full")) as m2:
+        assert vox.hip.vox_hip_decode_path(m2.engine) == 0
+        c = m2.transcribe(audio)
+    assert path == 1, "overlapped chain not active on this device"
+    assert len(c["tokens"]) > 100 and b["tokens"] == c["tokens"]
+
+
 def test_persistent_decode_kernel_matches_multi_launch_path(vox):
     """vox_persist.h (one cooperative launch for the whole greedy loop) against the per-GEMV
     launch path on the full-size model: same token ids, logits equal to float rounding."""

@@ -33,8 +33,13 @@ struct DecState {
 //   consumer: thread 0 polls the counter (bounded), agent-scope acquire fence, __syncthreads.
 // Counters grow monotonically; the host passes the cumulative value to wait for (wrap-safe).
 // ---------------------------------------------------------------------------------------
+constexpr int PDL_SLOT_STRIDE = 64;     // counters live 256 B apart (own cache lines); error word at [2 * stride]
+#ifndef PDL_POLL_SLEEP
+#define PDL_POLL_SLEEP 4                // x 64 clocks between polls
+#endif
+
 struct PdlArgs {
-    unsigned *flags;        // [2] completion counters (slot = launch parity); null = plain launch
+    unsigned *flags;        // completion counters at [slot * PDL_SLOT_STRIDE] (slot = launch parity); null = plain launch
     unsigned *err;          // set to a non-zero code when a wait times out
     int wait_slot;          // < 0: nothing to wait for
     unsigned wait_val;
@@ -46,14 +51,23 @@ struct PdlArgs {
 __device__ __forceinline__ void pdl_wait(const PdlArgs &p) {
     if (p.flags && p.wait_slot >= 0) {
         if (threadIdx.x == 0) {
-            const unsigned *f = p.flags + p.wait_slot;
-            const unsigned long long t0 = wall_clock64();
-            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.wait_val) < 0) {
-                __builtin_amdgcn_s_sleep(1);
-                if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // chain already broken
-                if (wall_clock64() - t0 > p.spin_limit) {
-                    __hip_atomic_store(p.err, 1u + (unsigned)p.wait_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+            // Every resident block of the consumer polls one word: keep the request rate low (the
+            // word's memory channel also carries 1/N of everybody's weight stream) and touch the
+            // error word only on the slow path.
+            const unsigned *f = p.flags + p.wait_slot * PDL_SLOT_STRIDE;
+            if ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.wait_val) < 0) {
+                const unsigned long long t0 = wall_clock64();
+                unsigned it = 0;
+                for (;;) {
+                    __builtin_amdgcn_s_sleep(PDL_POLL_SLEEP);
+                    if ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.wait_val) >= 0) break;
+                    if ((++it & 63u) == 0u) {
+                        if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // chain already broken
+                        if (wall_clock64() - t0 > p.spin_limit) {
+                            __hip_atomic_store(p.err, 1u + (unsigned)p.wait_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -73,7 +87,7 @@ __device__ __forceinline__ void pdl_signal(const PdlArgs &p) {
     if (p.flags && p.sig_slot >= 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(p.flags + p.sig_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(p.flags + p.sig_slot * PDL_SLOT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -115,7 +115,7 @@ struct vox_hip_engine {
     bool use_pdl = false, pdl_first = true;
     hipStream_t pdl_stream[2] = {nullptr, nullptr};
     hipEvent_t pdl_ev[3] = {nullptr, nullptr, nullptr};
-    unsigned *d_pdl = nullptr;          // [0..1] completion counters, [2] error word
+    unsigned *d_pdl = nullptr;          // completion counters at [0], [STRIDE]; error word at [2*STRIDE]
     unsigned pdl_g = 0, pdl_cum[2] = {0, 0};
     int pdl_runs = 0, pdl_failures = 0;
     int *d_tokens = nullptr;
@@ -436,19 +436,23 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
         }
     }
 
-    // overlapped decode chain: two streams, each restricted to one half of the CUs
+    // overlapped decode chain: two streams, each restricted to one half of the CUs.
+    // Measured on MI355X (profiles/r01_pdl_*): correct, kernels do overlap, but a software hand-off
+    // (poll + acquire + activation fetch + write-through publish + counter add) costs 9-10 us per
+    // kernel with 2 blocks/CU and ~19 us with 4 blocks/CU, against ~4.5 us of boundary + ramp for
+    // plain in-order launches: 3.3-3.6 ms/token vs 1.62.  Opt-in experiment (VOX_HIP_PDL=1).
     {
         hipDeviceProp_t prop;
         const bool geom = d.dec_dim == 3072 && e->dec_qd == 4096 && e->dec_kvd == 1024 && d.dec_hidden == 9216 &&
                           d.dec_head_dim == 128 && d.vocab % 32768 == 0;
-        if (geom && !getenv("VOX_HIP_NO_PDL") && hipGetDeviceProperties(&prop, device) == hipSuccess &&
+        if (geom && getenv("VOX_HIP_PDL") && !getenv("VOX_HIP_NO_PDL") && hipGetDeviceProperties(&prop, device) == hipSuccess &&
             prop.multiProcessorCount == 256) {
             uint32_t lo[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0, 0};
             uint32_t hi[8] = {0, 0, 0, 0, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
             bool ok = hipExtStreamCreateWithCUMask(&e->pdl_stream[0], 8, lo) == hipSuccess &&
                       hipExtStreamCreateWithCUMask(&e->pdl_stream[1], 8, hi) == hipSuccess;
             for (int i = 0; i < 3 && ok; i++) ok = hipEventCreateWithFlags(&e->pdl_ev[i], hipEventDisableTiming) == hipSuccess;
-            ok = ok && dalloc(e, &e->d_pdl, 4) == 0 && hipMemset(e->d_pdl, 0, 16) == hipSuccess;
+            ok = ok && dalloc(e, &e->d_pdl, 3 * PDL_SLOT_STRIDE) == 0 && hipMemset(e->d_pdl, 0, 3 * PDL_SLOT_STRIDE * 4) == hipSuccess;
             if (ok) e->use_pdl = true;
             else { (void)hipGetLastError(); fprintf(stderr, "vox_hip: CU-masked streams unavailable; plain decode launches\n"); }
         }
@@ -1244,7 +1248,7 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
 // ------------------------------------------------------------------------------------
 static hipStream_t pdl_next(vox_hip_engine *e, int blocks, PdlArgs &p) {
     const unsigned g = e->pdl_g++;
-    p.flags = e->d_pdl; p.err = e->d_pdl + 2; p.spin_limit = 2000000ull;       // 20 ms @ 100 MHz
+    p.flags = e->d_pdl; p.err = e->d_pdl + 2 * PDL_SLOT_STRIDE; p.spin_limit = 2000000ull;       // 20 ms @ 100 MHz
     if (e->pdl_first) { p.wait_slot = -1; p.wait_val = 0; e->pdl_first = false; }
     else { p.wait_slot = (int)((g - 1) & 1u); p.wait_val = e->pdl_cum[(g - 1) & 1u]; }
     p.sig_slot = (int)(g & 1u);
@@ -1462,13 +1466,13 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
             }
         }
         if (!launched && e->use_pdl) {
-            HC(hipMemsetAsync(e->d_pdl + 2, 0, sizeof(unsigned), s));
+            HC(hipMemsetAsync(e->d_pdl + 2 * PDL_SLOT_STRIDE, 0, sizeof(unsigned), s));
             if (pdl_begin(e)) return -1;
             for (int i = 0; i < batch; i++)
                 enqueue_step_pdl(e, e->dec_pos + i, logits_out ? lg + (size_t)i * V : lg, eos_token, 1);
             if (pdl_end(e)) return -1;
             unsigned errw = 0;
-            HC(hipMemcpyAsync(&errw, e->d_pdl + 2, sizeof errw, hipMemcpyDeviceToHost, s));
+            HC(hipMemcpyAsync(&errw, e->d_pdl + 2 * PDL_SLOT_STRIDE, sizeof errw, hipMemcpyDeviceToHost, s));
             HC(hipStreamSynchronize(s));
             e->pdl_runs++;
             if (errw == 0) launched = true;

@@ -112,6 +112,9 @@ hip.vox_hip_reset_encoder.argtypes = [C.c_void_p]
 hip.vox_hip_reset_decoder.argtypes = [C.c_void_p]
 hip.vox_hip_time_decoder_step.restype = C.c_double
 hip.vox_hip_time_decoder_step.argtypes = [C.c_void_p, C.c_int, C.c_int]
+hip.vox_hip_decode_path.restype = C.c_int
+hip.vox_hip_decode_path.argtypes = [C.c_void_p]
+hip.vox_hip_sync.argtypes = [C.c_void_p]
 hip.vox_hip_get_timing.argtypes = [C.c_void_p, C.POINTER(_Timing)]
 hip.vox_hip_reset_timing.argtypes = [C.c_void_p]
 hip.vox_hip_adapter_read.argtypes = [C.c_void_p, C.c_int64, C.c_int, f32p]

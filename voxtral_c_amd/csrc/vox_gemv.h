@@ -48,9 +48,8 @@ struct GemvArgs {
     float *x_out;              // PRO_EMBED_RMS: residual stream (written by block 0)
     const float *part_o, *part_ml;   // PRO_ATTN: split-K attention partials [heads][nsplit][HD], [..][2]
     int nsplit, attn_hd;
-    // overlapped launches (vox_common.h, PdlArgs): pos_host replaces st->pos (the host knows it)
-    PdlArgs pdl;
-    int pos_host;
+    PdlArgs pdl;               // overlapped launches (vox_common.h)
+    int pos_host;              // k_gemv3 EPI_QKV: logical position of this step (RoPE angle, KV slot)
     int row_base;              // EPI_LOGITS: added to the row index reported in blk_idx (vocabulary halves)
 };
 
@@ -496,7 +495,7 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
             for (int r = 0; r < RPW; r++) yv[r] = a.y[min(row0 + r, N - 1)];
         }
         if constexpr (EPI == EPI_QKV) {
-            pos = PDL ? a.pos_host : a.st->pos;
+            pos = a.pos_host;              // the host knows the position of every step it enqueues
 #pragma unroll
             for (int r = 0; r < RPW; r += 2) fr[r / 2] = a.inv_freq[((row0 + r) % a.head_dim) >> 1];
         }

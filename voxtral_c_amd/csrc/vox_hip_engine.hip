@@ -1175,19 +1175,22 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             a.N = DQ + 2 * DKV; a.K = DD; a.q_rows = DQ; a.k_rows = DKV; a.head_dim = HD; a.rope = e->dec_rope;
             a.kcache = L.kring; a.vcache = L.vring; a.kv_cap = e->dec_ring_cap; a.kv_dim = DKV; a.st = e->d_st;
             a.inv_freq = e->dec_inv_freq; a.adapter = e->adapter; a.tok_emb = e->tok_emb; a.x_out = e->dx;
+            a.pos_host = kv_pos;
             if (!fast) launch_gemv<PRO_RMS, EPI_QKV, 4>(e, a);
-            else if (e->use_gemv3 && l == 0 && build_embed) launch_gemv3<PRO_EMBED_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
-            else if (e->use_gemv3) launch_gemv3<PRO_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
+            else if (e->use_gemv3 && l == 0 && build_embed) launch_gemv3<PRO_EMBED_RMS, EPI_QKV, 2, 6, 1, 3>(e, a);
+            else if (e->use_gemv3) launch_gemv3<PRO_RMS, EPI_QKV, 2, 6, 1, 3>(e, a);
             else if (l == 0 && build_embed) launch_gemv2<PRO_EMBED_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
             else launch_gemv2<PRO_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
             prof_mark(e, PK_QKV);
         }
         {   // attention over the KV window (voxtral_decoder.c:667-673)
             AttnArgs a{};
-            a.out = e->dattn; a.ldo = DQ; a.q = e->dq; a.ldq = DQ; a.n_q = 1; a.qpos0 = 0;
-            a.posB0 = INT_MAX; a.last_key = 0; a.kA = L.kring; a.vA = L.vring; a.capA = e->dec_ring_cap; a.ldA = DKV;
+            a.out = e->dattn; a.ldo = DQ; a.q = e->dq; a.ldq = DQ; a.n_q = 1; a.qpos0 = kv_pos;
+            a.posB0 = INT_MAX; a.last_key = kv_pos; a.kA = L.kring; a.vA = L.vring; a.capA = e->dec_ring_cap; a.ldA = DKV;
             a.n_heads = d.dec_heads; a.n_kv_heads = d.dec_kv_heads; a.scale = scale; a.window = d.dec_window;
-            a.st = e->d_st; a.split_keys = split_keys; a.part_o = e->dpart_o; a.part_ml = e->dpart_ml;
+            // fast path: the position comes from the host (no dependent scalar load in front of the
+            // K/V reads); the generic kernels of the other geometries keep reading DecState
+            a.st = fast ? nullptr : e->d_st; a.split_keys = split_keys; a.part_o = e->dpart_o; a.part_ml = e->dpart_ml;
             a.force_partials = fuse_combine ? 1 : 0;
             if (e->use_dpp)
                 hipLaunchKernelGGL((k_attn_dec<128, 4, true>), dim3(d.dec_kv_heads, nsplit, 1), dim3(256), 0, s, a, nsplit);

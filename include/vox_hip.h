@@ -191,6 +191,12 @@ double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int kv_len);
  *  6 w2 gemv, 7 logits gemv, 8 argmax}; HIP events on the engine stream. Returns s/step. */
 double vox_hip_profile_decode(vox_hip_engine_t *e, int iters, int kv_len, double *avg_us, int *launches);
 
+/* BASELINE config 5: quantise the decoder matrices and the tied embedding to fp8 e4m3 (one f32 scale
+ * per output row) for the decode GEMVs; prefill and the encoder keep bf16.  Call after the uploads.
+ * vox_hip_weight_format: 0 = bf16, 1 = fp8 decode weights. */
+int vox_hip_quantize_decoder_fp8(vox_hip_engine_t *e);
+int vox_hip_weight_format(vox_hip_engine_t *e);
+
 /* Decode path used by vox_hip_decoder_run: 0 plain launches, 1 overlapped chain on two CU-masked
  * streams (VOX_HIP_PDL=1, experiment: slower than plain launches), 2 persistent kernel
  * (VOX_HIP_PERSIST=1, experiment). */

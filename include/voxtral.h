@@ -85,11 +85,13 @@ typedef struct vox_ctx {
 } vox_ctx_t;
 
 /* Optional load parameters (vox_load uses the defaults; the environment variables
- * VOX_DEVICE, VOX_ENC_WINDOW, VOX_DEC_WINDOW override them). */
+ * VOX_DEVICE, VOX_ENC_WINDOW, VOX_DEC_WINDOW, VOX_WEIGHTS override them). */
 typedef struct vox_load_opts {
     int device;        /* HIP device ordinal, default 0 */
     int enc_window;    /* encoder sliding window, default 750 */
     int dec_window;    /* decoder sliding window, default 8192 */
+    int weight_format; /* 0 = bf16 as stored (default); 1 = fp8 e4m3 copies of the decoder matrices for
+                          the decode GEMVs (BASELINE config 5; env VOX_WEIGHTS=fp8) */
 } vox_load_opts_t;
 
 /* ---- model lifetime (reference voxtral.h:217-223) ------------------------------- */

@@ -313,6 +313,33 @@ def test_stream_full_size_matches_reference_golden(vox):
         assert res["steps"] == res["ref_steps"], res
 
 
+def test_fp8_decode_weights_track_bf16(vox):
+    """BASELINE config 5: fp8 e4m3 copies (one scale per output row) of the decoder matrices for the
+    decode GEMVs.  Not a parity mode (the weights differ by up to 2^-4 relative); the check is that
+    the logits stay close to the bf16 run and that greedy decoding agrees on most steps of the
+    seeded synthetic checkpoint (random weights have far smaller top-2 margins than a trained
+    model, so exact agreement is not expected here; the agreement rate is reported in
+    gpurun_out/diag/fp8_vs_bf16.json)."""
+    audio = synth_speech(10.0, 91)
+    with vox.Model(model_dir("full")) as m:
+        a = m.transcribe(audio, record_logits=64)
+    with vox.Model(model_dir("full"), weights="fp8") as m8:
+        assert vox.hip.vox_hip_weight_format(m8.engine) == 1
+        b = m8.transcribe(audio, record_logits=64)
+        t = m8.time_decoder_step(20, 232)
+    la, lb = np.asarray(a["logits"]), np.asarray(b["logits"])
+    ta, tb = np.asarray(a["tokens"]), np.asarray(b["tokens"])
+    n = min(len(ta), len(tb))
+    first_div = next((i for i in range(n) if ta[i] != tb[i]), n)
+    # logits of the first step see identical inputs (the prefill uses the bf16 weights)
+    cos0 = float(np.dot(la[0], lb[0]) / (np.linalg.norm(la[0]) * np.linalg.norm(lb[0])))
+    rel0 = float(np.abs(la[0] - lb[0]).max() / (np.abs(la[0]).max() + 1e-30))
+    diag("fp8_vs_bf16", steps=int(n), first_divergence=int(first_div), agree=float((ta[:n] == tb[:n]).mean()),
+         cos_step0=cos0, rel_err_step0=rel0, ms_per_token_fp8=t * 1e3)
+    assert cos0 > 0.995 and rel0 < 0.1, (cos0, rel0)
+    assert t < 1.45e-3, t          # bf16 decode is 1.6 ms/token; half the weight bytes must show
+
+
 def test_overlapped_decode_chain_matches_plain_launches(vox):
     """Opt-in experiment (VOX_HIP_PDL=1): decode kernels alternate between two CU-masked streams
     and wait in-kernel for their predecessor.  Same kernels, same arithmetic: tokens must equal

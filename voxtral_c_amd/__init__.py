@@ -41,7 +41,7 @@ class _Ctx(C.Structure):
 
 
 class _LoadOpts(C.Structure):
-    _fields_ = [("device", C.c_int), ("enc_window", C.c_int), ("dec_window", C.c_int)]
+    _fields_ = [("device", C.c_int), ("enc_window", C.c_int), ("dec_window", C.c_int), ("weight_format", C.c_int)]
 
 
 class _Timing(C.Structure):
@@ -112,6 +112,8 @@ hip.vox_hip_reset_encoder.argtypes = [C.c_void_p]
 hip.vox_hip_reset_decoder.argtypes = [C.c_void_p]
 hip.vox_hip_time_decoder_step.restype = C.c_double
 hip.vox_hip_time_decoder_step.argtypes = [C.c_void_p, C.c_int, C.c_int]
+hip.vox_hip_weight_format.restype = C.c_int
+hip.vox_hip_weight_format.argtypes = [C.c_void_p]
 hip.vox_hip_decode_path.restype = C.c_int
 hip.vox_hip_decode_path.argtypes = [C.c_void_p]
 hip.vox_hip_sync.argtypes = [C.c_void_p]
@@ -159,8 +161,8 @@ def load_wav(path):
 class Model:
     """vox_load / vox_free (+ the stage-level functions of voxtral.h:309-328)."""
 
-    def __init__(self, model_dir, device=0, enc_window=0, dec_window=0):
-        opts = _LoadOpts(device, enc_window, dec_window)
+    def __init__(self, model_dir, device=0, enc_window=0, dec_window=0, weights="bf16"):
+        opts = _LoadOpts(device, enc_window, dec_window, 1 if weights == "fp8" else 0)
         self._ctx = lib.vox_load_ex(os.fsencode(model_dir), C.byref(opts))
         if not self._ctx:
             raise VoxError(f"vox_load failed for {model_dir}: {hip.vox_hip_last_error().decode()}")

@@ -175,4 +175,21 @@ __device__ __forceinline__ float dot8_bf16(const uint4 w, const float4 x0, const
     return acc;
 }
 
+// 16 fp8 (e4m3) weights x 16 f32 activations.  v_cvt_pk_f32_fp8 unpacks two bytes per instruction;
+// the quantiser (k_quant_fp8_rows) uses the inverse instruction, so the pair is self-consistent.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot16_fp8(const uint4 w, const float4 x0, const float4 x1, const float4 x2, const float4 x3,
+                                           float acc) {
+    f32x2 p;
+    p = __builtin_amdgcn_cvt_pk_f32_fp8((int)w.x, false); acc = fmaf(p.x, x0.x, acc); acc = fmaf(p.y, x0.y, acc);
+    p = __builtin_amdgcn_cvt_pk_f32_fp8((int)w.x, true);  acc = fmaf(p.x, x0.z, acc); acc = fmaf(p.y, x0.w, acc);
+    p = __builtin_amdgcn_cvt_pk_f32_fp8((int)w.y, false); acc = fmaf(p.x, x1.x, acc); acc = fmaf(p.y, x1.y, acc);
+    p = __builtin_amdgcn_cvt_pk_f32_fp8((int)w.y, true);  acc = fmaf(p.x, x1.z, acc); acc = fmaf(p.y, x1.w, acc);
+    p = __builtin_amdgcn_cvt_pk_f32_fp8((int)w.z, false); acc = fmaf(p.x, x2.x, acc); acc = fmaf(p.y, x2.y, acc);
+    p = __builtin_amdgcn_cvt_pk_f32_fp8((int)w.z, true);  acc = fmaf(p.x, x2.z, acc); acc = fmaf(p.y, x2.w, acc);
+    p = __builtin_amdgcn_cvt_pk_f32_fp8((int)w.w, false); acc = fmaf(p.x, x3.x, acc); acc = fmaf(p.y, x3.y, acc);
+    p = __builtin_amdgcn_cvt_pk_f32_fp8((int)w.w, true);  acc = fmaf(p.x, x3.z, acc); acc = fmaf(p.y, x3.w, acc);
+    return acc;
+}
+
 }  // namespace vox

@@ -50,10 +50,11 @@ struct GemvArgs {
     int nsplit, attn_hd;
     PdlArgs pdl;               // overlapped launches (vox_common.h)
     int pos_host;              // k_gemv3 EPI_QKV: logical position of this step (RoPE angle, KV slot)
+    const float *wscale, *wscale2;   // fp8 weights (W8): per-row dequantisation scale of W / W2
     int row_base;              // EPI_LOGITS: added to the row index reported in blk_idx (vocabulary halves)
 };
 
-template <int PRO, int EPI, int RPW, bool PDL = false>
+template <int PRO, int EPI, int RPW, bool PDL = false, bool W8 = false>
 __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *xs = smem;                 // [K]
@@ -88,7 +89,8 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     }
     __syncthreads();
 
-    const int nchunks = K >> 3;
+    constexpr int EPP = W8 ? 16 : 8;  // weights per 16-byte piece
+    const int nchunks = K / EPP;
     constexpr int NMAT = (EPI == EPI_SWIGLU) ? 2 : 1;
     constexpr int RPB = 4 * RPW;      // rows per block iteration
     float best_v = -3.0e38f;
@@ -100,8 +102,9 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 #pragma unroll
         for (int r = 0; r < RPW; r++) {
             const int row = min(r0 + r, N - 1);   // clamp: duplicates are discarded below
-            wp[0][r] = reinterpret_cast<const uint4 *>(a.W + (size_t)row * K);
-            if constexpr (NMAT == 2) wp[1][r] = reinterpret_cast<const uint4 *>(a.W2 + (size_t)row * K);
+            const size_t rowb = (size_t)K * (W8 ? 1 : 2);
+            wp[0][r] = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.W) + (size_t)row * rowb);
+            if constexpr (NMAT == 2) wp[1][r] = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.W2) + (size_t)row * rowb);
 #pragma unroll
             for (int m = 0; m < NMAT; m++) acc[m][r] = 0.f;
         }
@@ -112,17 +115,34 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
             for (int m = 0; m < NMAT; m++)
 #pragma unroll
                 for (int r = 0; r < RPW; r++) w[m][r] = ld_stream(wp[m][r] + c);
-            const float4 x0 = *reinterpret_cast<const float4 *>(xs + c * 8);
-            const float4 x1 = *reinterpret_cast<const float4 *>(xs + c * 8 + 4);
+            const float4 x0 = *reinterpret_cast<const float4 *>(xs + c * EPP);
+            const float4 x1 = *reinterpret_cast<const float4 *>(xs + c * EPP + 4);
+            if constexpr (W8) {
+                const float4 x2 = *reinterpret_cast<const float4 *>(xs + c * EPP + 8);
+                const float4 x3 = *reinterpret_cast<const float4 *>(xs + c * EPP + 12);
 #pragma unroll
-            for (int m = 0; m < NMAT; m++)
+                for (int m = 0; m < NMAT; m++)
 #pragma unroll
-                for (int r = 0; r < RPW; r++) acc[m][r] = dot8_bf16(w[m][r], x0, x1, acc[m][r]);
+                    for (int r = 0; r < RPW; r++) acc[m][r] = dot16_fp8(w[m][r], x0, x1, x2, x3, acc[m][r]);
+            } else {
+#pragma unroll
+                for (int m = 0; m < NMAT; m++)
+#pragma unroll
+                    for (int r = 0; r < RPW; r++) acc[m][r] = dot8_bf16(w[m][r], x0, x1, acc[m][r]);
+            }
         }
 #pragma unroll
         for (int m = 0; m < NMAT; m++)
 #pragma unroll
             for (int r = 0; r < RPW; r++) acc[m][r] = wave_sum(acc[m][r]);
+        if constexpr (W8) {
+#pragma unroll
+            for (int r = 0; r < RPW; r++) {
+                const int row = min(r0 + r, N - 1);
+                acc[0][r] *= a.wscale[row];
+                if constexpr (NMAT == 2) acc[1][r] *= a.wscale2[row];
+            }
+        }
 
         // ---- epilogue (lane 0 of the wave owns the RPW results) -------------------
         if (lane == 0) {
@@ -387,6 +407,33 @@ __global__ __launch_bounds__(256, MINW) void k_gemv2(const GemvArgs a) {
     }
 }
 
+// bf16 [N, K] -> fp8 e4m3 [N, K] with one f32 scale per row (BASELINE config 5: fp8 decode weights).
+// scale = max|w| / 224 keeps every quantised value inside the finite range of both e4m3 flavours;
+// block per row.
+__global__ __launch_bounds__(256) void k_quant_fp8_rows(const uint16_t *W, uint8_t *Q, float *scale, int K) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const uint16_t *w = W + (size_t)row * K;
+    float amax = 0.f;
+    for (int k = tid; k < K; k += 256) amax = fmaxf(amax, fabsf(bf16_to_f32(w[k])));
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = amax > 0.f ? amax / 224.0f : 1.0f;
+    const float inv = 1.0f / sc;
+    if (tid == 0) scale[row] = sc;
+    uint32_t *q = reinterpret_cast<uint32_t *>(Q + (size_t)row * K);
+    for (int k4 = tid; k4 < K / 4; k4 += 256) {
+        const float v0 = bf16_to_f32(w[4 * k4]) * inv, v1 = bf16_to_f32(w[4 * k4 + 1]) * inv;
+        const float v2 = bf16_to_f32(w[4 * k4 + 2]) * inv, v3 = bf16_to_f32(w[4 * k4 + 3]) * inv;
+        int word = 0;
+        word = __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, word, false);
+        word = __builtin_amdgcn_cvt_pk_fp8_f32(v2, v3, word, true);
+        q[k4] = (uint32_t)word;
+    }
+}
+
 // Final argmax over the per-block partials + decoder cursor advance.
 // One block of 256 threads.
 __global__ __launch_bounds__(256) void k_argmax_finish(const float *blk_val, const int *blk_idx, int nblk,
@@ -467,10 +514,11 @@ __global__ __launch_bounds__(256) void k_step_begin(const DecState *st, const fl
 //   5. prologue math in LDS, then the dot products piece by piece as the weights land.
 // K is a template constant (CPL * KS * 512).
 // ---------------------------------------------------------------------------------------
-template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW, bool PDL>
+template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW, bool PDL, bool W8 = false>
 __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int K = CPL * KS * 512;
+    constexpr int EPP = W8 ? 16 : 8;  // weights per 16-byte piece (fp8 e4m3 : bf16)
+    constexpr int K = CPL * KS * 64 * EPP;
     constexpr int NX = K / 1024;      // 16-byte pieces of a K-float vector per thread
     constexpr int NMAT = (EPI == EPI_SWIGLU) ? 2 : 1;
     constexpr int RG = 4 / KS;        // row groups (waves along rows) per block
@@ -555,8 +603,10 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
 #pragma unroll
         for (int r = 0; r < RPW; r++) {
             const int row = min(row0 + r, N - 1);
-            p0[r] = reinterpret_cast<const uint4 *>(a.W + (size_t)row * K) + kp * (CPL * 64) + lane;
-            if constexpr (NMAT == 2) p1[r] = reinterpret_cast<const uint4 *>(a.W2 + (size_t)row * K) + kp * (CPL * 64) + lane;
+            constexpr size_t ROWB = (size_t)K * (W8 ? 1 : 2);           // bytes per weight row
+            p0[r] = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.W) + (size_t)row * ROWB) + kp * (CPL * 64) + lane;
+            if constexpr (NMAT == 2)
+                p1[r] = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.W2) + (size_t)row * ROWB) + kp * (CPL * 64) + lane;
         }
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
@@ -682,18 +732,35 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
         for (int r = 0; r < RPW; r++) acc[m][r] = 0.f;
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
-        const float *xp = xs + ((kp * CPL + c) * 64 + lane) * 8;
+        const float *xp = xs + ((kp * CPL + c) * 64 + lane) * EPP;
         const float4 x0 = *reinterpret_cast<const float4 *>(xp);
         const float4 x1 = *reinterpret_cast<const float4 *>(xp + 4);
+        if constexpr (W8) {
+            const float4 x2 = *reinterpret_cast<const float4 *>(xp + 8);
+            const float4 x3 = *reinterpret_cast<const float4 *>(xp + 12);
 #pragma unroll
-        for (int m = 0; m < NMAT; m++)
+            for (int m = 0; m < NMAT; m++)
 #pragma unroll
-            for (int r = 0; r < RPW; r++) acc[m][r] = dot8_bf16(w[m][r][c], x0, x1, acc[m][r]);
+                for (int r = 0; r < RPW; r++) acc[m][r] = dot16_fp8(w[m][r][c], x0, x1, x2, x3, acc[m][r]);
+        } else {
+#pragma unroll
+            for (int m = 0; m < NMAT; m++)
+#pragma unroll
+                for (int r = 0; r < RPW; r++) acc[m][r] = dot8_bf16(w[m][r][c], x0, x1, acc[m][r]);
+        }
     }
 #pragma unroll
     for (int m = 0; m < NMAT; m++)
 #pragma unroll
         for (int r = 0; r < RPW; r++) acc[m][r] = wave_sum(acc[m][r]);
+    if constexpr (W8) {                                // per-row dequantisation scale
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const int row = min(row0 + r, N - 1);
+            acc[0][r] *= a.wscale[row];
+            if constexpr (NMAT == 2) acc[1][r] *= a.wscale2[row];
+        }
+    }
     if constexpr (KS == 2) {
         float *part = red + 16;                        // [RG][NMAT*RPW]
         if (kp == 1 && lane == 0) {

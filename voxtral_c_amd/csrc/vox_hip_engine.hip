@@ -61,6 +61,9 @@ struct EncLayer {
 };
 struct DecLayer {
     uint16_t *wqkv = nullptr, *wo = nullptr, *w13 = nullptr, *w2 = nullptr;
+    // optional fp8 (e4m3) copies of the four matrices with one f32 scale per output row
+    uint8_t *wqkv8 = nullptr, *wo8 = nullptr, *w138 = nullptr, *w28 = nullptr;
+    float *sqkv = nullptr, *so = nullptr, *s13 = nullptr, *s2 = nullptr;
     float *n1 = nullptr, *n2 = nullptr, *ada = nullptr;
     float *kring = nullptr, *vring = nullptr;
 };
@@ -111,6 +114,8 @@ struct vox_hip_engine {
     float *dx = nullptr, *dq = nullptr, *dattn = nullptr, *dh = nullptr, *dlogits = nullptr;
     float *blk_val = nullptr; int *blk_idx = nullptr; int logits_grid = 0;
     unsigned long long *d_trace = nullptr;
+    bool use_fp8 = false;               // decode GEMVs stream the fp8 copies (vox_hip_quantize_decoder_fp8)
+    uint8_t *tok_emb8 = nullptr; float *stok = nullptr;
     // overlapped decode chain
     bool use_pdl = false, pdl_first = true;
     hipStream_t pdl_stream[2] = {nullptr, nullptr};
@@ -475,7 +480,11 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     F(e->tok_emb); F(e->conv0_w); F(e->conv1_w); F(e->adapter0); F(e->adapter1);
     F(e->conv0_b); F(e->conv1_b); F(e->enc_final_norm); F(e->dec_final_norm);
     for (auto &L : e->enc) { F(L.wqkv); F(L.wo); F(L.w13); F(L.w2); F(L.bqkv); F(L.bo); F(L.b2); F(L.n1); F(L.n2); F(L.kring); F(L.vring); }
-    for (auto &L : e->dec) { F(L.wqkv); F(L.wo); F(L.w13); F(L.w2); F(L.n1); F(L.n2); F(L.ada); F(L.kring); F(L.vring); }
+    for (auto &L : e->dec) {
+        F(L.wqkv); F(L.wo); F(L.w13); F(L.w2); F(L.n1); F(L.n2); F(L.ada); F(L.kring); F(L.vring);
+        F(L.wqkv8); F(L.wo8); F(L.w138); F(L.w28); F(L.sqkv); F(L.so); F(L.s13); F(L.s2);
+    }
+    F(e->tok_emb8); F(e->stok);
     F(e->hann); F(e->cosT); F(e->sinT); F(e->filtT); F(e->enc_inv_freq); F(e->dec_inv_freq); F(e->dec_rope);
     F(e->d_st); F(e->dx); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
     F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_players); F(e->d_bar); F(e->d_pdl);
@@ -1139,15 +1148,15 @@ static void launch_gemv2(vox_hip_engine *e, const GemvArgs &a) {
     hipLaunchKernelGGL((k_gemv2<PRO, EPI, RPW, CPL, KS, MINW>), dim3(grid), dim3(256), lds, e->stream, a);
 }
 
-template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW>
+template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW, bool W8 = false>
 static void launch_gemv3(vox_hip_engine *e, const GemvArgs &a) {
-    constexpr int K = CPL * KS * 512;
+    constexpr int K = CPL * KS * 64 * (W8 ? 16 : 8);
     const int rows_per_block = (4 / KS) * RPW;
     const int grid = (a.N + rows_per_block - 1) / rows_per_block;
     size_t fl = K + 64;
     if (PRO == PRO_RMS || PRO == PRO_EMBED_RMS) fl += 2 * (size_t)K;
     if (PRO == PRO_ATTN) fl += 256;
-    hipLaunchKernelGGL((k_gemv3<PRO, EPI, RPW, CPL, KS, MINW, false>), dim3(grid), dim3(256), fl * sizeof(float), e->stream, a);
+    hipLaunchKernelGGL((k_gemv3<PRO, EPI, RPW, CPL, KS, MINW, false, W8>), dim3(grid), dim3(256), fl * sizeof(float), e->stream, a);
 }
 
 // Enqueue one decode step. kv_pos = logical position of this token (host mirror of st->pos).
@@ -1176,7 +1185,11 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             a.kcache = L.kring; a.vcache = L.vring; a.kv_cap = e->dec_ring_cap; a.kv_dim = DKV; a.st = e->d_st;
             a.inv_freq = e->dec_inv_freq; a.adapter = e->adapter; a.tok_emb = e->tok_emb; a.x_out = e->dx;
             a.pos_host = kv_pos;
+            const bool f8 = fast && e->use_fp8;
+            if (f8) { a.W = reinterpret_cast<const uint16_t *>(L.wqkv8); a.wscale = L.sqkv; }
             if (!fast) launch_gemv<PRO_RMS, EPI_QKV, 4>(e, a);
+            else if (f8 && l == 0 && build_embed) launch_gemv3<PRO_EMBED_RMS, EPI_QKV, 2, 3, 1, 3, true>(e, a);
+            else if (f8) launch_gemv3<PRO_RMS, EPI_QKV, 2, 3, 1, 3, true>(e, a);
             else if (e->use_gemv3 && l == 0 && build_embed) launch_gemv3<PRO_EMBED_RMS, EPI_QKV, 2, 6, 1, 3>(e, a);
             else if (e->use_gemv3) launch_gemv3<PRO_RMS, EPI_QKV, 2, 6, 1, 3>(e, a);
             else if (l == 0 && build_embed) launch_gemv2<PRO_EMBED_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
@@ -1207,7 +1220,11 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             GemvArgs a{};
             a.W = L.wo; a.x = e->dattn; a.y = e->dx; a.N = DD; a.K = DQ;
             a.part_o = e->dpart_o; a.part_ml = e->dpart_ml; a.nsplit = nsplit; a.attn_hd = HD;
+            const bool f8 = fast && e->use_fp8;
+            if (f8) { a.W = reinterpret_cast<const uint16_t *>(L.wo8); a.wscale = L.so; }
             if (!fast) launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
+            else if (f8 && fuse_combine) launch_gemv3<PRO_ATTN, EPI_RESID, 3, 4, 1, 1, true>(e, a);
+            else if (f8) launch_gemv3<PRO_NONE, EPI_RESID, 3, 4, 1, 1, true>(e, a);
             else if (e->use_gemv3 && fuse_combine) launch_gemv3<PRO_ATTN, EPI_RESID, 3, 8, 1, 1>(e, a);
             else if (e->use_gemv3) launch_gemv3<PRO_NONE, EPI_RESID, 3, 8, 1, 1>(e, a);
             else if (fuse_combine) launch_gemv2<PRO_ATTN, EPI_RESID, 3, 8, 1, 1>(e, a);
@@ -1218,7 +1235,13 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             GemvArgs a{};
             a.W = L.w13; a.W2 = L.w13 + (size_t)DH * DD; a.x = e->dx; a.norm_w = L.n2; a.ada = L.ada; a.eps = d.dec_eps;
             a.y = e->dh; a.N = DH; a.K = DD;
+            const bool f8 = fast && e->use_fp8;
+            if (f8) {
+                a.W = reinterpret_cast<const uint16_t *>(L.w138); a.W2 = reinterpret_cast<const uint16_t *>(L.w138 + (size_t)DH * DD);
+                a.wscale = L.s13; a.wscale2 = L.s13 + DH;
+            }
             if (!fast) launch_gemv<PRO_RMS, EPI_SWIGLU, 2>(e, a);
+            else if (f8) launch_gemv3<PRO_RMS, EPI_SWIGLU, 3, 3, 1, 3, true>(e, a);
             else if (e->use_gemv3) launch_gemv3<PRO_RMS, EPI_SWIGLU, 3, 6, 1, 3>(e, a);
             else launch_gemv2<PRO_RMS, EPI_SWIGLU, 3, 6, 1, 3>(e, a);
             prof_mark(e, PK_SWIGLU);
@@ -1226,7 +1249,10 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
         {   // x += h.W2^T
             GemvArgs a{};
             a.W = L.w2; a.x = e->dh; a.y = e->dx; a.N = DD; a.K = DH;
+            const bool f8 = fast && e->use_fp8;
+            if (f8) { a.W = reinterpret_cast<const uint16_t *>(L.w28); a.wscale = L.s2; }
             if (!fast) launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
+            else if (f8) launch_gemv3<PRO_NONE, EPI_RESID, 1, 9, 1, 3, true>(e, a);
             else if (e->use_gemv3) launch_gemv3<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
             else launch_gemv2<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
             prof_mark(e, PK_W2);
@@ -1236,7 +1262,12 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
         GemvArgs a{};
         a.W = e->tok_emb; a.x = e->dx; a.norm_w = e->dec_final_norm; a.eps = d.dec_eps; a.y = logits_dst;
         a.N = d.vocab; a.K = DD; a.blk_val = e->blk_val; a.blk_idx = e->blk_idx;
-        launch_gemv<PRO_RMS, EPI_LOGITS, 4>(e, a, e->logits_grid);
+        if (fast && e->use_fp8) {
+            a.W = reinterpret_cast<const uint16_t *>(e->tok_emb8); a.wscale = e->stok;
+            hipLaunchKernelGGL((k_gemv<PRO_RMS, EPI_LOGITS, 4, false, true>), dim3(e->logits_grid), dim3(256),
+                               ((size_t)DD + 16) * sizeof(float), s, a);
+        } else
+            launch_gemv<PRO_RMS, EPI_LOGITS, 4>(e, a, e->logits_grid);
         prof_mark(e, PK_LOGITS);
         hipLaunchKernelGGL(k_argmax_finish, dim3(1), dim3(256), 0, s, (const float *)e->blk_val, (const int *)e->blk_idx,
                            e->logits_grid, e->d_st, e->d_tokens, eos, advance, PdlArgs{});
@@ -1686,6 +1717,34 @@ extern "C" double vox_hip_profile_decode(vox_hip_engine_t *e, int iters, int kv_
     e->dec_pos = saved_pos;
     return total * 1e-3 / iters;
 }
+
+// BASELINE config 5: fp8 (e4m3, one f32 scale per output row) copies of the decoder matrices and
+// of the tied embedding for the HBM-bound decode GEMVs (3.43 GB per token instead of 6.86 GB).
+// Prefill and the encoder keep the bf16 weights.  Call after the bf16 uploads.  0 / -1.
+extern "C" int vox_hip_quantize_decoder_fp8(vox_hip_engine_t *e) {
+    if (!e) return -1;
+    HC(hipSetDevice(e->device));
+    const vox_hip_dims_t &d = e->d;
+    const int DD = d.dec_dim, DQ = e->dec_qd, DKV = e->dec_kvd, DH = d.dec_hidden;
+    if (!(DD == 3072 && DQ == 4096 && DKV == 1024 && DH == 9216)) { g_err = "fp8 decode weights: 4B geometry only"; return -1; }
+    auto quant = [&](const uint16_t *W, int N, int K, uint8_t **Q, float **S) -> int {
+        if (dalloc(e, Q, (size_t)N * K) || dalloc(e, S, (size_t)N)) return -1;
+        hipLaunchKernelGGL(k_quant_fp8_rows, dim3(N), dim3(256), 0, e->stream, W, *Q, *S, K);
+        return 0;
+    };
+    for (int l = 0; l < d.dec_layers; l++) {
+        DecLayer &L = e->dec[l];
+        if (quant(L.wqkv, DQ + 2 * DKV, DD, &L.wqkv8, &L.sqkv) || quant(L.wo, DD, DQ, &L.wo8, &L.so) ||
+            quant(L.w13, 2 * DH, DD, &L.w138, &L.s13) || quant(L.w2, DD, DH, &L.w28, &L.s2)) return -1;
+    }
+    if (quant(e->tok_emb, d.vocab, DD, &e->tok_emb8, &e->stok)) return -1;
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipGetLastError());
+    e->use_fp8 = true;
+    e->use_persist = false; e->use_pdl = false;      // the experiments only know the bf16 layout
+    return 0;
+}
+extern "C" int vox_hip_weight_format(vox_hip_engine_t *e) { return e ? (e->use_fp8 ? 1 : 0) : -1; }
 
 // Which decode path vox_hip_decoder_run uses: 0 = plain launches, 1 = overlapped chain on two
 // CU-masked streams, 2 = persistent kernel (opt-in experiment).

@@ -236,6 +236,20 @@ vox_ctx_t *vox_load_ex(const char *model_dir, const vox_load_opts_t *opts) {
                 (double)vox_hip_memory_used((vox_hip_engine_t *)ctx->engine) / (1024.0 * 1024.0));
         fprintf(stderr, "Model loaded.\n");
     }
+    {
+        int fmt = opts ? opts->weight_format : 0;
+        const char *wf = getenv("VOX_WEIGHTS");
+        if (wf && !strcmp(wf, "fp8")) fmt = 1;
+        if (wf && !strcmp(wf, "bf16")) fmt = 0;
+        if (fmt == 1) {
+            if (vox_hip_quantize_decoder_fp8((vox_hip_engine_t *)ctx->engine) != 0) {
+                fprintf(stderr, "vox_load: fp8 decode weights unavailable: %s\n", vox_hip_last_error());
+                vox_free(ctx);
+                return NULL;
+            }
+            if (vox_verbose >= 1) fprintf(stderr, "Decoder GEMV weights: fp8 e4m3 (per-row scale)\n");
+        }
+    }
     return ctx;
 }
 

@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=30.0, help="audio seconds per GPU")
     ap.add_argument("--preset", default="full", help="full | small | tiny (full = Voxtral-4B shapes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: BASELINE config 5 (row-scaled e4m3 decoder weights for the decode GEMVs); not the headline")
     ap.add_argument("--mode", default="batch", choices=["batch", "stream"],
                     help="batch: the headline (one feed of the whole clip); stream: BASELINE config 3, 0.5 s feeds at -I 0.5, "
                          "continuous mode (rolling KV), reports per-chunk latency as well")
@@ -167,7 +169,7 @@ def main():
 
     t0 = time.time()
     win = {} if args.preset != "tiny" else dict(enc_window=48, dec_window=64)
-    model = v.Model(mdir, device=local_rank, **win)
+    model = v.Model(mdir, device=local_rank, weights=args.weights, **win)
     load_s = time.time() - t0
     audio = synth_speech(args.seconds, 1234)
 
@@ -245,8 +247,14 @@ def main():
         "kernels": kernels,
     }
 
+    if args.weights == "fp8":       # half the weight bytes per token; the per-kernel byte table above is the bf16 one
+        roofline["note"] = "fp8 decode weights: algorithmic bytes per GEMV launch are half the bf16 figures listed"
+        roofline["decode_step"]["algorithmic_bytes"] = wbytes // 2 + kvbytes
+        roofline["decode_step"]["GBps"] = round((wbytes // 2 + kvbytes) / s_per_step / 1e9, 1)
+        roofline["decode_step"]["frac_of_peak"] = round((wbytes // 2 + kvbytes) / s_per_step / 1e9 / HBM_PEAK_GBS, 4)
     out = {
-        "metric": "real-time-factor + decode tokens/sec, Voxtral-4B bf16, 30s audio",
+        "metric": "real-time-factor + decode tokens/sec, Voxtral-4B bf16, 30s audio" if args.weights == "bf16" else
+                  "real-time-factor + decode tokens/sec, Voxtral-4B fp8 decode weights, 30s audio",
         "value": round(rtf, 5), "unit": "wall s / audio s (RTF)", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16 weights, f32 activations/accumulate (fp32 FMA GEMV, f32 MFMA GEMM)", "data": "synthetic",
@@ -256,7 +264,7 @@ def main():
         "hbm_resident_GB": round(model.memory_used() / 1e9, 2),
         "config": {"workload": f"Voxtral-4B ({args.preset} synthetic checkpoint) on 1xMI355X, single {args.seconds:g} s 16 kHz mono clip, "
                                "one vox_stream_feed (batch encoder) + finish, greedy decode",
-                   "audio_seconds": args.seconds, "preset": args.preset},
+                   "audio_seconds": args.seconds, "preset": args.preset, "decode_weights": args.weights},
         "roofline": roofline,
     }
     if not args.no_cpu_baseline and args.preset == "full":

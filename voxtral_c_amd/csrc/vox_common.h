@@ -45,6 +45,17 @@ struct PdlArgs {
     unsigned wait_val;
     int sig_slot;           // < 0: nothing to signal
     unsigned long long spin_limit;   // wall_clock64 ticks (100 MHz)
+    unsigned long long *trace;       // optional: 16 timestamps per (kernel, probe block), VOX_HIP_PDL_TRACE
+};
+
+// Timestamp probe for the overlapped chain: thread 0 of the first and the last block of a kernel.
+struct PdlProbe {
+    unsigned long long *p; int n;
+    __device__ __forceinline__ PdlProbe(const PdlArgs &a) : p(nullptr), n(0) {
+        if (a.trace && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && blockIdx.y == 0)
+            p = a.trace + (blockIdx.x == 0 ? 0 : 16);
+    }
+    __device__ __forceinline__ void mark() { if (p && n < 16) p[n++] = wall_clock64(); }
 };
 
 // All threads of the block call this (contains a __syncthreads()).

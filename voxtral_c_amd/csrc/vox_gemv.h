@@ -619,6 +619,7 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
         }
     };
 
+    PdlProbe probe(a.pdl);
     if constexpr (!PDL) {
         // plain launch: everything this kernel reads is final.  Activation side first (it is
         // needed first and a CU's memory path is in-order), then the weight stream.
@@ -634,15 +635,19 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
     } else {
         // overlapped launch: the predecessor may still be running.  Its output is the activation
         // side, so the weight stream goes first and the wait sits between the two.
+        probe.mark();                                   // 0: kernel start
         load_epilogue_operands();
         __builtin_amdgcn_sched_barrier(0);
         issue_weight_loads();
         __builtin_amdgcn_sched_barrier(0);
+        probe.mark();                                   // 1: weights issued
         pdl_wait(a.pdl);
+        probe.mark();                                   // 2: predecessor done, acquired
         load_activation_registers();
         __builtin_amdgcn_sched_barrier(0);
         issue_lds_dma();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        probe.mark();                                   // 3: weights + activations landed
     }
 
     // ---- prologue math (plain launch: under the weight stream) ---------------------------------
@@ -724,6 +729,7 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
         }
     }
 
+    if constexpr (PDL) probe.mark();                    // 4: prologue done
     // ---- dot products, in arrival order ----------------------------------------------------------
     float acc[NMAT][RPW];
 #pragma unroll
@@ -778,6 +784,7 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
         }
     }
 
+    if constexpr (PDL) probe.mark();                    // 5: dots + reductions done
     // ---- epilogue (no loads left).  Overlapped launches publish with write-through stores ------
     auto put = [&](float *p, float v) {
         if constexpr (PDL) pdl_store(p, v); else *p = v;
@@ -818,7 +825,11 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
             }
         }
     }
-    if constexpr (PDL) pdl_signal(a.pdl);
+    if constexpr (PDL) {
+        probe.mark();                                   // 6: stores issued
+        pdl_signal(a.pdl);
+        probe.mark();                                   // 7: drained + signalled
+    }
 }
 
 }  // namespace vox

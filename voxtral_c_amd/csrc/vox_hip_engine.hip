@@ -123,6 +123,7 @@ struct vox_hip_engine {
     unsigned *d_pdl = nullptr;          // completion counters at [0], [STRIDE]; error word at [2*STRIDE]
     unsigned pdl_g = 0, pdl_cum[2] = {0, 0};
     int pdl_runs = 0, pdl_failures = 0;
+    unsigned long long *d_pdl_trace = nullptr; bool pdl_trace_on = false; int pdl_trace_k = 0;
     int *d_tokens = nullptr;
     float *dpart_o = nullptr, *dpart_ml = nullptr;   // decode-step split-K partials (max splits)
     int dec_max_split = 0;
@@ -1286,6 +1287,8 @@ static hipStream_t pdl_next(vox_hip_engine *e, int blocks, PdlArgs &p) {
     if (e->pdl_first) { p.wait_slot = -1; p.wait_val = 0; e->pdl_first = false; }
     else { p.wait_slot = (int)((g - 1) & 1u); p.wait_val = e->pdl_cum[(g - 1) & 1u]; }
     p.sig_slot = (int)(g & 1u);
+    p.trace = nullptr;
+    if (e->d_pdl_trace && e->pdl_trace_on && e->pdl_trace_k < 160) p.trace = e->d_pdl_trace + 32 * (e->pdl_trace_k++);
     e->pdl_cum[g & 1u] += (unsigned)blocks;
     return e->pdl_stream[g & 1u];
 }
@@ -1662,10 +1665,23 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
         for (int i = 0; i < 3; i++) enqueue_step_pdl(e, pos, e->dlogits, -1, 0);  // warm-up
         pdl_end(e);
         hipEventRecord(e->ev0, e->stream);
+        const char *tp = getenv("VOX_HIP_PDL_TRACE");
+        if (tp && !e->d_pdl_trace) { if (hipMalloc((void **)&e->d_pdl_trace, 160 * 32 * 8) != hipSuccess) e->d_pdl_trace = nullptr; }
+        if (e->d_pdl_trace) hipMemsetAsync(e->d_pdl_trace, 0, 160 * 32 * 8, e->stream);
         pdl_begin(e);
-        for (int i = 0; i < iters; i++) enqueue_step_pdl(e, pos, e->dlogits, -1, 0);
+        for (int i = 0; i < iters; i++) {
+            e->pdl_trace_on = (tp && i == iters - 1); e->pdl_trace_k = 0;
+            enqueue_step_pdl(e, pos, e->dlogits, -1, 0);
+        }
+        e->pdl_trace_on = false;
         pdl_end(e);
         hipEventRecord(e->ev1, e->stream);
+        if (tp && e->d_pdl_trace) {
+            hipStreamSynchronize(e->stream);
+            std::vector<unsigned long long> h(160 * 32);
+            hipMemcpy(h.data(), e->d_pdl_trace, h.size() * 8, hipMemcpyDeviceToHost);
+            if (FILE *f = fopen(tp, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        }
     } else {
         for (int i = 0; i < 3; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);   // warm-up
         hipEventRecord(e->ev0, e->stream);

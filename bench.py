@@ -156,21 +156,20 @@ def main():
     import voxtral_c_amd as v
     from audio_util import synth_speech
     from conftest import model_dir
-    from oracle.vox_oracle import PRESETS
 
     if v.device_count() < 1:
         raise SystemExit("bench.py: no HIP device (the engine has no CPU fallback)")
-    dims = PRESETS[args.preset]
     mdir = model_dir(args.preset)
 
     if world > 1 or os.environ.get("VOX_FORCE_DIST") == "1":
         from voxtral_c_amd.multi_gpu import run_distributed_bench
-        return run_distributed_bench(args, rank, world, local_rank, mdir, dims)
+        return run_distributed_bench(args, rank, world, local_rank, mdir, None)
 
     t0 = time.time()
     win = {} if args.preset != "tiny" else dict(enc_window=48, dec_window=64)
     model = v.Model(mdir, device=local_rank, weights=args.weights, **win)
     load_s = time.time() - t0
+    dims = model.dims            # geometry as read from the checkpoint by vox_load
     audio = synth_speech(args.seconds, 1234)
 
     if args.mode == "stream":

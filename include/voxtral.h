@@ -82,6 +82,7 @@ typedef struct vox_ctx {
     int kv_cache_len, kv_cache_max, kv_pos_offset;
     int enc_kv_cache_len, enc_kv_pos_offset;
     int use_bf16;               /* always 1: weights stay bf16 in HBM */
+    void *tokenizer;            /* vox_tokenizer_t shared by the streams of this model (parsed once) */
 } vox_ctx_t;
 
 /* Optional load parameters (vox_load uses the defaults; the environment variables

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 300 python tools/pdl_trace.py 2>&1 | tail -30
+timeout 300 python tools/pass_breakdown.py 2>&1 | tail -8

@@ -37,7 +37,8 @@ class _Ctx(C.Structure):
                 ("safetensors", C.c_void_p), ("engine", C.c_void_p), ("delay_tokens", C.c_int),
                 ("t_cond", f32p), ("ada_scale", f32p), ("ada_down", C.c_void_p), ("ada_up", C.c_void_p),
                 ("kv_cache_len", C.c_int), ("kv_cache_max", C.c_int), ("kv_pos_offset", C.c_int),
-                ("enc_kv_cache_len", C.c_int), ("enc_kv_pos_offset", C.c_int), ("use_bf16", C.c_int)]
+                ("enc_kv_cache_len", C.c_int), ("enc_kv_pos_offset", C.c_int), ("use_bf16", C.c_int),
+                ("tokenizer", C.c_void_p)]
 
 
 class _LoadOpts(C.Structure):

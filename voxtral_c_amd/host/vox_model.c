@@ -260,6 +260,7 @@ void vox_free(vox_ctx_t *ctx) {
     if (ctx->ada_up) for (int i = 0; i < ctx->dims.dec_layers; i++) free(ctx->ada_up[i]);
     free(ctx->ada_down); free(ctx->ada_up); free(ctx->t_cond); free(ctx->ada_scale);
     if (ctx->safetensors) vox_st_close((vox_st_file_t *)ctx->safetensors);
+    if (ctx->tokenizer) vox_tokenizer_free((vox_tokenizer_t *)ctx->tokenizer);
     free(ctx);
 }
 

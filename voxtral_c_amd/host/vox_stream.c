@@ -336,9 +336,14 @@ vox_stream_t *vox_stream_init(vox_ctx_t *ctx) {
     if (!s) return NULL;
     s->ctx = ctx;
     s->eng = (vox_hip_engine_t *)ctx->engine;
-    char path[1024];
-    snprintf(path, sizeof path, "%s/tekken.json", ctx->model_dir);
-    s->tok = vox_tokenizer_load(path);
+    /* The reference parses tekken.json in every vox_stream_init (voxtral.c:1197-1199); the table is
+     * immutable, so the model keeps it (10+ ms per stream for the 131072-entry vocabulary). */
+    if (!ctx->tokenizer) {
+        char path[1024];
+        snprintf(path, sizeof path, "%s/tekken.json", ctx->model_dir);
+        ctx->tokenizer = vox_tokenizer_load(path);
+    }
+    s->tok = (vox_tokenizer_t *)ctx->tokenizer;
     if (!s->tok) { free(s); return NULL; }
     vox_hip_reset_encoder(s->eng);
     vox_hip_reset_decoder(s->eng);
@@ -445,7 +450,6 @@ void vox_stream_free(vox_stream_t *s) {
         }
     }
     vox_mel_free(s->mel);
-    if (s->tok) vox_tokenizer_free(s->tok);
     free(s->q); free(s->logits); free(s->tok_scratch); free(s->ids); free(s->rec);
     free(s);
 }

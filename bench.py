@@ -229,7 +229,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r01_pmc_decode_summary.json")) as fh:
             pm = json.load(fh)["kernels"]
         for name, ent in pm.items():
-            if "k_gemv3<1, 3, 3, 6, 1, 3>" in name:
+            if "k_gemv3<1, 3, 3, 6, 1, 3" in name:
                 traffic = round(ent["hbm_read_bytes_per_launch_corrected"])
     except Exception:
         traffic = None

@@ -221,7 +221,22 @@ def main():
                 ent["GBps"] = round(kern_bytes[name] / (avg[i] * 1e-6) / 1e9, 1) if avg[i] > 0 else 0.0
             kernels[name] = ent
     dom = "gemv_swiglu"
-    dom_ach = kernels.get(dom, {}).get("GBps", 0.0)
+    # Launch duration of the dominant kernel inside the chain: HIP events around N whole decode
+    # steps with and without the 26 w1;w3 launches, on the engine stream; the difference / 26 is
+    # what one launch costs in situ (boundary included, no event packets between kernels).  The
+    # event-per-kernel table below ("kernels") carries ~3 us of event overhead per entry.
+    v.hip.vox_hip_time_decoder_step_without.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    t_full, t_skip = C.c_double(), C.c_double()
+    dom_us = None
+    if v.hip.vox_hip_time_decoder_step_without(model.engine, 50, kv_len, 5, C.byref(t_full), C.byref(t_skip)) == 0:
+        dom_us = (t_full.value - t_skip.value) / dims.dec_layers * 1e6
+    if dom_us and dom_us > 0:
+        dom_bytes = kern_bytes[dom] // (2 if args.weights == "fp8" else 1)
+        dom_ach = round(dom_bytes / (dom_us * 1e-6) / 1e9, 1)
+    else:
+        dom_us = kernels.get(dom, {}).get("avg_us")
+        dom_ach = kernels.get(dom, {}).get("GBps", 0.0)
     # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in
     # its own run, tools/run_pmc.sh; x1024 x2 correction of MI355X_MICROARCH.md, HBM section)
     traffic = None
@@ -236,7 +251,9 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": "k_gemv3<PRO_RMS,EPI_SWIGLU,3,6,1,3> (decoder W1;W3 GEMV, 43% of the weight bytes of a token)",
         "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_ach / HBM_PEAK_GBS, 4),
-        "bytes_per_launch": kern_bytes[dom], "avg_us_per_launch": kernels.get(dom, {}).get("avg_us"),
+        "bytes_per_launch": kern_bytes[dom] // (2 if args.weights == "fp8" else 1), "avg_us_per_launch": round(dom_us, 2),
+        "method": "HIP events on the engine stream around 50 decode steps with and without the 26 launches of this kernel; "
+                  "(full - skipped) / 26",
         "traffic": traffic, "traffic_source": "profiles/r01_pmc_decode_summary.json (FETCH_SIZE, read bytes per launch)",
         "decode_step": {"algorithmic_bytes": wbytes + kvbytes, "ms": round(s_per_step * 1e3, 4),
                         "GBps": round((wbytes + kvbytes) / s_per_step / 1e9, 1),

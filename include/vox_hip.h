@@ -191,6 +191,11 @@ double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int kv_len);
  *  6 w2 gemv, 7 logits gemv, 8 argmax}; HIP events on the engine stream. Returns s/step. */
 double vox_hip_profile_decode(vox_hip_engine_t *e, int iters, int kv_len, double *avg_us, int *launches);
 
+/* In-situ cost of one decode kernel kind (1 qkv, 2 attention, 4 wo, 5 w1;w3, 6 w2): seconds per step
+ * with and without its launches; (full - skipped) / layers = what one launch adds to the chain. */
+int vox_hip_time_decoder_step_without(vox_hip_engine_t *e, int iters, int kv_len, int kind,
+                                      double *full_s, double *skipped_s);
+
 /* BASELINE config 5: quantise the decoder matrices and the tied embedding to fp8 e4m3 (one f32 scale
  * per output row) for the decode GEMVs; prefill and the encoder keep bf16.  Call after the uploads.
  * vox_hip_weight_format: 0 = bf16, 1 = fp8 decode weights. */

@@ -114,6 +114,7 @@ struct vox_hip_engine {
     float *dx = nullptr, *dq = nullptr, *dattn = nullptr, *dh = nullptr, *dlogits = nullptr;
     float *blk_val = nullptr; int *blk_idx = nullptr; int logits_grid = 0;
     unsigned long long *d_trace = nullptr;
+    unsigned skip_kinds = 0;            // timing experiments only: PK_* launches left out of a step
     bool use_fp8 = false;               // decode GEMVs stream the fp8 copies (vox_hip_quantize_decoder_fp8)
     uint8_t *tok_emb8 = nullptr; float *stok = nullptr;
     // overlapped decode chain
@@ -1179,6 +1180,7 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
     const float scale = 1.0f / sqrtf((float)HD);
     for (int l = 0; l < d.dec_layers; l++) {
         DecLayer &L = e->dec[l];
+        if (!(e->skip_kinds & (1u << PK_QKV)))
         {   // RMSNorm -> merged QKV GEMV -> RoPE -> KV append   (voxtral_decoder.c:656-665)
             GemvArgs a{};
             a.W = L.wqkv; a.x = e->dx; a.norm_w = L.n1; a.ada = nullptr; a.eps = d.dec_eps; a.y = e->dq;
@@ -1197,6 +1199,7 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             else launch_gemv2<PRO_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
             prof_mark(e, PK_QKV);
         }
+        if (!(e->skip_kinds & (1u << PK_ATTN)))
         {   // attention over the KV window (voxtral_decoder.c:667-673)
             AttnArgs a{};
             a.out = e->dattn; a.ldo = DQ; a.q = e->dq; a.ldq = DQ; a.n_q = 1; a.qpos0 = kv_pos;
@@ -1217,6 +1220,7 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
                 prof_mark(e, PK_COMBINE);
             }
         }
+        if (!(e->skip_kinds & (1u << PK_WO)))
         {   // x += attn.Wo^T   (fast path: the split-K partials are merged in the prologue)
             GemvArgs a{};
             a.W = L.wo; a.x = e->dattn; a.y = e->dx; a.N = DD; a.K = DQ;
@@ -1232,6 +1236,7 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             else launch_gemv2<PRO_NONE, EPI_RESID, 3, 8, 1, 1>(e, a);
             prof_mark(e, PK_WO);
         }
+        if (!(e->skip_kinds & (1u << PK_SWIGLU)))
         {   // RMSNorm * (1+ada) -> silu(W1 x) * (W3 x)
             GemvArgs a{};
             a.W = L.w13; a.W2 = L.w13 + (size_t)DH * DD; a.x = e->dx; a.norm_w = L.n2; a.ada = L.ada; a.eps = d.dec_eps;
@@ -1247,6 +1252,7 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
             else launch_gemv2<PRO_RMS, EPI_SWIGLU, 3, 6, 1, 3>(e, a);
             prof_mark(e, PK_SWIGLU);
         }
+        if (!(e->skip_kinds & (1u << PK_W2)))
         {   // x += h.W2^T
             GemvArgs a{};
             a.W = L.w2; a.x = e->dh; a.y = e->dx; a.N = DD; a.K = DH;
@@ -1693,6 +1699,24 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
     e->dec_pos = saved_pos;
     return (double)ms * 1e-3 / iters;
+}
+
+// In-situ cost of one kernel kind: seconds per step with and without its launches (same stream,
+// same neighbours, no events in between); (full - skipped) / launches_per_step is the time the
+// kernel adds to the chain, boundary included.  kind: 1 qkv, 2 attention, 4 wo, 5 swiglu, 6 w2.
+extern "C" int vox_hip_time_decoder_step_without(vox_hip_engine_t *e, int iters, int kv_len, int kind,
+                                                 double *full_s, double *skipped_s) {
+    if (!e || kind <= 0 || kind >= PK_LOGITS) return -1;
+    const bool pdl = e->use_pdl;
+    e->use_pdl = false;
+    const double a = vox_hip_time_decoder_step(e, iters, kv_len);
+    e->skip_kinds = 1u << kind;
+    const double b = vox_hip_time_decoder_step(e, iters, kv_len);
+    e->skip_kinds = 0;
+    e->use_pdl = pdl;
+    if (full_s) *full_s = a;
+    if (skipped_s) *skipped_s = b;
+    return (a > 0 && b > 0) ? 0 : -1;
 }
 
 // Per-kernel average durations of the decode step, measured with HIP events recorded on the

@@ -340,6 +340,52 @@ def test_fp8_decode_weights_track_bf16(vox):
     assert t < 1.45e-3, t          # bf16 decode is 1.6 ms/token; half the weight bytes must show
 
 
+def _decode_after_long_prefill(vox, n_prompt, n_steps, seed, env=None, **model_kw):
+    """Decoder only, through the device seam: n_prompt synthetic adapter rows are prefilled, then
+    n_steps greedy steps with their logits."""
+    saved = {}
+    for k, val in (env or {}).items():
+        saved[k] = os.environ.get(k)
+        os.environ[k] = val
+    try:
+        with vox.Model(model_dir("full"), **model_kw) as m:
+            h, e = vox.hip, m.engine
+            rng = np.random.default_rng(seed)
+            rows = (rng.standard_normal((n_prompt + n_steps, m.dims.dec_dim)) * 0.3).astype(np.float32)
+            h.vox_hip_reset_decoder(e)
+            assert h.vox_hip_adapter_append(e, rows.ctypes.data_as(vox.f32p), rows.shape[0]) == 0
+            first = h.vox_hip_decoder_prefill_stream(e, 0, n_prompt, 1, 32, None)
+            toks = np.zeros(n_steps, np.int32)
+            logits = np.zeros((n_steps, m.dims.vocab), np.float32)
+            got = h.vox_hip_decoder_run(e, n_prompt, n_steps, first, -1, toks.ctypes.data_as(vox.i32p),
+                                        logits.ctypes.data_as(vox.f32p))
+            assert got == n_steps
+            return first, toks, logits
+    finally:
+        for k, val in saved.items():
+            if val is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = val
+
+
+@pytest.mark.parametrize("n_prompt,window,n_steps", [(2600, 0, 6), (1000, 64, 100)])
+def test_fast_decode_kernels_at_long_context_and_ring_wrap(vox, n_prompt, window, n_steps):
+    """The 4B-geometry decode kernels (k_gemv3, host-supplied positions, > 8 attention slices with the
+    separate combine; and, with a 64-position window, the KV ring wrapping at slot 1088 after 88
+    steps) against the generic kernels of the other geometries, which the golden long-context
+    cases pin to the reference."""
+    kw = dict(dec_window=window) if window else {}
+    f0, t0, l0 = _decode_after_long_prefill(vox, n_prompt, n_steps, 5, **kw)
+    f1, t1, l1 = _decode_after_long_prefill(vox, n_prompt, n_steps, 5, env={"VOX_HIP_NO_GEMV2": "1"}, **kw)
+    same = int(np.argmax(t0 != t1)) if (t0 != t1).any() else n_steps      # steps before the paths could diverge
+    err = float(np.abs(l0[:same + 1 if same < n_steps else same] - l1[:same + 1 if same < n_steps else same]).max())
+    diag(f"fast_vs_generic_{n_prompt}_{window}", err=err, first=[int(f0), int(f1)], same_steps=same)
+    assert f0 == f1
+    assert same >= min(n_steps, 95), same          # the wrap (step 88) is inside the compared range
+    assert err < LOGIT_TOL, err
+
+
 def test_overlapped_decode_chain_matches_plain_launches(vox):
     """Opt-in experiment (VOX_HIP_PDL=1): decode kernels alternate between two CU-masked streams
     and wait in-kernel for their predecessor.  Same kernels, same arithmetic: tokens must equal

@@ -27,9 +27,13 @@ def main():
     win = {} if preset != "tiny" else dict(enc_window=48, dec_window=64)
     model = v.Model(model_dir(preset), device=dev, **win)
     sess = DistributedSession(model, comm)
-    toks = sess.transcribe(synth_speech(seconds, seed))
-    if comm.rank == 0:
-        np.save(out_path, toks)
+    if len(sys.argv) > 5 and sys.argv[5] == "many":     # one clip per rank, every encoder sharded over all ranks
+        toks = sess.transcribe_many([synth_speech(seconds, seed + r) for r in range(comm.world)])
+        np.save(f"{out_path}.{comm.rank}.npy", toks)
+    else:
+        toks = sess.transcribe(synth_speech(seconds, seed))
+        if comm.rank == 0:
+            np.save(out_path, toks)
     comm.barrier()
     model.close()
     dist.destroy_process_group()

@@ -42,6 +42,26 @@ def test_sharded_transcription_equals_single_gpu(tmp_path, preset, seconds, worl
     assert np.array_equal(sharded, single)
 
 
+@pytest.mark.parametrize("preset,seconds,world", [("tiny", 12.0, 2)])
+def test_one_clip_per_rank_sharded_encoders_parallel_decoders(tmp_path, preset, seconds, world):
+    """bench.py --gpus N workload: N clips, each clip's encoder sharded over all ranks and gathered to
+    its owner, every rank decodes its own clip.  Each rank's tokens = single-GPU transcription."""
+    import voxtral_c_amd as v
+    out = str(tmp_path / "toks")
+    env = dict(os.environ, VOX_DIST_BACKEND="gloo", VOX_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "mgpu_worker.py"), preset, str(seconds), "91", out, "many"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    win = {} if preset != "tiny" else dict(enc_window=48, dec_window=64)
+    with v.Model(model_dir(preset), **win) as m:
+        for rank in range(world):
+            single = m.transcribe(synth_speech(seconds, 91 + rank))["tokens"]
+            got = np.load(f"{out}.{rank}.npy")
+            assert np.array_equal(got, single), rank
+
+
 def test_rccl_backend_single_rank_bench_path(tmp_path):
     """The RCCL ("nccl") code path of bench.py --gpus N (GPU-resident staging tensors handed to
     the engine by data_ptr, device-side adapter append, all_reduce of the timing) with the only

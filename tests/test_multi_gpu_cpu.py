@@ -98,7 +98,7 @@ class OracleShardEngine:
         pass
 
 
-def _worker(rank, world, port, mdir, out_path):
+def _worker(rank, world, port, mdir, out_path, dst=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -119,15 +119,16 @@ def _worker(rank, world, port, mdir, out_path):
     def staging(shape):
         return Staging(comm.empty(shape))
 
-    rows, counts = encode_sharded(eng, comm, padded, n_frames, staging)
-    if rank == 0:
+    rows, counts = encode_sharded(eng, comm, padded, n_frames, staging, dst=dst)
+    assert (rows is not None) == (rank == dst)
+    if rank == dst:
         np.save(out_path, rows.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_encoder_equals_single_process(tmp_path, world):
+@pytest.mark.parametrize("world,dst", [(2, 0), (3, 0), (2, 1)])
+def test_sharded_encoder_equals_single_process(tmp_path, world, dst):
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp
     from audio_util import synth_speech
@@ -135,7 +136,7 @@ def test_sharded_encoder_equals_single_process(tmp_path, world):
     from voxtral_c_amd.multi_gpu import padded_stream
     mdir = model_dir("tiny")
     out = str(tmp_path / "rows.npy")
-    mp.spawn(_worker, args=(world, _free_port(), mdir, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mdir, out, dst), nprocs=world, join=True)
     got = np.load(out)
     # single-process reference: whole clip through the oracle's stream encoder
     dims = vo.PRESETS["tiny"]

@@ -150,14 +150,14 @@ class TorchComm:
     def recv(self, t, src):
         self.dist.recv(t, src)
 
-    def gather_rows(self, t, counts):
-        """Variable-length gather of [m_r, D] row blocks to rank 0 (padded to the max count)."""
+    def gather_rows(self, t, counts, dst=0):
+        """Variable-length gather of [m_r, D] row blocks to rank `dst` (padded to the max count)."""
         mx = max(counts)
         pad = self.empty((mx, t.shape[1]))
         pad[:t.shape[0]] = t
-        lst = [self.empty((mx, t.shape[1])) for _ in range(self.world)] if self.rank == 0 else None
-        self.dist.gather(pad, lst, dst=0)
-        if self.rank != 0:
+        lst = [self.empty((mx, t.shape[1])) for _ in range(self.world)] if self.rank == dst else None
+        self.dist.gather(pad, lst, dst=dst)
+        if self.rank != dst:
             return None
         return self.torch.cat([lst[r][:counts[r]] for r in range(self.world)])
 
@@ -190,9 +190,9 @@ class Staging:
             self._to_dev()
 
 
-def encode_sharded(eng, comm, padded, n_frames, staging):
+def encode_sharded(eng, comm, padded, n_frames, staging, dst=0):
     """Wavefront context-parallel encode. `staging(shape)` returns a Staging buffer.
-    Returns (gathered adapter rows on rank 0 | None, per-rank row counts)."""
+    Returns (gathered adapter rows on rank `dst` | None, per-rank row counts)."""
     rank, world = comm.rank, comm.world
     plan = shard_plan(n_frames, world)
     pos0, pos1 = plan[rank]
@@ -221,7 +221,7 @@ def encode_sharded(eng, comm, padded, n_frames, staging):
     s_ad.after_engine_write()
     assert m == (pos1 - pos0) // 4
     counts = [(b - a) // 4 for a, b in plan]
-    return comm.gather_rows(s_ad.tensor, counts), counts
+    return comm.gather_rows(s_ad.tensor, counts, dst), counts
 
 
 # ---------------------------------------------------------------------------------------
@@ -243,10 +243,16 @@ def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
     win = {} if args.preset != "tiny" else dict(enc_window=48, dec_window=64)
     model = v.Model(mdir, device=dev, **win)
     session = DistributedSession(model, comm)
-    audio = synth_speech(args.seconds * world, 1234)
+    # one clip per GPU ("owner"); every clip's encoder is sharded over all GPUs, every GPU decodes
+    # its own clip (VOX_DIST_MODE=single: one long clip, decoder on rank 0 only — BASELINE config 4)
+    single = os.environ.get("VOX_DIST_MODE") == "single"
+    if single:
+        audio = synth_speech(args.seconds * world, 1234)
+    else:
+        audios = [synth_speech(args.seconds, 1234 + r) for r in range(world)]
 
     def one_pass():
-        toks = session.transcribe(audio)
+        toks = session.transcribe(audio) if single else session.transcribe_many(audios)
         comm.barrier()
         return toks
 
@@ -259,24 +265,35 @@ def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
         toks = one_pass()
     comm.barrier(); torch.cuda.synchronize()
     wall = time.time() - t0
-    tmax = torch.tensor([wall], dtype=torch.float64, device=comm.device if comm.on_gpu else "cpu")
+    dev_t = comm.device if comm.on_gpu else "cpu"
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev_t)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
+    t = model.timing()                       # of the last pass on this rank
+    agg = torch.tensor([float(t["decode_steps"]), float(len(toks)) if toks is not None else 0.0], dtype=torch.float64, device=dev_t)
+    dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+    dmax = torch.tensor([float(t["decode_ms"])], dtype=torch.float64, device=dev_t)
+    dist.all_reduce(dmax, op=dist.ReduceOp.MAX)
     if rank == 0:
-        t = model.timing()
         audio_s = args.seconds * world
+        dec_ms = float(dmax.item())
         out = {
             "metric": "real-time-factor + decode tokens/sec, Voxtral-4B bf16, 30s audio",
             "value": round(wall / args.steps / audio_s, 5), "unit": "wall s / audio s (RTF)", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 2),
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 weights, f32 activations/accumulate", "data": "synthetic",
-            "decode_tok_s": round(t["decode_steps"] / (t["decode_ms"] * 1e-3), 1) if t["decode_ms"] > 0 else 0.0,
-            "decoder_steps_per_pass": int(len(toks)) if toks is not None else 0,
-            "config": {"workload": f"Voxtral-4B ({args.preset} synthetic checkpoint), {audio_s:g} s clip = {args.seconds:g} s per GPU: "
-                                   f"encoder positions sharded over {world} GPUs (wavefront K/V halo over xGMI), adapter rows gathered "
-                                   "to rank 0, single-stream greedy decode on rank 0",
-                       "audio_seconds": audio_s, "parallelism": f"cp{world} encoder / 1 decoder", "backend": backend},
+            "decode_tok_s": round(float(agg[0].item()) / (dec_ms * 1e-3), 1) if dec_ms > 0 else 0.0,
+            "decode_tok_s_per_stream": round(t["decode_steps"] / (t["decode_ms"] * 1e-3), 1) if t["decode_ms"] > 0 else 0.0,
+            "decoder_steps_per_pass": int(agg[1].item()),
+            "config": {"workload": (f"Voxtral-4B ({args.preset} synthetic checkpoint), one {audio_s:g} s clip: encoder positions sharded over "
+                                    f"{world} GPUs (wavefront K/V halo over xGMI), adapter rows gathered to rank 0, single-stream greedy "
+                                    "decode on rank 0") if single else
+                                   (f"Voxtral-4B ({args.preset} synthetic checkpoint), {world} clips of {args.seconds:g} s (one per GPU): each clip's "
+                                    f"encoder positions are sharded over all {world} GPUs (wavefront K/V halo over xGMI, RCCL gather of the "
+                                    "adapter rows to the clip's GPU), then every GPU runs the single-stream greedy decoder of its own clip"),
+                       "audio_seconds": audio_s, "parallelism": f"cp{world} encoder / " + ("1 decoder" if single else f"{world} decoders"),
+                       "backend": backend},
         }
         print(json.dumps(out), flush=True)
     model.close()
@@ -315,16 +332,38 @@ class DistributedSession:
             self.v.hip.vox_hip_device_free(self.model.engine, C.c_void_p(d))
         self._dev_bufs = []
 
+    def transcribe_many(self, audios, delay_tokens=6):
+        """One clip per rank ("owner").  Every clip's encoder is sharded over ALL ranks (wavefront K/V
+        halo, adapter rows gathered to the clip's owner); afterwards every rank decodes its own
+        clip, so the strictly sequential decoders of the N streams run side by side.  Returns
+        this rank's token ids."""
+        assert len(audios) == self.comm.world
+        rows_mine = None
+        for owner, audio in enumerate(audios):
+            padded, n_frames = padded_stream(audio, delay_tokens)
+            self.eng.reset()
+            rows, _ = encode_sharded(self.eng, self.comm, padded, n_frames, self.staging, dst=owner)
+            if self.comm.on_gpu and rows is not None:
+                rows = rows.clone()              # outlives the staging buffers of the later clips
+            self._free_staging()
+            if owner == self.comm.rank:
+                rows_mine = rows
+        self.eng.reset()
+        return self._decode_rows(rows_mine, delay_tokens)
+
     def transcribe(self, audio, delay_tokens=6):
         """Sharded encode on all ranks, greedy decode on rank 0. Returns token ids on rank 0."""
-        v, h, comm, model = self.v, self.v.hip, self.comm, self.model
         padded, n_frames = padded_stream(audio, delay_tokens)
-        prompt_len = 1 + LEFT_PAD_TOKENS + delay_tokens
         self.eng.reset()
-        rows, counts = encode_sharded(self.eng, comm, padded, n_frames, self.staging)
+        rows, counts = encode_sharded(self.eng, self.comm, padded, n_frames, self.staging)
         self._free_staging()
+        return self._decode_rows(rows, delay_tokens) if self.comm.rank == 0 else None
+
+    def _decode_rows(self, rows, delay_tokens):
+        v, h, comm, model = self.v, self.v.hip, self.comm, self.model
+        prompt_len = 1 + LEFT_PAD_TOKENS + delay_tokens
         toks = None
-        if comm.rank == 0:
+        if rows is not None:
             total = int(rows.shape[0])
             if comm.on_gpu:
                 comm.sync()

@@ -85,6 +85,82 @@ def cpu_baseline(model_dir_full, preset_dims):
         return {"error": str(ex)}
 
 
+def roofline_block(v, model, dims, n_tok, weights="bf16"):
+    """roofline object of the JSON line: dominant decode kernel (w1;w3 GEMV) measured live with HIP
+    events on the engine stream, plus the per-kernel table and the whole-step figure."""
+    # ---- roofline of the dominant kernel, measured live with HIP events --------------------
+    import ctypes as C
+    v.hip.vox_hip_profile_decode.restype = C.c_double
+    v.hip.vox_hip_profile_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    kv_len = int(min(39 + n_tok / 2, dims.dec_window))      # mean KV length over the decode of this clip
+    avg = (C.c_double * 9)(); cnt = (C.c_int * 9)()
+    s_per_step_prof = v.hip.vox_hip_profile_decode(model.engine, 20, kv_len, avg, cnt)
+    s_per_step = model.time_decoder_step(50, kv_len)
+    wbytes, kvbytes, kern_bytes = decode_bytes(dims, kv_len)
+    v.hip.vox_hip_time_layer_repeat.restype = C.c_double
+    v.hip.vox_hip_time_layer_repeat.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    avg_c = (C.c_double * 9)(); cnt_c = (C.c_int * 9)()
+    v.hip.vox_hip_time_layer_repeat(model.engine, 100, kv_len, avg_c, cnt_c)
+    cached = {PK_NAMES[i]: round(avg_c[i], 2) for i in range(9) if cnt_c[i]}
+    kernels = {}
+    for i, name in enumerate(PK_NAMES):
+        if cnt[i]:
+            ent = {"launches_per_token": cnt[i], "avg_us": round(avg[i], 2)}
+            if name in kern_bytes:
+                ent["bytes"] = kern_bytes[name]
+                ent["GBps"] = round(kern_bytes[name] / (avg[i] * 1e-6) / 1e9, 1) if avg[i] > 0 else 0.0
+            kernels[name] = ent
+    dom = "gemv_swiglu"
+    # Launch duration of the dominant kernel inside the chain: HIP events around N whole decode
+    # steps with and without the 26 w1;w3 launches, on the engine stream; the difference / 26 is
+    # what one launch costs in situ (boundary included, no event packets between kernels).  The
+    # event-per-kernel table below ("kernels") carries ~3 us of event overhead per entry.
+    v.hip.vox_hip_time_decoder_step_without.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    t_full, t_skip = C.c_double(), C.c_double()
+    dom_us = None
+    if v.hip.vox_hip_time_decoder_step_without(model.engine, 50, kv_len, 5, C.byref(t_full), C.byref(t_skip)) == 0:
+        dom_us = (t_full.value - t_skip.value) / dims.dec_layers * 1e6
+    if dom_us and dom_us > 0:
+        dom_bytes = kern_bytes[dom] // (2 if weights == "fp8" else 1)
+        dom_ach = round(dom_bytes / (dom_us * 1e-6) / 1e9, 1)
+    else:
+        dom_us = kernels.get(dom, {}).get("avg_us")
+        dom_ach = kernels.get(dom, {}).get("GBps", 0.0)
+    # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in
+    # its own run, tools/run_pmc.sh; x1024 x2 correction of MI355X_MICROARCH.md, HBM section)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_decode_summary.json")) as fh:
+            pm = json.load(fh)["kernels"]
+        for name, ent in pm.items():
+            if "k_gemv3<1, 3, 3, 6, 1, 3" in name:
+                traffic = round(ent["hbm_read_bytes_per_launch_corrected"])
+    except Exception:
+        traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": "k_gemv3<PRO_RMS,EPI_SWIGLU,3,6,1,3> (decoder W1;W3 GEMV, 43% of the weight bytes of a token)",
+        "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_ach / HBM_PEAK_GBS, 4),
+        "bytes_per_launch": kern_bytes[dom] // (2 if weights == "fp8" else 1), "avg_us_per_launch": round(dom_us, 2),
+        "method": "HIP events on the engine stream around 50 decode steps with and without the 26 launches of this kernel; "
+                  "(full - skipped) / 26",
+        "traffic": traffic, "traffic_source": "profiles/r01_pmc_decode_summary.json (FETCH_SIZE, read bytes per launch)",
+        "decode_step": {"algorithmic_bytes": wbytes + kvbytes, "ms": round(s_per_step * 1e3, 4),
+                        "GBps": round((wbytes + kvbytes) / s_per_step / 1e9, 1),
+                        "frac_of_peak": round((wbytes + kvbytes) / s_per_step / 1e9 / HBM_PEAK_GBS, 4),
+                        "kv_len": kv_len, "ms_event_bracketed": round(s_per_step_prof * 1e3, 4),
+                        "one_layer_repeated_us (weights Infinity-Cache resident)": cached},
+        "kernels": kernels,
+    }
+
+    if weights == "fp8":       # half the weight bytes per token; the per-kernel byte table above is the bf16 one
+        roofline["note"] = "fp8 decode weights: algorithmic bytes per GEMV launch are half the bf16 figures listed"
+        roofline["decode_step"]["algorithmic_bytes"] = wbytes // 2 + kvbytes
+        roofline["decode_step"]["GBps"] = round((wbytes // 2 + kvbytes) / s_per_step / 1e9, 1)
+        roofline["decode_step"]["frac_of_peak"] = round((wbytes // 2 + kvbytes) / s_per_step / 1e9 / HBM_PEAK_GBS, 4)
+    return roofline
+
+
 def stream_mode(args, model, audio, v):
     """BASELINE config 3: the clip arrives in 0.5 s pieces (vox_stream_feed per piece, -I 0.5,
     continuous mode so the decoder KV rolls over); not paced to real time — the per-chunk latency
@@ -198,76 +274,7 @@ def main():
     n_tok = steps_tokens / args.steps
     decode_tok_s = dec_steps / (dec_ms * 1e-3) if dec_ms > 0 else 0.0
 
-    # ---- roofline of the dominant kernel, measured live with HIP events --------------------
-    import ctypes as C
-    v.hip.vox_hip_profile_decode.restype = C.c_double
-    v.hip.vox_hip_profile_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
-    kv_len = int(min(39 + n_tok / 2, dims.dec_window))      # mean KV length over the decode of this clip
-    avg = (C.c_double * 9)(); cnt = (C.c_int * 9)()
-    s_per_step_prof = v.hip.vox_hip_profile_decode(model.engine, 20, kv_len, avg, cnt)
-    s_per_step = model.time_decoder_step(50, kv_len)
-    wbytes, kvbytes, kern_bytes = decode_bytes(dims, kv_len)
-    v.hip.vox_hip_time_layer_repeat.restype = C.c_double
-    v.hip.vox_hip_time_layer_repeat.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
-    avg_c = (C.c_double * 9)(); cnt_c = (C.c_int * 9)()
-    v.hip.vox_hip_time_layer_repeat(model.engine, 100, kv_len, avg_c, cnt_c)
-    cached = {PK_NAMES[i]: round(avg_c[i], 2) for i in range(9) if cnt_c[i]}
-    kernels = {}
-    for i, name in enumerate(PK_NAMES):
-        if cnt[i]:
-            ent = {"launches_per_token": cnt[i], "avg_us": round(avg[i], 2)}
-            if name in kern_bytes:
-                ent["bytes"] = kern_bytes[name]
-                ent["GBps"] = round(kern_bytes[name] / (avg[i] * 1e-6) / 1e9, 1) if avg[i] > 0 else 0.0
-            kernels[name] = ent
-    dom = "gemv_swiglu"
-    # Launch duration of the dominant kernel inside the chain: HIP events around N whole decode
-    # steps with and without the 26 w1;w3 launches, on the engine stream; the difference / 26 is
-    # what one launch costs in situ (boundary included, no event packets between kernels).  The
-    # event-per-kernel table below ("kernels") carries ~3 us of event overhead per entry.
-    v.hip.vox_hip_time_decoder_step_without.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    t_full, t_skip = C.c_double(), C.c_double()
-    dom_us = None
-    if v.hip.vox_hip_time_decoder_step_without(model.engine, 50, kv_len, 5, C.byref(t_full), C.byref(t_skip)) == 0:
-        dom_us = (t_full.value - t_skip.value) / dims.dec_layers * 1e6
-    if dom_us and dom_us > 0:
-        dom_bytes = kern_bytes[dom] // (2 if args.weights == "fp8" else 1)
-        dom_ach = round(dom_bytes / (dom_us * 1e-6) / 1e9, 1)
-    else:
-        dom_us = kernels.get(dom, {}).get("avg_us")
-        dom_ach = kernels.get(dom, {}).get("GBps", 0.0)
-    # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in
-    # its own run, tools/run_pmc.sh; x1024 x2 correction of MI355X_MICROARCH.md, HBM section)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_decode_summary.json")) as fh:
-            pm = json.load(fh)["kernels"]
-        for name, ent in pm.items():
-            if "k_gemv3<1, 3, 3, 6, 1, 3" in name:
-                traffic = round(ent["hbm_read_bytes_per_launch_corrected"])
-    except Exception:
-        traffic = None
-    roofline = {
-        "bound": "hbm", "kernel": "k_gemv3<PRO_RMS,EPI_SWIGLU,3,6,1,3> (decoder W1;W3 GEMV, 43% of the weight bytes of a token)",
-        "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_ach / HBM_PEAK_GBS, 4),
-        "bytes_per_launch": kern_bytes[dom] // (2 if args.weights == "fp8" else 1), "avg_us_per_launch": round(dom_us, 2),
-        "method": "HIP events on the engine stream around 50 decode steps with and without the 26 launches of this kernel; "
-                  "(full - skipped) / 26",
-        "traffic": traffic, "traffic_source": "profiles/r01_pmc_decode_summary.json (FETCH_SIZE, read bytes per launch)",
-        "decode_step": {"algorithmic_bytes": wbytes + kvbytes, "ms": round(s_per_step * 1e3, 4),
-                        "GBps": round((wbytes + kvbytes) / s_per_step / 1e9, 1),
-                        "frac_of_peak": round((wbytes + kvbytes) / s_per_step / 1e9 / HBM_PEAK_GBS, 4),
-                        "kv_len": kv_len, "ms_event_bracketed": round(s_per_step_prof * 1e3, 4),
-                        "one_layer_repeated_us (weights Infinity-Cache resident)": cached},
-        "kernels": kernels,
-    }
-
-    if args.weights == "fp8":       # half the weight bytes per token; the per-kernel byte table above is the bf16 one
-        roofline["note"] = "fp8 decode weights: algorithmic bytes per GEMV launch are half the bf16 figures listed"
-        roofline["decode_step"]["algorithmic_bytes"] = wbytes // 2 + kvbytes
-        roofline["decode_step"]["GBps"] = round((wbytes // 2 + kvbytes) / s_per_step / 1e9, 1)
-        roofline["decode_step"]["frac_of_peak"] = round((wbytes // 2 + kvbytes) / s_per_step / 1e9 / HBM_PEAK_GBS, 4)
+    roofline = roofline_block(v, model, dims, n_tok, args.weights)
     out = {
         "metric": "real-time-factor + decode tokens/sec, Voxtral-4B bf16, 30s audio" if args.weights == "bf16" else
                   "real-time-factor + decode tokens/sec, Voxtral-4B fp8 decode weights, 30s audio",

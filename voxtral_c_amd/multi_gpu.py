@@ -238,7 +238,10 @@ def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
     share = os.environ.get("VOX_SHARE_GPU") == "1"          # several ranks on one GPU (gloo only; tests)
     dev = 0 if share else local_rank
     torch.cuda.set_device(dev)
-    dist.init_process_group(backend=backend)
+    if backend == "nccl":
+        dist.init_process_group(backend=backend, device_id=torch.device(f"cuda:{dev}"))
+    else:
+        dist.init_process_group(backend=backend)
     comm = TorchComm(device=f"cuda:{dev}")
     win = {} if args.preset != "tiny" else dict(enc_window=48, dec_window=64)
     model = v.Model(mdir, device=dev, **win)
@@ -295,6 +298,11 @@ def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
                        "audio_seconds": audio_s, "parallelism": f"cp{world} encoder / " + ("1 decoder" if single else f"{world} decoders"),
                        "backend": backend},
         }
+        try:        # same live roofline measurement as the 1-GPU line (rank 0's engine)
+            from bench import roofline_block
+            out["roofline"] = roofline_block(v, model, model.dims, float(len(toks)) if toks is not None else 380.0)
+        except Exception as ex:
+            out["roofline"] = {"error": str(ex)}
         print(json.dumps(out), flush=True)
     model.close()
     dist.destroy_process_group()

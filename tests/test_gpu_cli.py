@@ -1,0 +1,71 @@
+"""GPU: the reference's own CLI (main.c, unmodified, compiled against include/ and linked with
+libvoxtral.so by oracle/Makefile -> oracle/_ref/voxtral_cli_hip) transcribing a WAV file on the
+engine.  Checks the drop-in boundary end to end: WAV loading, the stream API as main.c drives it
+(-i file, --stdin with -I), text on stdout, the Audio/Encoder/Decoder stat lines benchmark.py
+parses on stderr.  The expected text comes from the same engine through the Python mirror."""
+import os
+import re
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+
+from audio_util import synth_speech
+from conftest import ROOT, model_dir
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ROOT, "oracle", "_ref", "voxtral_cli_hip")
+
+
+def _write_wav(path, samples):
+    pcm = np.clip(np.round(samples * 32767.0), -32768, 32767).astype("<i2")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(pcm.tobytes())
+
+
+@pytest.fixture(scope="module")
+def clip(tmp_path_factory):
+    path = str(tmp_path_factory.mktemp("cli") / "clip.wav")
+    _write_wav(path, synth_speech(9.0, 314))
+    return path
+
+
+def _expected(vox, samples, **kw):
+    with vox.Model(model_dir("full")) as m:
+        r = m.transcribe(samples, **kw)
+    return "".join(p for p in r["pieces"]), len(r["tokens"])
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="oracle/_ref/voxtral_cli_hip not built (needs the reference checkout at build time)")
+def test_reference_cli_transcribes_a_wav_on_the_engine(clip):
+    import voxtral_c_amd as vox
+    audio = vox.load_wav(clip)
+    # main.c feeds a file in 16000-sample pieces (DEFAULT_FEED_CHUNK, main.c:21,109-118)
+    want, n_tok = _expected(vox, audio, feed_sizes=[16000] * (len(audio) // 16000 + 1))
+    r = subprocess.run([CLI, "-d", model_dir("full"), "-i", clip], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(want.strip()) > 40, want            # real text, not an empty-vs-empty comparison
+    assert r.stdout.strip() == want.strip()
+    assert n_tok > 50
+    # the lines benchmark.py scrapes (benchmark.py:25-30; format of voxtral.c:1308-1316)
+    assert re.search(r"Audio: \d+ samples", r.stderr), r.stderr[-500:]
+    assert re.search(r"Encoder: \d+ mel -> \d+ tokens \(\d+ ms\)", r.stderr), r.stderr[-500:]
+    assert re.search(r"Decoder: \d+ text tokens \(\d+ steps\) in \d+ ms", r.stderr), r.stderr[-500:]
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="oracle/_ref/voxtral_cli_hip not built")
+def test_reference_cli_stdin_streaming(clip):
+    """--stdin with raw s16le 16 kHz audio and -I 0.5: the CLI feeds 4096-sample reads."""
+    import voxtral_c_amd as vox
+    with wave.open(clip, "rb") as w:
+        pcm = w.readframes(w.getnframes())
+    # main.c: first a 4096-byte header probe (2048 samples), then 4096-sample reads, /32768,
+    # continuous mode for live sources (main.c:204-206,301-378)
+    audio = np.frombuffer(pcm, "<i2").astype(np.float32) / 32768.0
+    want, _ = _expected(vox, audio, feed_sizes=[2048] + [4096] * (len(audio) // 4096 + 1), interval=0.5, continuous=True)
+    r = subprocess.run([CLI, "-d", model_dir("full"), "--stdin", "-I", "0.5"], input=pcm, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(want.strip()) > 40, want
+    assert r.stdout.decode().strip() == want.strip()

@@ -235,6 +235,10 @@ def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
 
     backend = os.environ.get("VOX_DIST_BACKEND", "nccl")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # one node, no fabric: keep RCCL's bootstrap off interface / InfiniBand probing (seen to stall
+    # communicator creation for ~2 minutes on boxes without a network)
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     share = os.environ.get("VOX_SHARE_GPU") == "1"          # several ranks on one GPU (gloo only; tests)
     dev = 0 if share else local_rank
     torch.cuda.set_device(dev)

@@ -69,3 +69,24 @@ def test_reference_cli_stdin_streaming(clip):
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(want.strip()) > 40, want
     assert r.stdout.decode().strip() == want.strip()
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="oracle/_ref/voxtral_cli_hip not built")
+def test_engine_cli_prints_what_the_reference_binary_prints(tmp_path):
+    """tests/golden/cli_full.json holds stdout of the reference's own binary (CPU, `make blas` flags,
+    tools/make_cli_golden.py) for a seeded clip and the full-size synthetic checkpoint; the same
+    main.c on the engine must print the same text for the same WAV."""
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "cli_full.json")))
+    clip = str(tmp_path / "clip.wav")
+    _write_wav(clip, synth_speech(float(g["seconds"]), int(g["seed"])))
+    r = subprocess.run([CLI, "-d", model_dir("full"), "-i", clip], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(g["stdout"].strip()) > 40
+    assert r.stdout == g["stdout"]
+    # same audio / mel / token accounting in the stat lines (timings differ, of course)
+    ref_enc = re.search(r"Encoder: (\d+) mel -> (\d+) tokens", "\n".join(g["stderr_stats"])).groups()
+    got_enc = re.search(r"Encoder: (\d+) mel -> (\d+) tokens", r.stderr).groups()
+    ref_dec = re.search(r"Decoder: (\d+) text tokens \((\d+) steps\)", "\n".join(g["stderr_stats"])).groups()
+    got_dec = re.search(r"Decoder: (\d+) text tokens \((\d+) steps\)", r.stderr).groups()
+    assert ref_enc == got_enc and ref_dec == got_dec

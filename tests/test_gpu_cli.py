@@ -90,3 +90,22 @@ def test_engine_cli_prints_what_the_reference_binary_prints(tmp_path):
     ref_dec = re.search(r"Decoder: (\d+) text tokens \((\d+) steps\)", "\n".join(g["stderr_stats"])).groups()
     got_dec = re.search(r"Decoder: (\d+) text tokens \((\d+) steps\)", r.stderr).groups()
     assert ref_enc == got_enc and ref_dec == got_dec
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="oracle/_ref/voxtral_cli_hip not built")
+def test_engine_cli_stdin_stream_prints_what_the_reference_binary_prints(tmp_path):
+    """Same golden clip as a raw s16le stream on stdin with -I 0.5 (continuous mode, 4096-sample reads):
+    stdout of the reference binary (tests/golden/cli_full_stdin.json) vs the engine."""
+    import json
+    path = os.path.join(ROOT, "tests", "golden", "cli_full_stdin.json")
+    if not os.path.exists(path):
+        pytest.skip("golden not generated")
+    g = json.load(open(path))
+    clip = str(tmp_path / "clip.wav")
+    _write_wav(clip, synth_speech(float(g["seconds"]), int(g["seed"])))
+    with wave.open(clip, "rb") as w:
+        pcm = w.readframes(w.getnframes())
+    r = subprocess.run([CLI, "-d", model_dir("full"), "--stdin", "-I", "0.5"], input=pcm, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(g["stdout"].strip()) > 40
+    assert r.stdout.decode() == g["stdout"]

@@ -43,6 +43,21 @@ def main():
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1)[:1500])
 
+    # the same clip as a raw s16le stream on stdin, processing interval 0.5 s (main.c: 4096-sample
+    # reads, continuous mode)
+    with wave.open(clip, "rb") as w:
+        pcm = w.readframes(w.getnframes())
+    t0 = time.time()
+    r = subprocess.run([REF, "-d", model_dir("full"), "--stdin", "-I", "0.5"], input=pcm, capture_output=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    err = r.stderr.decode()
+    out = {"seconds": SECONDS, "seed": SEED, "stdout": r.stdout.decode(),
+           "stderr_stats": [ln for ln in err.splitlines() if ln.startswith(("Audio:", "Encoder:", "Decoder:"))],
+           "generator": "tools/make_cli_golden.py (--stdin -I 0.5, raw s16le)", "cpu_seconds": round(time.time() - t0, 1)}
+    with open(os.path.join(ROOT, "tests", "golden", "cli_full_stdin.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1)[:1500])
+
 
 if __name__ == "__main__":
     main()

@@ -109,3 +109,19 @@ def test_engine_cli_stdin_stream_prints_what_the_reference_binary_prints(tmp_pat
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(g["stdout"].strip()) > 40
     assert r.stdout.decode() == g["stdout"]
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="oracle/_ref/voxtral_cli_hip not built")
+def test_engine_cli_alt_tokens_print_what_the_reference_binary_prints(tmp_path):
+    """--alt 0.9 (vox_stream_set_alt / vox_stream_get_alt: host softmax over each logits row,
+    voxtral.c:911-966): stdout of the reference binary vs the engine."""
+    import json
+    path = os.path.join(ROOT, "tests", "golden", "cli_full_alt.json")
+    if not os.path.exists(path):
+        pytest.skip("golden not generated")
+    g = json.load(open(path))
+    clip = str(tmp_path / "clip.wav")
+    _write_wav(clip, synth_speech(float(g["seconds"]), int(g["seed"])))
+    r = subprocess.run([CLI, "-d", model_dir("full"), "-i", clip, "--alt", "0.9"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == g["stdout"]

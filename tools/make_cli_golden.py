@@ -43,6 +43,16 @@ def main():
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1)[:1500])
 
+    # --alt 0.9: alternatives within the softmax cutoff are printed in brackets (main.c:46-80)
+    t0 = time.time()
+    r = subprocess.run([REF, "-d", model_dir("full"), "-i", clip, "--alt", "0.9"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = {"seconds": SECONDS, "seed": SEED, "stdout": r.stdout, "generator": "tools/make_cli_golden.py (--alt 0.9)",
+           "cpu_seconds": round(time.time() - t0, 1)}
+    with open(os.path.join(ROOT, "tests", "golden", "cli_full_alt.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1)[:800])
+
     # the same clip as a raw s16le stream on stdin, processing interval 0.5 s (main.c: 4096-sample
     # reads, continuous mode)
     with wave.open(clip, "rb") as w:

@@ -273,6 +273,28 @@ def test_stream_tiny_matches_reference_golden(tiny, name, feed, interval, cont):
         assert res["pieces_equal"], res
 
 
+@pytest.mark.parametrize("name,preset,feed", [("tiny_delay240", "tiny", None), ("tiny_delay960", "tiny", 16000),
+                                              ("small_delay160", "small", None)])
+def test_stream_with_other_delay_matches_reference_golden(tiny, small, name, preset, feed):
+    """vox_set_delay: time conditioning (a6, host side), prompt of 1 + 32 + delay tokens, right padding."""
+    g = gold(f"stream_{name}.npz")
+    meta = g["meta"]
+    audio = synth_speech(float(meta[1]), int(meta[2]))
+    feeds = None if feed is None else [feed] * (len(audio) // feed + 1)
+    m = tiny if preset == "tiny" else small
+    try:
+        got = m.transcribe(audio, feed_sizes=feeds, record_logits=4096, delay_ms=int(meta[6]))
+    finally:
+        m.set_delay(480)
+    res = compare_stream(name, got, g)
+    assert res.get("logit_err", 0.0) < LOGIT_TOL, res
+    if res["first_mismatch"] is not None:
+        assert res["ref_margin_at_mismatch"] < 2 * LOGIT_TOL, res
+    else:
+        assert res["steps"] == res["ref_steps"], res
+        assert res["pieces_equal"], res
+
+
 def test_stream_small_matches_reference_golden(small):
     g = gold("stream_small_batch.npz")
     meta = g["meta"]

@@ -60,6 +60,19 @@ def test_stream_transcription_matches_golden():
     assert np.abs(top - g["top_vals"]).max() < 1e-3
 
 
+def test_stream_transcription_with_other_delay_matches_golden():
+    """vox_set_delay(240 ms): time conditioning (voxtral.c:31-80), prompt length 1+32+3, right padding."""
+    from audio_util import synth_speech
+    g = gold("stream_tiny_delay240.npz")
+    o = vo.Oracle(model_dir("tiny"), TINY)
+    o.delay_tokens = int(g["meta"][6]) // 80
+    o.update_time_conditioning()
+    toks, logs = o.transcribe(synth_speech(float(g["meta"][1]), int(g["meta"][2])))
+    assert np.array_equal(toks, g["tokens"])
+    top = np.take_along_axis(logs, g["top_ids"], axis=1)
+    assert np.abs(top - g["top_vals"]).max() < 1e-3
+
+
 @pytest.mark.skipif(not have_ref("tiny"), reason="oracle/_ref not built")
 def test_kernels_match_live_reference(ref_tiny):
     rng = np.random.default_rng(0)

@@ -40,6 +40,10 @@ CASES = [
     ("tiny_continuous", "tiny", 200.0, 3, 4096, 0.5, True),    # restarts at kv > 2000
     ("small_batch", "small", 8.0, 4, None, None, False),
     ("small_long", "small", 95.0, 6, None, None, False),       # > 1024 decoder positions: split-K attention + combine kernel
+    # vox_set_delay (time conditioning a6, prompt length 1+32+delay, right padding): 240 ms and 960 ms
+    ("tiny_delay240", "tiny", 10.0, 8, None, None, False, 240),
+    ("tiny_delay960", "tiny", 10.0, 8, "1s", None, False, 960),
+    ("small_delay160", "small", 8.0, 4, None, None, False, 160),
 ]
 
 
@@ -74,7 +78,9 @@ def main():
     cases = list(CASES)
     if args.full:
         cases.append(("full_batch", "full", 6.0, 5, None, None, False))
-    for name, preset, secs, aseed, feed, interval, cont in cases:
+    for case in cases:
+        name, preset, secs, aseed, feed, interval, cont = case[:7]
+        delay_ms = case[7] if len(case) > 7 else None
         if args.only and args.only != name:
             continue
         if preset not in libs:
@@ -84,10 +90,12 @@ def main():
         audio = synth_speech(secs, aseed)
         ctx = R.load(model_dir(preset))
         r = R.transcribe_stream(ctx, audio, feed_sizes=feeds_for(feed, len(audio)), interval=interval,
-                                continuous=cont, vocab=d.vocab, max_logit_rows=4096 if preset != "full" else 512)
+                                continuous=cont, vocab=d.vocab, max_logit_rows=4096 if preset != "full" else 512,
+                                delay_ms=delay_ms)
         R.free(ctx)
         out = summarise(r, d.vocab)
-        out["meta"] = np.array([preset, str(secs), str(aseed), str(feed), str(interval), str(int(cont))], dtype=object)
+        out["meta"] = np.array([preset, str(secs), str(aseed), str(feed), str(interval), str(int(cont)),
+                                str(delay_ms if delay_ms is not None else 480)], dtype=object)
         np.savez_compressed(os.path.join(GOLD, f"stream_{name}.npz"), **out)
         mg = out.get("margin")
         print(f"{name}: {len(out['tokens'])} steps, {len(set(out['tokens'].tolist()))} distinct tokens, "

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_cli.py -m gpu -q -x --durations=5 -p no:cacheprovider 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "delay" --durations=5 -p no:cacheprovider 2>&1 | tail -12

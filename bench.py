@@ -138,6 +138,9 @@ def roofline_block(v, model, dims, n_tok, weights="bf16"):
                 traffic = round(ent["hbm_read_bytes_per_launch_corrected"])
     except Exception:
         traffic = None
+    v.hip.vox_hip_time_empty_launches.restype = C.c_double
+    v.hip.vox_hip_time_empty_launches.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    floor_us = {g: round(v.hip.vox_hip_time_empty_launches(model.engine, 2000, g) * 1e6, 2) for g in (256, 768)}
     roofline = {
         "bound": "hbm", "kernel": "k_gemv3<PRO_RMS,EPI_SWIGLU,3,6,1,3> (decoder W1;W3 GEMV, 43% of the weight bytes of a token)",
         "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_ach / HBM_PEAK_GBS, 4),
@@ -149,6 +152,7 @@ def roofline_block(v, model, dims, n_tok, weights="bf16"):
                         "GBps": round((wbytes + kvbytes) / s_per_step / 1e9, 1),
                         "frac_of_peak": round((wbytes + kvbytes) / s_per_step / 1e9 / HBM_PEAK_GBS, 4),
                         "kv_len": kv_len, "ms_event_bracketed": round(s_per_step_prof * 1e3, 4),
+                        "empty_kernel_us_per_launch (grid 256 / 768 x 256 threads, back to back)": floor_us,
                         "one_layer_repeated_us (weights Infinity-Cache resident)": cached},
         "kernels": kernels,
     }

@@ -191,6 +191,10 @@ double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int kv_len);
  *  6 w2 gemv, 7 logits gemv, 8 argmax}; HIP events on the engine stream. Returns s/step. */
 double vox_hip_profile_decode(vox_hip_engine_t *e, int iters, int kv_len, double *avg_us, int *launches);
 
+/* Seconds per launch of n back-to-back launches of an (almost) empty kernel with `grid` blocks of 256
+ * threads on the engine stream: the kernel-boundary floor of the launch model on this stack. */
+double vox_hip_time_empty_launches(vox_hip_engine_t *e, int n, int grid);
+
 /* In-situ cost of one decode kernel kind (1 qkv, 2 attention, 4 wo, 5 w1;w3, 6 w2): seconds per step
  * with and without its launches; (full - skipped) / layers = what one launch adds to the chain. */
 int vox_hip_time_decoder_step_without(vox_hip_engine_t *e, int iters, int kv_len, int kind,

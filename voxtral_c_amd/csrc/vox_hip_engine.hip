@@ -1701,6 +1701,24 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
     return (double)ms * 1e-3 / iters;
 }
 
+// What a kernel boundary costs on this stack: n back-to-back launches of a kernel that only reads
+// its argument and writes one word per block, with a GEMV-sized grid.  Returns seconds per launch.
+__global__ __launch_bounds__(256) void k_boundary_probe(float *sink, int blocks_that_write) {
+    if (threadIdx.x == 0 && (int)blockIdx.x < blocks_that_write) sink[blockIdx.x] = (float)blockIdx.x;
+}
+extern "C" double vox_hip_time_empty_launches(vox_hip_engine_t *e, int n, int grid) {
+    if (!e || n <= 0 || grid <= 0) return -1.0;
+    if (hipSetDevice(e->device) != hipSuccess) return -1.0;
+    for (int i = 0; i < 8; i++) hipLaunchKernelGGL(k_boundary_probe, dim3(grid), dim3(256), 0, e->stream, e->dh, 16);
+    hipEventRecord(e->ev0, e->stream);
+    for (int i = 0; i < n; i++) hipLaunchKernelGGL(k_boundary_probe, dim3(grid), dim3(256), 0, e->stream, e->dh, 16);
+    hipEventRecord(e->ev1, e->stream);
+    hipStreamSynchronize(e->stream);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    return (double)ms * 1e-3 / n;
+}
+
 // In-situ cost of one kernel kind: seconds per step with and without its launches (same stream,
 // same neighbours, no events in between); (full - skipped) / launches_per_step is the time the
 // kernel adds to the chain, boundary included.  kind: 1 qkv, 2 attention, 4 wo, 5 swiglu, 6 w2.

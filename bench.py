@@ -140,7 +140,10 @@ def roofline_block(v, model, dims, n_tok, weights="bf16"):
         traffic = None
     v.hip.vox_hip_time_empty_launches.restype = C.c_double
     v.hip.vox_hip_time_empty_launches.argtypes = [C.c_void_p, C.c_int, C.c_int]
-    floor_us = {g: round(v.hip.vox_hip_time_empty_launches(model.engine, 2000, g) * 1e6, 2) for g in (256, 768)}
+    v.hip.vox_hip_time_empty_launches_graph.restype = C.c_double
+    v.hip.vox_hip_time_empty_launches_graph.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    floor_us = {f"eager_{g}": round(v.hip.vox_hip_time_empty_launches(model.engine, 2000, g) * 1e6, 2) for g in (256, 768)}
+    floor_us.update({f"graph_{g}": round(v.hip.vox_hip_time_empty_launches_graph(model.engine, 2000, g) * 1e6, 2) for g in (256, 768)})
     roofline = {
         "bound": "hbm", "kernel": "k_gemv3<PRO_RMS,EPI_SWIGLU,3,6,1,3> (decoder W1;W3 GEMV, 43% of the weight bytes of a token)",
         "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_ach / HBM_PEAK_GBS, 4),

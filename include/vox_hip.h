@@ -194,6 +194,8 @@ double vox_hip_profile_decode(vox_hip_engine_t *e, int iters, int kv_len, double
 /* Seconds per launch of n back-to-back launches of an (almost) empty kernel with `grid` blocks of 256
  * threads on the engine stream: the kernel-boundary floor of the launch model on this stack. */
 double vox_hip_time_empty_launches(vox_hip_engine_t *e, int n, int grid);
+/* The same chain captured into a hipGraph and replayed (no host launch cost in the timed region). */
+double vox_hip_time_empty_launches_graph(vox_hip_engine_t *e, int n, int grid);
 
 /* In-situ cost of one decode kernel kind (1 qkv, 2 attention, 4 wo, 5 w1;w3, 6 w2): seconds per step
  * with and without its launches; (full - skipped) / layers = what one launch adds to the chain. */

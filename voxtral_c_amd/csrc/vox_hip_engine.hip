@@ -1718,6 +1718,31 @@ extern "C" double vox_hip_time_empty_launches(vox_hip_engine_t *e, int n, int gr
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
     return (double)ms * 1e-3 / n;
 }
+// The same chain captured once into a hipGraph and replayed: no host launch cost in the timed
+// region, i.e. the GPU-side boundary alone.
+extern "C" double vox_hip_time_empty_launches_graph(vox_hip_engine_t *e, int n, int grid) {
+    if (!e || n <= 0 || grid <= 0) return -1.0;
+    if (hipSetDevice(e->device) != hipSuccess) return -1.0;
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    hipStreamSynchronize(e->stream);
+    if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
+    for (int i = 0; i < n; i++) hipLaunchKernelGGL(k_boundary_probe, dim3(grid), dim3(256), 0, e->stream, e->dh, 16);
+    if (hipStreamEndCapture(e->stream, &g) != hipSuccess || !g) { (void)hipGetLastError(); return -1.0; }
+    double r = -1.0;
+    if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
+        hipGraphLaunch(ge, e->stream);                         // warm-up replay
+        hipEventRecord(e->ev0, e->stream);
+        hipGraphLaunch(ge, e->stream);
+        hipEventRecord(e->ev1, e->stream);
+        hipStreamSynchronize(e->stream);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e->ev0, e->ev1);
+        r = (double)ms * 1e-3 / n;
+        hipGraphExecDestroy(ge);
+    } else (void)hipGetLastError();
+    hipGraphDestroy(g);
+    return r;
+}
 
 // In-situ cost of one kernel kind: seconds per step with and without its launches (same stream,
 // same neighbours, no events in between); (full - skipped) / launches_per_step is the time the

@@ -1688,6 +1688,24 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
             hipMemcpy(h.data(), e->d_pdl_trace, h.size() * 8, hipMemcpyDeviceToHost);
             if (FILE *f = fopen(tp, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
         }
+    } else if (getenv("VOX_HIP_GRAPH_TIMING")) {
+        // experiment: the same step captured once into a hipGraph and replayed (no host launch cost)
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        for (int i = 0; i < 3; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);
+        hipStreamSynchronize(e->stream);
+        bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            enqueue_step(e, pos, true, e->dlogits, -1, 0);
+            ok = hipStreamEndCapture(e->stream, &g) == hipSuccess && g &&
+                 hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
+        }
+        if (!ok) { (void)hipGetLastError(); return -1.0; }
+        for (int i = 0; i < 3; i++) hipGraphLaunch(ge, e->stream);
+        hipEventRecord(e->ev0, e->stream);
+        for (int i = 0; i < iters; i++) hipGraphLaunch(ge, e->stream);
+        hipEventRecord(e->ev1, e->stream);
+        hipStreamSynchronize(e->stream);
+        hipGraphExecDestroy(ge); hipGraphDestroy(g);
     } else {
         for (int i = 0; i < 3; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);   // warm-up
         hipEventRecord(e->ev0, e->stream);

@@ -52,6 +52,12 @@ float *vox_parse_wav_buffer(const uint8_t *data, size_t size, int *out_n_samples
         fprintf(stderr, "parse_wav_buffer: unsupported format (need 16-bit PCM, got fmt=%d bits=%d)\n", fmt, bits);
         return NULL;
     }
+    /* a zero / absurd sample rate divides by zero in the resampler below (the reference does, too:
+     * voxtral_audio.c:112-116); found by tools/fuzz_host.c */
+    if (rate < 100 || rate > 3072000) {
+        fprintf(stderr, "parse_wav_buffer: unsupported sample rate %d\n", rate);
+        return NULL;
+    }
     int n = pcm_bytes / (channels * 2);
     float *mono = (float *)malloc((size_t)(n > 0 ? n : 1) * sizeof(float));
     if (!mono) return NULL;

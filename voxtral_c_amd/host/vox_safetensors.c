@@ -125,7 +125,7 @@ vox_st_file_t *vox_st_open(const char *path) {
             } else skip(&c);
             free(key);
         }
-        if (c.bad || off1 < off0 || (uint64_t)off1 > payload_size) {
+        if (c.bad || off0 < 0 || off1 < off0 || (uint64_t)off1 > payload_size) {
             fprintf(stderr, "%s: tensor %s out of bounds\n", path, name);
             free(name); c.bad = 1; break;
         }
@@ -134,7 +134,7 @@ vox_st_file_t *vox_st_open(const char *path) {
         f->tensors[f->n_tensors++] = t;
     }
     if (c.bad) { fprintf(stderr, "%s: cannot parse safetensors header\n", path); vox_st_close(f); return NULL; }
-    qsort(f->tensors, (size_t)f->n_tensors, sizeof(vox_st_tensor_t), cmp_name);
+    if (f->n_tensors > 0) qsort(f->tensors, (size_t)f->n_tensors, sizeof(vox_st_tensor_t), cmp_name);
     return f;
 }
 

@@ -100,6 +100,12 @@ int main(int argc, char **argv) {
             ok_st++;
             const vox_st_tensor_t *t = vox_st_find(f, "mm_streams_embeddings.embedding_module.tok_embeddings.weight");
             if (t) (void)vox_st_numel(t);
+            static const char *names[] = {"norm.weight", "layers.0.attention.wq.weight",
+                                          "mm_streams_embeddings.embedding_module.tok_embeddings.weight"};
+            for (int k = 0; k < 3; k++) {
+                const vox_st_tensor_t *u = vox_st_find(f, names[k]);
+                if (u) { float *v = vox_st_to_f32(u); if (v) { volatile float a = v[0]; (void)a; free(v); } }
+            }
             vox_st_close(f);
         }
 

@@ -108,7 +108,7 @@ static int discover_dims(const vox_st_file_t *sf, vox_model_dims_t *d) {
     snprintf(nm, sizeof nm, ENC_PFX ".transformer.layers.0.feed_forward.w1.weight");
     if (!(t = need(sf, nm))) return -1;
     d->enc_hidden = (int)t->shape[0];
-    if (!(t = need(sf, EMB_PFX ".tok_embeddings.weight"))) return -1;
+    if (!(t = need(sf, EMB_PFX ".tok_embeddings.weight")) || t->ndim != 2) return -1;
     d->vocab = (int)t->shape[0]; d->dec_dim = (int)t->shape[1];
     d->dec_layers = count_layers(sf, "layers.%d.attention.wq.weight");
     if (!(t = need(sf, "layers.0.attention.wq.weight"))) return -1;
@@ -123,6 +123,23 @@ static int discover_dims(const vox_st_file_t *sf, vox_model_dims_t *d) {
     d->dec_window = VOX_DEC_WINDOW;
     if (d->mel_bins != VOX_MEL_BINS || d->enc_layers <= 0 || d->dec_layers <= 0) {
         fprintf(stderr, "vox_load: unexpected checkpoint geometry\n");
+        return -1;
+    }
+    /* the header is user data: refuse geometries the engine cannot mean (a hostile or truncated
+     * file must fail here, not in an allocation of 2^60 bytes) */
+    const int lim[][3] = {
+        {d->enc_dim, 64, 1 << 16}, {d->enc_heads, 1, 1024}, {d->enc_hidden, 64, 1 << 18}, {d->enc_layers, 1, 1024},
+        {d->dec_dim, 64, 1 << 16}, {d->dec_heads, 1, 1024}, {d->dec_kv_heads, 1, 1024}, {d->dec_hidden, 64, 1 << 18},
+        {d->dec_layers, 1, 1024}, {d->vocab, 1000 + 2, 1 << 22}, {d->ada_dim, 1, 1 << 16},
+    };
+    for (size_t i = 0; i < sizeof lim / sizeof lim[0]; i++)
+        if (lim[i][0] < lim[i][1] || lim[i][0] > lim[i][2]) {
+            fprintf(stderr, "vox_load: checkpoint geometry out of range (field %d = %d)\n", (int)i, lim[i][0]);
+            return -1;
+        }
+    if (d->dec_heads % d->dec_kv_heads != 0 || d->enc_dim % 8 != 0 || d->dec_dim % 8 != 0 || d->enc_hidden % 8 != 0 ||
+        d->dec_hidden % 8 != 0) {
+        fprintf(stderr, "vox_load: checkpoint geometry not supported (head grouping / alignment)\n");
         return -1;
     }
     return 0;

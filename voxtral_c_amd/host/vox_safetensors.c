@@ -130,6 +130,18 @@ vox_st_file_t *vox_st_open(const char *path) {
             free(name); c.bad = 1; break;
         }
         t.data = payload + off0; t.nbytes = (size_t)(off1 - off0);
+        {   /* shape and byte span must agree: vox_st_to_f32 and the uploads trust numel */
+            int64_t n = 1; int okshape = 1;
+            for (int i = 0; i < t.ndim; i++) {
+                if (t.shape[i] < 0 || (t.shape[i] > 0 && n > ((int64_t)1 << 40) / t.shape[i])) { okshape = 0; break; }
+                n *= t.shape[i];
+            }
+            const int64_t esz = (t.dtype == VOX_ST_F32) ? 4 : (t.dtype == VOX_ST_BF16 || t.dtype == VOX_ST_F16) ? 2 : 0;
+            if (!okshape || (esz && (uint64_t)(n * esz) != (uint64_t)t.nbytes)) {
+                fprintf(stderr, "%s: tensor %s: shape does not match its data span\n", path, name);
+                free(name); c.bad = 1; break;
+            }
+        }
         if (f->n_tensors == cap) { cap = cap ? cap * 2 : 1024; f->tensors = (vox_st_tensor_t *)realloc(f->tensors, (size_t)cap * sizeof t); }
         f->tensors[f->n_tensors++] = t;
     }
@@ -177,12 +189,12 @@ float *vox_st_to_f32(const vox_st_tensor_t *t) {
     float *out = (float *)malloc((size_t)(n > 0 ? n : 1) * sizeof(float));
     if (!out) return NULL;
     if (t->dtype == VOX_ST_F32) memcpy(out, t->data, (size_t)n * 4);
-    else if (t->dtype == VOX_ST_BF16) {
-        const uint16_t *s = (const uint16_t *)t->data;
-        for (int64_t i = 0; i < n; i++) { uint32_t u = (uint32_t)s[i] << 16; memcpy(&out[i], &u, 4); }
+    else if (t->dtype == VOX_ST_BF16) {           /* memcpy reads: a hand-made header may leave the payload unaligned */
+        const uint8_t *s = (const uint8_t *)t->data;
+        for (int64_t i = 0; i < n; i++) { uint16_t h; memcpy(&h, s + 2 * i, 2); uint32_t u = (uint32_t)h << 16; memcpy(&out[i], &u, 4); }
     } else if (t->dtype == VOX_ST_F16) {
-        const uint16_t *s = (const uint16_t *)t->data;
-        for (int64_t i = 0; i < n; i++) out[i] = half_to_float(s[i]);
+        const uint8_t *s = (const uint8_t *)t->data;
+        for (int64_t i = 0; i < n; i++) { uint16_t h; memcpy(&h, s + 2 * i, 2); out[i] = half_to_float(h); }
     } else { free(out); return NULL; }
     return out;
 }

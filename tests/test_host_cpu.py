@@ -131,3 +131,28 @@ def test_safetensors_index_against_python_reader(tiny_dir):
     open(os.path.join(bad, "consolidated.safetensors"), "wb").write(src[: len(src) // 2])
     with pytest.raises(v.VoxError):
         v.Model(bad)
+
+
+def test_public_api_tolerates_null_and_missing_inputs():
+    """Error conventions of voxtral.h (NULL / -1 / 0), no crash: NULL handles and missing files."""
+    import ctypes as C
+    import voxtral_c_amd as v
+    lib = v.lib
+    assert not lib.vox_load_ex(None, None)
+    lib.vox_free(None)
+    assert lib.vox_stream_init(None) is None
+    assert lib.vox_stream_feed(None, None, 10) == -1
+    assert lib.vox_stream_finish(None) == -1 and lib.vox_stream_flush(None) == -1
+    lib.vox_stream_free(None)
+    buf = (C.c_char_p * 4)()
+    lib.vox_stream_get.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int]
+    assert lib.vox_stream_get(None, buf, 4) == 0
+    lib.vox_stream_set_alt.argtypes = [C.c_void_p, C.c_int, C.c_float]
+    lib.vox_stream_set_alt(None, 3, 0.5)
+    lib.vox_set_processing_interval.argtypes = [C.c_void_p, C.c_float]
+    lib.vox_set_processing_interval(None, 0.5)
+    lib.vox_stream_set_continuous(None, 1)
+    lib.vox_set_delay(None, 480)
+    n = C.c_int(0)
+    assert not lib.vox_load_wav(b"/nonexistent.wav", C.byref(n))
+    assert not lib.vox_tokenizer_load(b"/nonexistent.json")

@@ -490,3 +490,16 @@ def test_empty_and_ragged_inputs(tiny, vox):
     s.free()
     # 160 samples: M = 32 + 1 + 17 = 50 adapter tokens, prompt 39 -> 12 decoder steps (or EOS earlier)
     assert 1 <= len(toks) <= 12
+
+
+def test_load_fails_cleanly_when_hbm_cannot_hold_the_kv_rings(vox):
+    """A decoder window whose single K ring (window x 4 KB) exceeds the HBM: vox_load must fail with an
+    error (NULL), free what it had taken and leave the device usable."""
+    before = None
+    with vox.Model(model_dir("tiny"), enc_window=48, dec_window=64) as m:
+        before = m.transcribe(synth_speech(3.0, 5))["tokens"]
+    with pytest.raises(vox.VoxError):
+        vox.Model(model_dir("tiny"), dec_window=200_000_000)
+    with vox.Model(model_dir("tiny"), enc_window=48, dec_window=64) as m:
+        after = m.transcribe(synth_speech(3.0, 5))["tokens"]
+    assert np.array_equal(before, after)

@@ -503,3 +503,18 @@ def test_load_fails_cleanly_when_hbm_cannot_hold_the_kv_rings(vox):
     with vox.Model(model_dir("tiny"), enc_window=48, dec_window=64) as m:
         after = m.transcribe(synth_speech(3.0, 5))["tokens"]
     assert np.array_equal(before, after)
+
+
+def test_garbage_audio_does_not_take_the_device_down(tiny, vox):
+    """NaN / Inf / huge samples (an uninitialised buffer handed to vox_stream_feed): logits become NaN, the
+    argmax scan has no winner -> token 0 like the reference's scan; no out-of-range embedding gather,
+    and the next clean transcription is unaffected."""
+    clean = synth_speech(4.0, 6)
+    want = tiny.transcribe(clean)["tokens"]
+    bad = clean.copy()
+    bad[1000:1200] = np.nan
+    bad[5000:5100] = np.inf
+    bad[9000:9050] = -3.0e38
+    got = tiny.transcribe(bad)["tokens"]
+    assert len(got) >= 1 and int(np.max(got)) < tiny.dims.vocab and int(np.min(got)) >= 0
+    assert np.array_equal(tiny.transcribe(clean)["tokens"], want)

@@ -458,7 +458,11 @@ __global__ __launch_bounds__(256) void k_argmax_finish(const float *blk_val, con
         __syncthreads();
     }
     if (tid == 0) {
-        const int tok = si[0];
+        // all-NaN / all -inf logits (garbage audio) leave the scan without a winner; the reference's
+        // scan (voxtral_decoder.c:697-704) then keeps index 0.  Never hand an out-of-range id to the
+        // embedding gather of the next step.
+        int tok = si[0];
+        if (tok < 0 || tok == 0x7fffffff) tok = 0;
         if (!st->stop) {
             // write-through stores: under overlapped launches the next step's first kernel may
             // already be resident on the other half of the chip

@@ -590,7 +590,7 @@ __device__ __forceinline__ void persist_control(const PersistArgs &a, const Pers
             const int oi = __shfl_xor(bi, off, 64);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        token = bi;
+        token = (bi < 0 || bi == 0x7fffffff) ? 0 : bi;      // no winner (all-NaN logits): index 0 like the reference's scan
         if (lane == 0) reinterpret_cast<int *>(m.ctl)[0] = token;
         __syncthreads();                                                           // S17
         pos += 1; arow += 1;

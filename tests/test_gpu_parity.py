@@ -518,3 +518,26 @@ def test_garbage_audio_does_not_take_the_device_down(tiny, vox):
     got = tiny.transcribe(bad)["tokens"]
     assert len(got) >= 1 and int(np.max(got)) < tiny.dims.vocab and int(np.min(got)) >= 0
     assert np.array_equal(tiny.transcribe(clean)["tokens"], want)
+
+
+def test_repeated_streams_and_models_do_not_leak(vox):
+    """50 streams on one model and 6 model load/free cycles: device memory accounted by the engine and
+    the host RSS stay flat (stream-owned host buffers, tokenizer cache, scratch growth)."""
+    import psutil
+    proc = psutil.Process()
+    audio = synth_speech(3.0, 8)
+    with vox.Model(model_dir("tiny"), enc_window=48, dec_window=64) as m:
+        for _ in range(5):
+            m.transcribe(audio)
+        mem0, rss0 = m.memory_used(), proc.memory_info().rss
+        for _ in range(50):
+            m.transcribe(audio, feed_sizes=[4096] * 12, interval=0.1)
+        mem1, rss1 = m.memory_used(), proc.memory_info().rss
+    assert mem1 == mem0, (mem0, mem1)
+    assert rss1 - rss0 < 8 << 20, (rss0, rss1)
+    rss2 = proc.memory_info().rss
+    for _ in range(6):
+        with vox.Model(model_dir("small")) as m2:
+            m2.transcribe(audio)
+    rss3 = proc.memory_info().rss
+    assert rss3 - rss2 < 64 << 20, (rss2, rss3)

@@ -541,3 +541,29 @@ def test_repeated_streams_and_models_do_not_leak(vox):
             m2.transcribe(audio)
     rss3 = proc.memory_info().rss
     assert rss3 - rss2 < 64 << 20, (rss2, rss3)
+
+
+def test_two_models_interleaved_and_in_threads(vox):
+    """No hidden global state: two engines alive at once, fed alternately, and two threads each driving
+    its own model give the tokens of isolated runs."""
+    import threading
+    a1, a2 = synth_speech(5.0, 11), synth_speech(5.0, 12)
+    kw = dict(enc_window=48, dec_window=64)
+    with vox.Model(model_dir("tiny"), **kw) as m:
+        want1, want2 = m.transcribe(a1)["tokens"], m.transcribe(a2)["tokens"]
+    with vox.Model(model_dir("tiny"), **kw) as m1, vox.Model(model_dir("tiny"), **kw) as m2:
+        s1, s2 = vox.Stream(m1), vox.Stream(m2)
+        for off in range(0, len(a1), 8000):
+            s1.feed(a1[off:off + 8000]); s2.feed(a2[off:off + 8000])
+        s1.finish(); s2.finish()
+        t1, t2 = s1.token_ids(), s2.token_ids()
+        s1.free(); s2.free()
+        assert np.array_equal(t1, want1) and np.array_equal(t2, want2)
+        out = {}
+
+        def run(model, audio, key):
+            out[key] = [model.transcribe(audio)["tokens"] for _ in range(5)]
+        th = [threading.Thread(target=run, args=(m1, a1, 1)), threading.Thread(target=run, args=(m2, a2, 2))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert all(np.array_equal(t, want1) for t in out[1]) and all(np.array_equal(t, want2) for t in out[2])

@@ -6,7 +6,11 @@ mono audio per GPU, batch encoder + greedy decode through the voxtral.h API.
 A "step" = one complete transcription (vox_stream_init -> feed(all samples) -> finish).
 Weights are the full-size seeded synthetic checkpoint (tools/synth_model.c, exact 4B
 architecture; there are no real weights offline) already resident in HBM when the timed
-region starts; the audio is synthetic speech-like noise (tests/audio_util.py).
+region starts.  The 30 s input is the one SURVEY 8(d) names - the first 480 000 samples of
+the reference's samples/benchmark/night1968/45s_right_through_the_billboard.wav, carried by
+the golden fixture tests/golden/stream_full_batch.npz - and after the timed region the pass's
+token ids are compared with that fixture, i.e. with the reference CPU path's own run on the
+same checkpoint and audio ("parity" in the JSON line).  Other lengths tile that clip.
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
@@ -29,6 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 PK_NAMES = ["step_begin", "gemv_qkv_rope_kv", "attn_dec", "attn_combine", "gemv_wo_resid", "gemv_swiglu",
             "gemv_w2_resid", "gemv_logits_argmax", "argmax_finish"]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (≈6.3 TB/s achievable)
+DOM_KERNEL_SUBSTR = "k_gemv3<1, 3, 3, 6, 1, 3"     # the W1;W3 + SwiGLU decode GEMV as rocprofv3 prints it
 
 
 def decode_bytes(d, kv_len):
@@ -46,6 +51,72 @@ def decode_bytes(d, kv_len):
         "attn_dec": 2 * kv_len * dkv * 4,
     }
     return w, kv, kern
+
+
+def headline_audio(seconds):
+    """(samples, golden or None): the SURVEY 8(d) 30 s input from the golden fixture, tiled for longer runs."""
+    path = os.path.join(ROOT, "tests", "golden", "stream_full_batch.npz")
+    try:
+        g = np.load(path, allow_pickle=True)
+        base = g["audio_i16"].astype(np.float32) / 32768.0
+    except Exception:
+        from audio_util import synth_speech
+        return synth_speech(seconds, 1234), None, "synthetic speech-like signal (tests/audio_util.py); golden fixture missing"
+    n = int(round(seconds * 16000))
+    if n == len(base):
+        return base, g, "first 480000 samples of night1968/45s_right_through_the_billboard.wav (SURVEY 8(d)), from tests/golden/stream_full_batch.npz"
+    reps = -(-n // len(base))
+    return np.tile(base, reps)[:n].copy(), None, f"the 30 s night1968 clip of tests/golden/stream_full_batch.npz tiled to {seconds:g} s"
+
+
+def parity_block(tokens, g):
+    """Token ids of the timed pass against the reference's own run (golden generated from oracle/_ref)."""
+    if g is None:
+        return {"checked": False, "reason": "no golden for this length / preset"}
+    ref = g["tokens"]
+    t = np.asarray(tokens)
+    n = min(len(t), len(ref))
+    mism = int((t[:n] != ref[:n]).sum()) + abs(len(t) - len(ref))
+    first = next((int(i) for i in range(n) if t[i] != ref[i]), None)
+    return {"checked": True, "steps": int(len(ref)), "mismatches": mism, "first_mismatch": first,
+            "distinct_ref_tokens": int(len(set(ref.tolist()))), "min_ref_margin": float(g["margin"].min()),
+            "golden": "tests/golden/stream_full_batch.npz (reference CPU path, oracle/_ref, same checkpoint + audio)"}
+
+
+def live_pmc_traffic(kernel_substr, timeout_s=240):
+    """HBM read bytes per launch of the dominant kernel from a live `rocprofv3 --pmc FETCH_SIZE` sub-run
+    (own pass, --kernel-trace only, as MI355X_MICROARCH.md prescribes; x1024 x2 correction).  None if the
+    profiler is unavailable or the run fails."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    out = tempfile.mkdtemp(prefix="vox_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+           sys.executable, os.path.join(ROOT, "tools", "pmc_decode.py"), "3"]
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_summary
+        dst = os.path.join(out, "summary.json")
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            if pmc_summary.main(out, dst) != 0:
+                return None, "no counter_collection.csv produced"
+        with open(dst) as fh:
+            ks = json.load(fh)["kernels"]
+        for name, ent in ks.items():
+            if kernel_substr in name and "hbm_read_bytes_per_launch_corrected" in ent:
+                return round(ent["hbm_read_bytes_per_launch_corrected"]), \
+                    f"live rocprofv3 --pmc FETCH_SIZE --kernel-trace sub-run of tools/pmc_decode.py ({ent['FETCH_SIZE']['launches']} launches; KB x1024 x2)"
+        return None, "dominant kernel not found in the counter output"
+    except Exception as ex:
+        return None, f"pmc sub-run failed: {type(ex).__name__}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def cpu_baseline(model_dir_full, preset_dims):
@@ -73,7 +144,14 @@ def cpu_baseline(model_dir_full, preset_dims):
         # 30 s clip: 1696 encoder rows (attention cost grows with the window, so this linear
         # extrapolation of a 100-row chunk is a lower bound), 38-row prefill, 386 steps
         est = t_enc * 1696 / 100 + t_pre + 386 * t_step
+        measured = None
+        try:       # the unmodified reference CLI run end to end on a GPU-box host (tools/cpu_baseline_cli.py), committed per round
+            with open(os.path.join(ROOT, "profiles", "r02_cpu_baseline_cli.json")) as fh:
+                measured = json.load(fh)
+        except Exception:
+            pass
         return {"value": round(est / 30.0, 2), "unit": "wall s / audio s (RTF), 30 s clip, extrapolated from the sample",
+                "measured_end_to_end": measured,
                 "cores": os.cpu_count(), "kind": "reference",
                 "threads_note": "decode GEMV is single-threaded in the reference; OpenBLAS threads only in the M>1 GEMMs",
                 "decode_tok_s": round(1.0 / t_step, 3), "ms_per_decode_step": round(t_step * 1e3, 1),
@@ -85,7 +163,7 @@ def cpu_baseline(model_dir_full, preset_dims):
         return {"error": str(ex)}
 
 
-def roofline_block(v, model, dims, n_tok, weights="bf16"):
+def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True):
     """roofline object of the JSON line: dominant decode kernel (w1;w3 GEMV) measured live with HIP
     events on the engine stream, plus the per-kernel table and the whole-step figure."""
     # ---- roofline of the dominant kernel, measured live with HIP events --------------------
@@ -127,17 +205,26 @@ def roofline_block(v, model, dims, n_tok, weights="bf16"):
     else:
         dom_us = kernels.get(dom, {}).get("avg_us")
         dom_ach = kernels.get(dom, {}).get("GBps", 0.0)
-    # HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in
-    # its own run, tools/run_pmc.sh; x1024 x2 correction of MI355X_MICROARCH.md, HBM section)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_decode_summary.json")) as fh:
-            pm = json.load(fh)["kernels"]
-        for name, ent in pm.items():
-            if "k_gemv3<1, 3, 3, 6, 1, 3" in name:
-                traffic = round(ent["hbm_read_bytes_per_launch_corrected"])
-    except Exception:
-        traffic = None
+    # HBM traffic of the dominant kernel: a live rocprofv3 --pmc FETCH_SIZE sub-run (own pass,
+    # --kernel-trace only; x1024 x2 correction of MI355X_MICROARCH.md, HBM section).  Only if that is
+    # impossible, the committed PMC pass of an earlier run - and the JSON says which it was.
+    traffic, traffic_source = (None, "disabled (--no-pmc)")
+    if pmc and weights == "bf16":
+        traffic, traffic_source = live_pmc_traffic(DOM_KERNEL_SUBSTR)
+    if traffic is None:
+        why = traffic_source
+        for prof in ("r02_pmc_decode_summary.json", "r01_pmc_decode_summary.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", prof)) as fh:
+                    pm = json.load(fh)["kernels"]
+                for name, ent in pm.items():
+                    if DOM_KERNEL_SUBSTR in name:
+                        traffic = round(ent["hbm_read_bytes_per_launch_corrected"])
+                        traffic_source = f"NOT measured in this run ({why}); committed pass profiles/{prof}"
+                if traffic is not None:
+                    break
+            except Exception:
+                pass
     v.hip.vox_hip_time_empty_launches.restype = C.c_double
     v.hip.vox_hip_time_empty_launches.argtypes = [C.c_void_p, C.c_int, C.c_int]
     v.hip.vox_hip_time_empty_launches_graph.restype = C.c_double
@@ -150,7 +237,7 @@ def roofline_block(v, model, dims, n_tok, weights="bf16"):
         "bytes_per_launch": kern_bytes[dom] // (2 if weights == "fp8" else 1), "avg_us_per_launch": round(dom_us, 2),
         "method": "HIP events on the engine stream around 50 decode steps with and without the 26 launches of this kernel; "
                   "(full - skipped) / 26",
-        "traffic": traffic, "traffic_source": "profiles/r01_pmc_decode_summary.json (FETCH_SIZE, read bytes per launch)",
+        "traffic": traffic, "traffic_source": traffic_source,
         "decode_step": {"algorithmic_bytes": wbytes + kvbytes, "ms": round(s_per_step * 1e3, 4),
                         "GBps": round((wbytes + kvbytes) / s_per_step / 1e9, 1),
                         "frac_of_peak": round((wbytes + kvbytes) / s_per_step / 1e9 / HBM_PEAK_GBS, 4),
@@ -222,6 +309,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=30.0, help="audio seconds per GPU")
     ap.add_argument("--preset", default="full", help="full | small | tiny (full = Voxtral-4B shapes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc FETCH_SIZE sub-run (roofline.traffic)")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: BASELINE config 5 (row-scaled e4m3 decoder weights for the decode GEMVs); not the headline")
     ap.add_argument("--mode", default="batch", choices=["batch", "stream"],
@@ -253,7 +341,9 @@ def main():
     model = v.Model(mdir, device=local_rank, weights=args.weights, **win)
     load_s = time.time() - t0
     dims = model.dims            # geometry as read from the checkpoint by vox_load
-    audio = synth_speech(args.seconds, 1234)
+    audio, golden, audio_desc = headline_audio(args.seconds)
+    if args.preset != "full" or args.weights != "bf16":
+        golden = None
 
     if args.mode == "stream":
         return stream_mode(args, model, audio, v)
@@ -281,13 +371,18 @@ def main():
     n_tok = steps_tokens / args.steps
     decode_tok_s = dec_steps / (dec_ms * 1e-3) if dec_ms > 0 else 0.0
 
-    roofline = roofline_block(v, model, dims, n_tok, args.weights)
+    parity = parity_block(r["tokens"], golden)
+    roofline = roofline_block(v, model, dims, n_tok, args.weights, pmc=not args.no_pmc and args.preset == "full")
+    mask, path_names = model.active_paths()
     out = {
         "metric": "real-time-factor + decode tokens/sec, Voxtral-4B bf16, 30s audio" if args.weights == "bf16" else
                   "real-time-factor + decode tokens/sec, Voxtral-4B fp8 decode weights, 30s audio",
         "value": round(rtf, 5), "unit": "wall s / audio s (RTF)", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 weights, f32 activations/accumulate (fp32 FMA GEMV, f32 MFMA GEMM)", "data": "synthetic",
+        "dtype": "bf16 weights, f32 activations/accumulate (fp32 FMA GEMV, f32 MFMA GEMM)",
+        "data": "synthetic",
+        "data_note": "weights: seeded synthetic checkpoint of the exact architecture (no real weights offline); audio: " + audio_desc,
+        "parity": parity, "active_paths": path_names,
         "decode_tok_s": round(decode_tok_s, 1), "decode_ms_per_token": round(dec_ms / max(dec_steps, 1), 4),
         "encode_ms": round(enc_ms / args.steps, 2), "prefill_ms": round(pre_ms / args.steps, 2),
         "decoder_steps_per_pass": n_tok, "model_load_s": round(load_s, 1),

@@ -113,6 +113,11 @@ int vox_hip_adapter(vox_hip_engine_t *e, const float *enc_out, int enc_len, floa
  * boundary state on the device. out may be NULL. Returns rows produced ([rows, enc_dim]). */
 int vox_hip_conv_stem(vox_hip_engine_t *e, const float *mel_new, int n_mel, float *out, int out_cap_rows);
 
+/* Batch-conv tail (vox_causal_conv1d right padding, voxtral_kernels.c:293-340 as used by
+ * vox_encoder_forward, voxtral_encoder.c:162-176): if an odd conv0 frame is waiting for its stride-2
+ * partner, pair it with a zero frame and emit the last row. out_row [enc_dim]. Returns 1 / 0 / -1. */
+int vox_hip_conv_stem_pad_odd(vox_hip_engine_t *e, float *out_row);
+
 /* vox_decoder_prefill (voxtral_decoder.c:410): embeds [seq_len, dec_dim]. */
 int vox_hip_decoder_prefill(vox_hip_engine_t *e, const float *embeds, int seq_len);
 
@@ -208,10 +213,24 @@ int vox_hip_time_decoder_step_without(vox_hip_engine_t *e, int iters, int kv_len
 int vox_hip_quantize_decoder_fp8(vox_hip_engine_t *e);
 int vox_hip_weight_format(vox_hip_engine_t *e);
 
-/* Decode path used by vox_hip_decoder_run: 0 plain launches, 1 overlapped chain on two CU-masked
- * streams (VOX_HIP_PDL=1, experiment: slower than plain launches), 2 persistent kernel
- * (VOX_HIP_PERSIST=1, experiment). */
-int vox_hip_decode_path(vox_hip_engine_t *e);
+/* Which kernel families are live (bit set = the production variant).  The start-up self-tests compare
+ * each MFMA / DPP kernel with a plain HIP cross-check; a mismatch makes vox_hip_engine_create (and so
+ * vox_load) FAIL unless VOX_HIP_ALLOW_FALLBACK=1, in which case the bit is cleared.  The A/B switches
+ * VOX_HIP_NO_* clear bits too.  VOX_PATH_GEMV3 is reported only for the 4B decoder shapes the kernel
+ * is specialised for (other geometries run the generic k_gemv). */
+enum vox_hip_path {
+    VOX_PATH_GEMM_MFMA_BF16X3 = 1u << 0,   /* large-M GEMM: 3-term bf16 split on v_mfma_f32_32x32x16_bf16 */
+    VOX_PATH_GEMM_MFMA_F32    = 1u << 1,   /* large-M GEMM: v_mfma_f32_32x32x2_f32 (K % 64 != 0 shapes)    */
+    VOX_PATH_GEMM_SPLITK      = 1u << 2,   /* split-K + fixed-order reduce for skinny tile counts          */
+    VOX_PATH_ATTN_ENC_MFMA    = 1u << 3,   /* encoder attention on the f32 MFMA                            */
+    VOX_PATH_ATTN_DEC_DPP     = 1u << 4,   /* decoder attention with DPP row reductions                    */
+    VOX_PATH_GEMV3            = 1u << 5,   /* decode GEMVs: k_gemv3 (LDS-DMA activations, ordered queue)   */
+    VOX_PATH_FP8_DECODE       = 1u << 6,   /* fp8 decode weights in use (config 5 only)                    */
+    VOX_PATH_SKINNY_ENC       = 1u << 7,   /* streaming encoder chunks (<= 32 rows) on the weight-streaming kernels */
+};
+#define VOX_PATH_ALL_BF16 (VOX_PATH_GEMM_MFMA_BF16X3 | VOX_PATH_GEMM_MFMA_F32 | VOX_PATH_GEMM_SPLITK | \
+                           VOX_PATH_ATTN_ENC_MFMA | VOX_PATH_ATTN_DEC_DPP | VOX_PATH_GEMV3)
+unsigned vox_hip_active_paths(const vox_hip_engine_t *e);
 
 /* Experiment: seconds per pass over ONE decoder layer's five kernels run back to back (weights
  * stay in the 256 MB Infinity Cache), for comparison with the streamed per-layer time. */

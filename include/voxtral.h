@@ -131,9 +131,16 @@ int   vox_decoder_kv_cache_preallocate(vox_ctx_t *ctx, int max_seq);
 int   vox_encoder_kv_cache_preallocate(vox_ctx_t *ctx, int max_pos);
 
 /* ---- extensions (not in the reference) -------------------------------------------- */
-/* Token ids of every decoder step taken by the stream since init (tests, tooling).
- * Returns the number of ids copied (<= max). */
+/* Opt-in history of the engine's greedy id of every decoder step since init (tests, tooling; off by
+ * default so that a long-running stream holds no growing buffer).  vox_stream_token_ids returns the
+ * number of ids copied (<= max), or the number recorded when out_ids is NULL. */
+void vox_stream_record_ids(vox_stream_t *s, int enable);
 int vox_stream_token_ids(vox_stream_t *s, int *out_ids, int max);
+/* Teacher forcing (parity tests): decoder step i (counted from vox_stream_init) carries ids[i]
+ * forward - as the previous token of step i+1 and for the stream's control flow - instead of the
+ * engine's own argmax, which is still what vox_stream_token_ids / the recorded logits report.
+ * `ids` must stay valid while the stream is used.  Steps beyond n run freely. */
+void vox_stream_force_tokens(vox_stream_t *s, const int *ids, int n);
 /* Record the full logits row of each decoder step (up to max_rows) for parity tests. */
 void vox_stream_record_logits(vox_stream_t *s, int max_rows);
 int  vox_stream_recorded_logits(vox_stream_t *s, const float **rows_out);

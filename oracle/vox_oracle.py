@@ -43,6 +43,8 @@ PRESETS = {
     "tiny": Dims(enc_dim=256, enc_layers=3, enc_heads=4, enc_hidden=512, enc_window=48,
                  dec_dim=384, dec_layers=3, dec_heads=8, dec_kv_heads=2, dec_hidden=768,
                  dec_window=64, vocab=2048),
+    "deep": Dims(enc_dim=256, enc_heads=4, enc_hidden=512, dec_dim=384, dec_heads=8, dec_kv_heads=2,
+                 dec_hidden=768, vocab=8192),
 }
 
 

@@ -27,7 +27,7 @@ def _run(*extra):
 def test_headline_line():
     d = _run()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "decode_tok_s"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "decode_tok_s", "parity", "active_paths"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["higher_is_better"] is False and d["scaling"] == "weak" and d["vs_baseline"] is None

@@ -3,9 +3,10 @@
   * the committed golden fixtures generated from the real reference (tests/golden), and
   * the real reference itself, live, when oracle/_ref travelled to the box, and
   * the numpy oracle for stages that have no exported reference entry point (conv stem).
-Tolerances: logits 1e-3 absolute (north_star), activations 2e-4..1e-3, token ids identical;
-at a token mismatch the reference's own top-2 margin must be below the logit tolerance
-(near-tie) for the test to accept it.
+Tolerances: logits 1e-3 absolute (north_star), activations 2e-4..1e-3, token ids identical.
+A differing token id never ends a comparison: the run is repeated with the reference's ids
+teacher-forced, all remaining steps are compared, and a differing argmax is accepted only
+where the reference's own top-2 margin is below twice the logit tolerance (check_stream).
 """
 import json
 import os
@@ -230,24 +231,83 @@ def test_full_shape_layers_match_live_reference(small, ref_small):
 # ---------------------------------------------------------------------------------------
 # stream level: the voxtral.h API end to end
 # ---------------------------------------------------------------------------------------
-def compare_stream(name, got, g):
+def golden_audio(g):
+    """The case's input: stored in the fixture for the reference's own sample clips (SURVEY 8(d):
+    night1968 / jfk.wav - /root/reference does not exist on the GPU box), regenerated for synthetic ones."""
+    if "audio_i16" in g.files:
+        return g["audio_i16"].astype(np.float32) / 32768.0
+    meta = g["meta"]
+    return synth_speech(float(meta[1]), int(meta[2]))
+
+
+def logit_errors(lg, g, upto):
+    """max |logit - reference| over the reference's top-8 of every step < upto and over the full rows the
+    golden stores on a stride."""
+    out = {}
+    m = min(upto, lg.shape[0], g["top_vals"].shape[0])
+    mine = np.take_along_axis(lg[:m], g["top_ids"][:m], axis=1)
+    out["top8"] = float(np.abs(mine - g["top_vals"][:m]).max()) if m else 0.0
+    rows = 0
+    worst = 0.0
+    if "logits_stride" in g.files:
+        for st, row in zip(g["stride_steps"], g["logits_stride"]):
+            if st < m:
+                worst = max(worst, float(np.abs(lg[st] - row).max()))
+                rows += 1
+    head = g["logits_head"]
+    for i in range(min(len(head), m)):
+        worst = max(worst, float(np.abs(lg[i] - head[i]).max()))
+        rows += 1
+    out["full_rows"] = worst
+    out["n_full_rows"] = rows
+    return out
+
+
+def check_stream(name, g, run):
+    """`run(force_tokens=None)` drives the engine through the voxtral.h stream API with every logits row
+    recorded.  Pass 1 runs freely (the product behaviour): token ids must equal the reference's.  If a
+    step differs, nothing is waved through: pass 2 teacher-forces the reference's ids so that EVERY step
+    is still compared, every logits row must be within tolerance, and each differing argmax must be
+    explained by a reference top-2 margin below twice that tolerance."""
     ref_t = g["tokens"]
-    toks = got["tokens"]
+    got = run()
+    toks = np.asarray(got["tokens"])
     n = min(len(toks), len(ref_t))
     mism = np.nonzero(toks[:n] != ref_t[:n])[0]
     first = int(mism[0]) if len(mism) else None
-    res = dict(steps=len(toks), ref_steps=len(ref_t), first_mismatch=first)
-    lg = got["logits"]
-    upto = n if first is None else first + 1
-    if lg is not None and "top_vals" in g.files:
-        m = min(upto, lg.shape[0], g["top_vals"].shape[0])
-        mine = np.take_along_axis(lg[:m], g["top_ids"][:m], axis=1)
-        res["logit_err"] = float(np.abs(mine - g["top_vals"][:m]).max()) if m else 0.0
-    if first is not None:
-        res["ref_margin_at_mismatch"] = float(g["margin"][first])
-    res["pieces_equal"] = (first is None and len(toks) == len(ref_t) and got["pieces"] == list(g["pieces"]))
+    res = dict(steps=int(len(toks)), ref_steps=int(len(ref_t)), first_mismatch=first,
+               n_distinct_ref=int(len(set(ref_t.tolist()))), min_ref_margin=float(g["margin"].min()))
+    res["free"] = logit_errors(got["logits"], g, n if first is None else first + 1)
+    ok = res["free"]["top8"] < LOGIT_TOL and res["free"]["full_rows"] < LOGIT_TOL
+    if first is None:
+        res["pieces_equal"] = got["pieces"] == list(g["pieces"])
+        ok = ok and len(toks) == len(ref_t) and res["pieces_equal"]
+    else:
+        forced = run(force_tokens=ref_t)
+        ft = np.asarray(forced["tokens"])
+        res["forced_steps"] = int(len(ft))
+        res["forced"] = logit_errors(forced["logits"], g, len(ref_t))
+        bad = np.nonzero(ft[:len(ref_t)] != ref_t[:len(ft)])[0]
+        res["argmax_differs_at"] = bad.tolist()
+        res["ref_margin_there"] = g["margin"][bad].tolist()
+        res["pieces_equal"] = forced["pieces"] == list(g["pieces"])
+        ok = ok and len(ft) == len(ref_t) and res["pieces_equal"]
+        ok = ok and res["forced"]["top8"] < LOGIT_TOL and res["forced"]["full_rows"] < LOGIT_TOL
+        ok = ok and bool((g["margin"][bad] < 2 * LOGIT_TOL).all())
+    res["ok"] = bool(ok)
     diag("stream_" + name, **res)
     return res
+
+
+def run_case(model, g, feed=None, interval=None, cont=False, delay_ms=None):
+    audio = golden_audio(g)
+    feeds = None if feed is None else [feed] * (len(audio) // feed + 1)
+    rows = len(g["tokens"]) + 8
+
+    def run(force_tokens=None):
+        return model.transcribe(audio, feed_sizes=feeds, interval=interval, continuous=cont, record_logits=rows,
+                                delay_ms=delay_ms, force_tokens=force_tokens)
+    return run
 
 
 @pytest.mark.parametrize("name,feed,interval,cont", [
@@ -259,18 +319,8 @@ def compare_stream(name, got, g):
 ])
 def test_stream_tiny_matches_reference_golden(tiny, name, feed, interval, cont):
     g = gold(f"stream_{name}.npz")
-    meta = g["meta"]
-    audio = synth_speech(float(meta[1]), int(meta[2]))
-    feeds = None if feed is None else [feed] * (len(audio) // feed + 1)
-    got = tiny.transcribe(audio, feed_sizes=feeds, interval=interval, continuous=cont, record_logits=4096)
-    res = compare_stream(name, got, g)
-    assert res.get("logit_err", 0.0) < LOGIT_TOL, res
-    if res["first_mismatch"] is not None:
-        # only acceptable at a reference near-tie
-        assert res["ref_margin_at_mismatch"] < 2 * LOGIT_TOL, res
-    else:
-        assert res["steps"] == res["ref_steps"], res
-        assert res["pieces_equal"], res
+    res = check_stream(name, g, run_case(tiny, g, feed, interval, cont))
+    assert res["ok"], res
 
 
 @pytest.mark.parametrize("name,preset,feed", [("tiny_delay240", "tiny", None), ("tiny_delay960", "tiny", 16000),
@@ -278,61 +328,55 @@ def test_stream_tiny_matches_reference_golden(tiny, name, feed, interval, cont):
 def test_stream_with_other_delay_matches_reference_golden(tiny, small, name, preset, feed):
     """vox_set_delay: time conditioning (a6, host side), prompt of 1 + 32 + delay tokens, right padding."""
     g = gold(f"stream_{name}.npz")
-    meta = g["meta"]
-    audio = synth_speech(float(meta[1]), int(meta[2]))
-    feeds = None if feed is None else [feed] * (len(audio) // feed + 1)
     m = tiny if preset == "tiny" else small
     try:
-        got = m.transcribe(audio, feed_sizes=feeds, record_logits=4096, delay_ms=int(meta[6]))
+        res = check_stream(name, g, run_case(m, g, feed, delay_ms=int(g["meta"][6])))
     finally:
         m.set_delay(480)
-    res = compare_stream(name, got, g)
-    assert res.get("logit_err", 0.0) < LOGIT_TOL, res
-    if res["first_mismatch"] is not None:
-        assert res["ref_margin_at_mismatch"] < 2 * LOGIT_TOL, res
-    else:
-        assert res["steps"] == res["ref_steps"], res
-        assert res["pieces_equal"], res
+    assert res["ok"], res
 
 
-def test_stream_small_matches_reference_golden(small):
-    g = gold("stream_small_batch.npz")
-    meta = g["meta"]
-    audio = synth_speech(float(meta[1]), int(meta[2]))
-    got = small.transcribe(audio, record_logits=512)
-    res = compare_stream("small_batch", got, g)
-    assert res.get("logit_err", 0.0) < LOGIT_TOL, res
-    assert res["first_mismatch"] is None and res["steps"] == res["ref_steps"], res
+@pytest.mark.parametrize("name", ["small_batch", "small_jfk", "small_long", "small_xlong"])
+def test_stream_small_matches_reference_golden(small, name):
+    """2 + 2 layers at the real per-layer shapes (the 4B decode kernels).  small_jfk = BASELINE config 1's
+    input (samples/jfk.wav); small_long = 95 s (> 1024 decoder positions, encoder window roll-over inside
+    one chunk); small_xlong = 300 s: 3761 decoder steps with the KV growing to 3799 rows, i.e. the
+    long-context split-K attention + merge path at every slice count up to 30."""
+    g = gold(f"stream_{name}.npz")
+    res = check_stream(name, g, run_case(small, g))
+    assert res["ok"], res
 
 
-def test_stream_small_long_context_matches_reference_golden(small):
-    """95 s clip: > 1024 decoder positions, so the decode attention runs with > 8 key slices and
-    the separate combine kernel, and the encoder window (750) rolls over inside one chunk."""
-    g = gold("stream_small_long.npz")
-    meta = g["meta"]
-    audio = synth_speech(float(meta[1]), int(meta[2]))
-    got = small.transcribe(audio, record_logits=2048)
-    res = compare_stream("small_long", got, g)
-    assert res.get("logit_err", 0.0) < LOGIT_TOL, res
-    if res["first_mismatch"] is not None:
-        assert res["ref_margin_at_mismatch"] < 2 * LOGIT_TOL, res
-    else:
-        assert res["steps"] == res["ref_steps"], res
+@pytest.fixture(scope="module")
+def deep(vox):
+    m = vox.Model(model_dir("deep"))
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("name", ["deep_batch", "deep_long"])
+def test_stream_deep_matches_reference_golden(deep, name):
+    """The full depth (32 + 26 layers) and the real windows at the tiny widths: 30 s of the headline
+    input, and 300 s (3761 steps, KV to 3799) - depth x context in one case."""
+    g = gold(f"stream_{name}.npz")
+    res = check_stream(name, g, run_case(deep, g))
+    assert res["ok"], res
 
 
 def test_stream_full_size_matches_reference_golden(vox):
-    """The real 4B geometry (32+26 layers, vocab 131072) on the seeded synthetic checkpoint."""
+    """THE HEADLINE CONFIGURATION: the real 4B geometry (32 + 26 layers, vocabulary 131072) on the seeded
+    synthetic checkpoint, the 30 s input SURVEY 8(d) names (first 480 000 samples of night1968/
+    45s_right_through_the_billboard.wav, stored in the fixture): 386 decoder steps, KV to 424, against the
+    reference's own run (oracle/_ref, tools/make_golden.py --full).  Also: the product's batched decode
+    (all steps enqueued at once, no logits D2H) gives the same ids as the recorded step-by-step run."""
     g = gold("stream_full_batch.npz")
-    meta = g["meta"]
-    audio = synth_speech(float(meta[1]), int(meta[2]))
     with vox.Model(model_dir("full")) as m:
-        got = m.transcribe(audio, record_logits=512)
-    res = compare_stream("full_batch", got, g)
-    assert res.get("logit_err", 0.0) < LOGIT_TOL, res
-    if res["first_mismatch"] is not None:
-        assert res["ref_margin_at_mismatch"] < 2 * LOGIT_TOL, res
-    else:
-        assert res["steps"] == res["ref_steps"], res
+        res = check_stream("full_batch", g, run_case(m, g))
+        plain = m.transcribe(golden_audio(g))
+    assert res["ok"], res
+    assert res["ref_steps"] >= 380 and res["n_distinct_ref"] > 100, res
+    if res["first_mismatch"] is None:
+        assert np.array_equal(np.asarray(plain["tokens"]), g["tokens"])
 
 
 def test_fp8_decode_weights_track_bf16(vox):
@@ -408,43 +452,20 @@ def test_fast_decode_kernels_at_long_context_and_ring_wrap(vox, n_prompt, window
     assert err < LOGIT_TOL, err
 
 
-def test_overlapped_decode_chain_matches_plain_launches(vox):
-    """Opt-in experiment (VOX_HIP_PDL=1): decode kernels alternate between two CU-masked streams
-    and wait in-kernel for their predecessor.  Same kernels, same arithmetic: tokens must equal
-    those of plain in-order launches."""
-    audio = synth_speech(12.0, 77)
-    os.environ["VOX_HIP_PDL"] = "1"
+def test_production_kernels_are_the_ones_running(vox, small):
+    """No silent downgrade: on gfx950 every production kernel family must be live (vox_hip_active_paths).
+    A start-up self-test failure makes vox_load fail; the A/B switches show up as cleared bits."""
+    mask, names = small.active_paths()
+    diag("active_paths", mask=int(mask), names=names)
+    assert mask == vox.PATH_ALL_BF16, names
+    os.environ["VOX_HIP_NO_BF16X3"] = "1"
     try:
-        with vox.Model(model_dir("full")) as m:
-            path = vox.hip.vox_hip_decode_path(m.engine)
-            b = m.transcribe(audio)
+        with vox.Model(model_dir("tiny"), enc_window=48, dec_window=64) as m:
+            mk, _ = m.active_paths()
     finally:
-        del os.environ["VOX_HIP_PDL"]
-    with vox.Model(model_dir("full")) as m2:
-        assert vox.hip.vox_hip_decode_path(m2.engine) == 0
-        c = m2.transcribe(audio)
-    assert path == 1, "overlapped chain not active on this device"
-    assert len(c["tokens"]) > 100 and np.array_equal(np.asarray(b["tokens"]), np.asarray(c["tokens"]))
-
-
-def test_persistent_decode_kernel_matches_multi_launch_path(vox):
-    """vox_persist.h (one cooperative launch for the whole greedy loop) against the per-GEMV
-    launch path on the full-size model: same token ids, logits equal to float rounding."""
-    audio = synth_speech(10.0, 55)
-    os.environ["VOX_HIP_PERSIST"] = "1"       # opt-in experiment (slower than the launch path, see DESIGN.md)
-    try:
-        with vox.Model(model_dir("full")) as m:
-            a = m.transcribe(audio, record_logits=256)
-            b = m.transcribe(audio)               # no logits recording: one launch for all steps
-    finally:
-        del os.environ["VOX_HIP_PERSIST"]
-    with vox.Model(model_dir("full")) as m2:
-        c = m2.transcribe(audio, record_logits=256)
-    diag("persist_vs_launch", steps=int(len(a["tokens"])), max_logit_diff=float(np.abs(a["logits"] - c["logits"]).max()),
-         equal_tokens=bool(np.array_equal(a["tokens"], c["tokens"])))
-    assert len(a["tokens"]) > 100
-    assert np.array_equal(a["tokens"], c["tokens"]) and np.array_equal(b["tokens"], c["tokens"])
-    assert np.abs(a["logits"] - c["logits"]).max() < 1e-4
+        del os.environ["VOX_HIP_NO_BF16X3"]
+    assert not (mk & vox.PATHS["gemm_mfma_bf16x3"]) and (mk & vox.PATHS["gemm_mfma_f32"])
+    assert not (mk & vox.PATHS["gemv3"])          # tiny geometry: the generic GEMV, reported as such
 
 
 def test_batch_and_streaming_feeds_agree(tiny):

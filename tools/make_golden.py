@@ -9,7 +9,13 @@ audio (tests/audio_util.py) and stores, per case:
   pieces      the strings vox_stream_get surfaced
   top_ids/top_vals   the 8 largest logits of every step
   logits_head full logits rows for the first 4 steps
+  logits_stride / stride_steps   full logits rows of every 16th step (32nd at vocabulary 131072; at most 64 rows): the whole row, not only the top-8
   margin      top1-top2 logit gap per step (how fragile the argmax is)
+  n_distinct / margin_hist   distinct greedy ids and a histogram of the margins (edges in margin_edges):
+              says how much "identical token ids" means on this checkpoint
+  audio_i16   the input itself for the cases that run on the reference's own sample clips
+              (30 s = first 480 000 samples of night1968/45s_right_through_the_billboard.wav,
+              config 1 = samples/jfk.wav); /root/reference does not exist on the GPU box
   mel_sha/adapter checks are covered by stage-level goldens (stage_*.npz)
 The fixtures are small (a few hundred kB) and committed; the generator is committed so they
 can be re-derived.  usage: python tools/make_golden.py [--full]
@@ -44,20 +50,62 @@ CASES = [
     ("tiny_delay240", "tiny", 10.0, 8, None, None, False, 240),
     ("tiny_delay960", "tiny", 10.0, 8, "1s", None, False, 960),
     ("small_delay160", "small", 8.0, 4, None, None, False, 160),
+    # BASELINE config 1 input (samples/jfk.wav, 11 s) at the real per-layer shapes
+    ("small_jfk", "small", 0, 0, None, None, False, None, "jfk.wav"),
+    # the headline input (30 s of night1968) through the full depth at the tiny widths, and 300 s of
+    # synthetic audio through it: 3761 decoder steps, KV to 3799
+    ("deep_batch", "deep", 30.0, 0, None, None, False, None, "benchmark/night1968/45s_right_through_the_billboard.wav"),
+    ("deep_long", "deep", 300.0, 11, None, None, False),
+    # 300 s at the real per-layer shapes: decode attention with KV to 3799 (many key slices)
+    ("small_xlong", "small", 300.0, 12, None, None, False),
 ]
+# the headline configuration itself: 32 + 26 layers, vocabulary 131072, the 30 s night1968 input
+FULL_CASES = [
+    ("full_batch", "full", 30.0, 0, None, None, False, None, "benchmark/night1968/45s_right_through_the_billboard.wav"),
+]
+
+
+MARGIN_EDGES = np.array([0, 1e-4, 3e-4, 1e-3, 3e-3, 1e-2, 3e-2, 1e-1, 3e-1, 1, 1e9], np.float64)
+STRIDE = 16
 
 
 def summarise(r, vocab):
     lg = r["logits"]
     out = dict(tokens=r["tokens"].astype(np.int32), pieces=np.array(r["pieces"], dtype=object))
+    out["n_distinct"] = np.int32(len(set(r["tokens"].tolist())))
     if lg is not None and len(lg):
-        order = np.argsort(-lg, axis=1)[:, :8]
+        part = np.argpartition(-lg, 8, axis=1)[:, :8]
+        pv = np.take_along_axis(lg, part, axis=1)
+        o2 = np.argsort(-pv, axis=1, kind="stable")
+        order = np.take_along_axis(part, o2, axis=1)
         out["top_ids"] = order.astype(np.int32)
         out["top_vals"] = np.take_along_axis(lg, order, axis=1).astype(np.float32)
-        out["logits_head"] = lg[:4].astype(np.float32)
-        srt = np.sort(lg, axis=1)
-        out["margin"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)
+        out["logits_head"] = lg[:(1 if vocab > 65536 else 4)].astype(np.float32)
+        stride = 32 if vocab > 65536 else max(STRIDE, -(-len(lg) // 64))     # keeps the fixture at a few MB
+        steps = np.arange(0, len(lg), stride)
+        out["stride_steps"] = steps.astype(np.int32)
+        out["logits_stride"] = lg[steps].astype(np.float32)
+        out["margin"] = (out["top_vals"][:, 0] - out["top_vals"][:, 1]).astype(np.float32)
+        out["margin_edges"] = MARGIN_EDGES
+        out["margin_hist"] = np.histogram(out["margin"], bins=MARGIN_EDGES)[0].astype(np.int32)
     return out
+
+
+REF_SAMPLES = "/root/reference/samples"
+
+
+def case_audio(R, spec, secs, aseed):
+    """(samples f32, int16 copy or None).  spec None = synthetic; otherwise a path under the reference's samples/."""
+    if spec is None:
+        return synth_speech(secs, aseed), None
+    a = R.load_wav(os.path.join(REF_SAMPLES, spec))          # the reference's own WAV loader (s16 / 32768)
+    if a is None:
+        raise RuntimeError("cannot load " + spec)
+    if secs:
+        a = a[:int(secs * 16000)]
+    i16 = np.round(a * 32768.0).astype(np.int16)
+    assert np.array_equal(i16.astype(np.float32) / 32768.0, a)
+    return a, i16
 
 
 def feeds_for(spec, n):
@@ -77,17 +125,18 @@ def main():
     libs = {}
     cases = list(CASES)
     if args.full:
-        cases.append(("full_batch", "full", 6.0, 5, None, None, False))
+        cases += FULL_CASES
     for case in cases:
         name, preset, secs, aseed, feed, interval, cont = case[:7]
         delay_ms = case[7] if len(case) > 7 else None
+        wav = case[8] if len(case) > 8 else None
         if args.only and args.only != name:
             continue
         if preset not in libs:
             libs[preset] = RefLib(preset)
         R = libs[preset]
         d = vo.PRESETS[preset]
-        audio = synth_speech(secs, aseed)
+        audio, audio_i16 = case_audio(R, wav, secs, aseed)
         ctx = R.load(model_dir(preset))
         r = R.transcribe_stream(ctx, audio, feed_sizes=feeds_for(feed, len(audio)), interval=interval,
                                 continuous=cont, vocab=d.vocab, max_logit_rows=4096 if preset != "full" else 512,
@@ -95,11 +144,14 @@ def main():
         R.free(ctx)
         out = summarise(r, d.vocab)
         out["meta"] = np.array([preset, str(secs), str(aseed), str(feed), str(interval), str(int(cont)),
-                                str(delay_ms if delay_ms is not None else 480)], dtype=object)
+                                str(delay_ms if delay_ms is not None else 480), str(wav)], dtype=object)
+        if audio_i16 is not None:
+            out["audio_i16"] = audio_i16
         np.savez_compressed(os.path.join(GOLD, f"stream_{name}.npz"), **out)
         mg = out.get("margin")
-        print(f"{name}: {len(out['tokens'])} steps, {len(set(out['tokens'].tolist()))} distinct tokens, "
-              f"{len(out['pieces'])} pieces, min margin {mg.min() if mg is not None else None}")
+        print(f"{name}: {len(out['tokens'])} steps, {int(out['n_distinct'])} distinct tokens, "
+              f"{len(out['pieces'])} pieces, min margin {mg.min() if mg is not None else None}, "
+              f"margin hist {out['margin_hist'].tolist() if mg is not None else None}", flush=True)
 
     # ---- stage-level goldens on the tiny model (reference functions called directly) ----
     if not args.only or args.only == "stage":

@@ -33,6 +33,9 @@ typedef struct {
 static const dims_t PRESET_FULL  = {1280, 32, 32, 64, 5120, 3072, 26, 32, 8, 128, 9216, 131072, 32, 128};
 static const dims_t PRESET_SMALL = {1280,  2, 32, 64, 5120, 3072,  2, 32, 8, 128, 9216,   4096, 32, 128};
 static const dims_t PRESET_TINY  = { 256,  3,  4, 64,  512,  384,  3,  8, 2, 128,  768,   2048, 32, 128};
+/* "deep": the full model's depth (32 + 26 layers) at the tiny model's width, with the real attention
+ * windows: depth x context effects in seconds of CPU time (oracle/Makefile builds the matching reference). */
+static const dims_t PRESET_DEEP  = { 256, 32,  4, 64,  512,  384, 26,  8, 2, 128,  768,   8192, 32, 128};
 
 typedef struct {
     char name[200];
@@ -108,12 +111,13 @@ static void b64(const unsigned char *in, int n, char *out) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s <out_dir> <full|small|tiny> [seed]\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <out_dir> <full|small|tiny|deep> [seed]\n", argv[0]); return 2; }
     const char *out_dir = argv[1];
     dims_t d;
     if (!strcmp(argv[2], "full")) d = PRESET_FULL;
     else if (!strcmp(argv[2], "small")) d = PRESET_SMALL;
     else if (!strcmp(argv[2], "tiny")) d = PRESET_TINY;
+    else if (!strcmp(argv[2], "deep")) d = PRESET_DEEP;
     else { fprintf(stderr, "unknown preset %s\n", argv[2]); return 2; }
     uint64_t seed = argc > 3 ? strtoull(argv[3], NULL, 10) : 1234;
 
@@ -122,6 +126,23 @@ int main(int argc, char **argv) {
     int eq = d.enc_heads * d.enc_head_dim;
     int dq = d.dec_heads * d.dec_head_dim, dkv = d.dec_kv_heads * d.dec_head_dim;
 #define STD(fan) (1.0f / sqrtf((float)(fan)))
+    /* Residual-branch gains and attention sharpness.  With unit gains a 32 + 26 layer random-init
+     * stack collapses: near-uniform attention adds the same mean-V vector to every position in every
+     * layer, the per-position signal drowns, and the greedy stream degenerates to one or two ids
+     * (round-1 checkpoint: 2 distinct tokens in 61 steps), which makes token-id parity vacuous.
+     * A smaller attention output projection (x0.3) keeps the per-position signal alive through the
+     * depth and 4x larger query weights make the softmax peaky, so attention transports position-
+     * specific content; the position-wise FFN branch keeps unit gain.  Measured with the reference
+     * (oracle/_ref) on the 30 s night1968 clip at the "deep" geometry: 356 distinct ids in 386 steps
+     * (5 with unit gains); the distinct count and the margin histogram of every golden are stored in
+     * the fixture (tools/make_golden.py).
+     * Overridable through the environment for tuning only (tests and goldens use the defaults). */
+    const float enc_gain = getenv("SYNTH_ENC_GAIN") ? (float)atof(getenv("SYNTH_ENC_GAIN")) : 1.0f;
+    const float dec_gain = getenv("SYNTH_DEC_GAIN") ? (float)atof(getenv("SYNTH_DEC_GAIN")) : 1.0f;
+    const float enc_wo = getenv("SYNTH_ENC_WO") ? (float)atof(getenv("SYNTH_ENC_WO")) : 0.3f;
+    const float dec_wo = getenv("SYNTH_DEC_WO") ? (float)atof(getenv("SYNTH_DEC_WO")) : 0.3f;
+    const float enc_qk = getenv("SYNTH_ENC_QK") ? (float)atof(getenv("SYNTH_ENC_QK")) : 4.0f;
+    const float dec_qk = getenv("SYNTH_DEC_QK") ? (float)atof(getenv("SYNTH_DEC_QK")) : 4.0f;
     /* tok_embeddings: logits std ~3 (realistic range); adapter output is scaled to a
      * comparable norm below so that the previous-token feedback visibly steers the
      * greedy sequence (a constant-token sequence would make id parity vacuous). */
@@ -132,16 +153,16 @@ int main(int argc, char **argv) {
     snprintf(nm, sizeof nm, "%s.conv_layers.1.conv.bias", EP);   add(nm, 3, 0.02f, 1, d.enc_dim, 0, 0);
     for (int i = 0; i < d.enc_layers; i++) {
 #define EN(sfx) snprintf(nm, sizeof nm, "%s.transformer.layers.%d." sfx, EP, i)
-        EN("attention.wq.weight"); add(nm, 0, STD(d.enc_dim), 2, eq, d.enc_dim, 0);
+        EN("attention.wq.weight"); add(nm, 0, enc_qk * STD(d.enc_dim), 2, eq, d.enc_dim, 0);
         EN("attention.wq.bias");   add(nm, 2, 0.02f, 1, eq, 0, 0);
         EN("attention.wk.weight"); add(nm, 0, STD(d.enc_dim), 2, eq, d.enc_dim, 0);
         EN("attention.wv.weight"); add(nm, 0, STD(d.enc_dim), 2, eq, d.enc_dim, 0);
         EN("attention.wv.bias");   add(nm, 2, 0.02f, 1, eq, 0, 0);
-        EN("attention.wo.weight"); add(nm, 0, STD(eq), 2, d.enc_dim, eq, 0);
+        EN("attention.wo.weight"); add(nm, 0, enc_wo * STD(eq), 2, d.enc_dim, eq, 0);
         EN("attention.wo.bias");   add(nm, 2, 0.02f, 1, d.enc_dim, 0, 0);
         EN("attention_norm.weight"); add(nm, 1, 0, 1, d.enc_dim, 0, 0);
         EN("feed_forward.w1.weight"); add(nm, 0, STD(d.enc_dim), 2, d.enc_hidden, d.enc_dim, 0);
-        EN("feed_forward.w2.weight"); add(nm, 0, STD(d.enc_hidden), 2, d.enc_dim, d.enc_hidden, 0);
+        EN("feed_forward.w2.weight"); add(nm, 0, enc_gain * STD(d.enc_hidden), 2, d.enc_dim, d.enc_hidden, 0);
         EN("feed_forward.w2.bias");   add(nm, 2, 0.02f, 1, d.enc_dim, 0, 0);
         EN("feed_forward.w3.weight"); add(nm, 0, STD(d.enc_dim), 2, d.enc_hidden, d.enc_dim, 0);
         EN("ffn_norm.weight");        add(nm, 1, 0, 1, d.enc_dim, 0, 0);
@@ -153,13 +174,13 @@ int main(int argc, char **argv) {
 #define DN(sfx) snprintf(nm, sizeof nm, "layers.%d." sfx, i)
         DN("ada_rms_norm_t_cond.0.weight"); add(nm, 0, STD(d.dec_dim), 2, d.ada_dim, d.dec_dim, 0);
         DN("ada_rms_norm_t_cond.2.weight"); add(nm, 0, 0.1f * STD(d.ada_dim), 2, d.dec_dim, d.ada_dim, 0);
-        DN("attention.wq.weight"); add(nm, 0, STD(d.dec_dim), 2, dq, d.dec_dim, 0);
+        DN("attention.wq.weight"); add(nm, 0, dec_qk * STD(d.dec_dim), 2, dq, d.dec_dim, 0);
         DN("attention.wk.weight"); add(nm, 0, STD(d.dec_dim), 2, dkv, d.dec_dim, 0);
         DN("attention.wv.weight"); add(nm, 0, STD(d.dec_dim), 2, dkv, d.dec_dim, 0);
-        DN("attention.wo.weight"); add(nm, 0, STD(dq), 2, d.dec_dim, dq, 0);
+        DN("attention.wo.weight"); add(nm, 0, dec_wo * STD(dq), 2, d.dec_dim, dq, 0);
         DN("attention_norm.weight"); add(nm, 1, 0, 1, d.dec_dim, 0, 0);
         DN("feed_forward.w1.weight"); add(nm, 0, STD(d.dec_dim), 2, d.dec_hidden, d.dec_dim, 0);
-        DN("feed_forward.w2.weight"); add(nm, 0, STD(d.dec_hidden), 2, d.dec_dim, d.dec_hidden, 0);
+        DN("feed_forward.w2.weight"); add(nm, 0, dec_gain * STD(d.dec_hidden), 2, d.dec_dim, d.dec_hidden, 0);
         DN("feed_forward.w3.weight"); add(nm, 0, STD(d.dec_dim), 2, d.dec_hidden, d.dec_dim, 0);
         DN("ffn_norm.weight"); add(nm, 1, 0, 1, d.dec_dim, 0, 0);
     }

@@ -55,8 +55,11 @@ def _load_libs():
         raise ImportError(
             f"voxtral_c_amd: {HIP_LIB_PATH} / {LIB_PATH} not built. Run `make -C voxtral_c_amd` "
             "(or __graft_entry__.build()). There is no CPU fallback.")
-    hip = C.CDLL(HIP_LIB_PATH, mode=C.RTLD_GLOBAL)
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    # RTLD_LOCAL: libvoxtral.so finds libvoxhip.so through its own DT_NEEDED + rpath, and the
+    # reference-named symbols it exports (vox_linear_bf16, vox_mel_feed, ...) must never interpose
+    # on another library in the process that defines the same names (the test oracle oracle/_ref).
+    hip = C.CDLL(HIP_LIB_PATH, mode=C.RTLD_LOCAL)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
     return hip, lib
 
 
@@ -81,6 +84,8 @@ lib.vox_stream_get_alt.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C
 lib.vox_set_processing_interval.argtypes = [C.c_void_p, C.c_float]
 lib.vox_stream_set_continuous.argtypes = [C.c_void_p, C.c_int]
 lib.vox_stream_token_ids.argtypes = [C.c_void_p, i32p, C.c_int]
+lib.vox_stream_record_ids.argtypes = [C.c_void_p, C.c_int]
+lib.vox_stream_force_tokens.argtypes = [C.c_void_p, i32p, C.c_int]
 lib.vox_stream_record_logits.argtypes = [C.c_void_p, C.c_int]
 lib.vox_stream_recorded_logits.argtypes = [C.c_void_p, C.POINTER(f32p)]
 lib.vox_transcribe_audio.restype = C.c_void_p
@@ -109,14 +114,15 @@ hip.vox_hip_linear_bf16.argtypes = [C.c_void_p, f32p, f32p, u16p, f32p, C.c_int,
 hip.vox_hip_causal_attention.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p] + [C.c_int] * 5 + \
     [C.c_float, C.c_int, C.c_int]
 hip.vox_hip_conv_stem.argtypes = [C.c_void_p, f32p, C.c_int, f32p, C.c_int]
+hip.vox_hip_conv_stem_pad_odd.argtypes = [C.c_void_p, f32p]
 hip.vox_hip_reset_encoder.argtypes = [C.c_void_p]
 hip.vox_hip_reset_decoder.argtypes = [C.c_void_p]
 hip.vox_hip_time_decoder_step.restype = C.c_double
 hip.vox_hip_time_decoder_step.argtypes = [C.c_void_p, C.c_int, C.c_int]
 hip.vox_hip_weight_format.restype = C.c_int
 hip.vox_hip_weight_format.argtypes = [C.c_void_p]
-hip.vox_hip_decode_path.restype = C.c_int
-hip.vox_hip_decode_path.argtypes = [C.c_void_p]
+hip.vox_hip_active_paths.restype = C.c_uint
+hip.vox_hip_active_paths.argtypes = [C.c_void_p]
 hip.vox_hip_sync.argtypes = [C.c_void_p]
 hip.vox_hip_get_timing.argtypes = [C.c_void_p, C.POINTER(_Timing)]
 hip.vox_hip_reset_timing.argtypes = [C.c_void_p]
@@ -138,6 +144,12 @@ _libc.free.argtypes = [C.c_void_p]
 
 def _fp(a):
     return a.ctypes.data_as(f32p)
+
+
+# vox_hip.h enum vox_hip_path
+PATHS = {"gemm_mfma_bf16x3": 1 << 0, "gemm_mfma_f32": 1 << 1, "gemm_splitk": 1 << 2, "attn_enc_mfma": 1 << 3,
+         "attn_dec_dpp": 1 << 4, "gemv3": 1 << 5, "fp8_decode": 1 << 6, "skinny_enc": 1 << 7}
+PATH_ALL_BF16 = sum(v for k, v in PATHS.items() if k not in ("fp8_decode", "skinny_enc"))
 
 
 def device_count():
@@ -187,6 +199,11 @@ class Model:
 
     def set_delay(self, delay_ms):
         lib.vox_set_delay(self._ctx, int(delay_ms))
+
+    def active_paths(self):
+        """vox_hip_active_paths as (mask, [names]): which production kernel families are live."""
+        m = hip.vox_hip_active_paths(self.engine)
+        return m, [k for k, v in PATHS.items() if m & v]
 
     def memory_used(self):
         return hip.vox_hip_memory_used(self.engine)
@@ -291,8 +308,10 @@ class Model:
         return Stream(self, **kw)
 
     def transcribe(self, samples, feed_sizes=None, interval=None, continuous=False, record_logits=0,
-                   delay_ms=None, n_alt=1, alt_cutoff=0.0):
-        """Drive the stream API like the reference CLI does. Returns dict(tokens, pieces, logits)."""
+                   delay_ms=None, n_alt=1, alt_cutoff=0.0, force_tokens=None):
+        """Drive the stream API like the reference CLI does. Returns dict(tokens, pieces, logits).
+        force_tokens: teacher forcing (vox_stream_force_tokens) - `tokens` is then the engine's own
+        argmax at every step given the forced history."""
         if delay_ms is not None:
             self.set_delay(delay_ms)
         s = Stream(self)
@@ -305,6 +324,8 @@ class Model:
                 s.record_logits(record_logits)
             if n_alt > 1:
                 s.set_alt(n_alt, alt_cutoff)
+            if force_tokens is not None:
+                s.force_tokens(force_tokens)
             x = np.ascontiguousarray(samples, np.float32)
             pieces = []
             if feed_sizes is None:
@@ -332,6 +353,8 @@ class Stream:
         self._s = lib.vox_stream_init(model._ctx)
         if not self._s:
             raise VoxError("vox_stream_init failed")
+        lib.vox_stream_record_ids(self._s, 1)
+        self._forced = None
 
     def feed(self, samples):
         x = np.ascontiguousarray(samples, np.float32)
@@ -376,6 +399,10 @@ class Stream:
 
     def record_logits(self, max_rows):
         lib.vox_stream_record_logits(self._s, int(max_rows))
+
+    def force_tokens(self, ids):
+        self._forced = np.ascontiguousarray(ids, np.int32)          # must outlive the stream's use of it
+        lib.vox_stream_force_tokens(self._s, self._forced.ctypes.data_as(i32p), len(self._forced))
 
     def token_ids(self):
         n = lib.vox_stream_token_ids(self._s, None, 0)

@@ -44,7 +44,6 @@ struct AttnArgs {
     int split_keys;                 // keys per blockIdx.y
     float *part_o, *part_ml;        // [n_q][n_heads][nsplit][HD], [..][2]
     int force_partials;             // write partials even when nsplit == 1 (merged by the Wo GEMV prologue)
-    PdlArgs pdl;                    // overlapped launches (vox_common.h); st must be null then
 };
 
 template <int HD>
@@ -367,10 +366,9 @@ __global__ __launch_bounds__(256) void k_attn_enc_mfma(const AttnArgs a) {
 // ---------------------------------------------------------------------------------
 // Decoder attention.  grid = (n_kv_heads, nsplit, n_q); block = 256 (4 waves).
 // ---------------------------------------------------------------------------------
-template <int HD, int HPK, bool USE_DPP, bool PDL = false>
+template <int HD, int HPK, bool USE_DPP>
 __global__ __launch_bounds__(256) void k_attn_dec(const AttnArgs a, const int nsplit) {
     static_assert(HD == 128, "16 lanes x 8 dims");
-    if constexpr (PDL) pdl_wait(a.pdl);          // q and this position's K/V row come from the predecessor
     __shared__ float sm_m[4][HPK], sm_l[4][HPK];
     __shared__ __attribute__((aligned(16))) float sm_o[4][HPK][HD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -492,7 +490,7 @@ __global__ __launch_bounds__(256) void k_attn_dec(const AttnArgs a, const int ns
             }
             const int head = kvh * HPK + h;
             auto put = [&](float *p, float v) {
-                if constexpr (PDL) pdl_store(p, v); else *p = v;
+                *p = v;
             };
             if (nsplit == 1 && !a.force_partials) {
                 const float inv = ll > 0.f ? 1.0f / ll : 0.f;
@@ -506,7 +504,6 @@ __global__ __launch_bounds__(256) void k_attn_dec(const AttnArgs a, const int ns
             }
         }
     }
-    if constexpr (PDL) pdl_signal(a.pdl);
 }
 
 // Merge split-K partials.  grid = (n_heads, n_q), block = HD threads.

@@ -19,89 +19,6 @@ struct DecState {
     long long adapter_row;  // physical adapter row of this step
 };
 
-// ---------------------------------------------------------------------------------------
-// Overlapped dependent launches ("software PDL").  The decode step is a chain of ~130 short
-// HBM-streaming kernels; each pays ~3 us of ramp-up / drain during which HBM idles.  The chain
-// is therefore issued alternately on two HIP streams whose CU masks split the chip in halves:
-// kernel g+1 starts on its half while kernel g is still running on the other half, issues its
-// weight loads (they depend on nothing), and only then waits for kernel g's completion counter
-// before touching kernel g's output.  Disjoint CU sets matter: a CU's vector-memory path is a
-// FIFO, so on a shared CU the producer's result stores would queue behind the consumer's
-// prefetch (measured: profiles/r01_run3_persistent_*).
-//   producer: payload stores are agent-scope relaxed atomic stores (sc1, write-through), then
-//             s_waitcnt vmcnt(0), then one relaxed agent-scope add per block on its counter;
-//   consumer: thread 0 polls the counter (bounded), agent-scope acquire fence, __syncthreads.
-// Counters grow monotonically; the host passes the cumulative value to wait for (wrap-safe).
-// ---------------------------------------------------------------------------------------
-constexpr int PDL_SLOT_STRIDE = 64;     // counters live 256 B apart (own cache lines); error word at [2 * stride]
-#ifndef PDL_POLL_SLEEP
-#define PDL_POLL_SLEEP 4                // x 64 clocks between polls
-#endif
-
-struct PdlArgs {
-    unsigned *flags;        // completion counters at [slot * PDL_SLOT_STRIDE] (slot = launch parity); null = plain launch
-    unsigned *err;          // set to a non-zero code when a wait times out
-    int wait_slot;          // < 0: nothing to wait for
-    unsigned wait_val;
-    int sig_slot;           // < 0: nothing to signal
-    unsigned long long spin_limit;   // wall_clock64 ticks (100 MHz)
-    unsigned long long *trace;       // optional: 16 timestamps per (kernel, probe block), VOX_HIP_PDL_TRACE
-};
-
-// Timestamp probe for the overlapped chain: thread 0 of the first and the last block of a kernel.
-struct PdlProbe {
-    unsigned long long *p; int n;
-    __device__ __forceinline__ PdlProbe(const PdlArgs &a) : p(nullptr), n(0) {
-        if (a.trace && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && blockIdx.y == 0)
-            p = a.trace + (blockIdx.x == 0 ? 0 : 16);
-    }
-    __device__ __forceinline__ void mark() { if (p && n < 16) p[n++] = wall_clock64(); }
-};
-
-// All threads of the block call this (contains a __syncthreads()).
-__device__ __forceinline__ void pdl_wait(const PdlArgs &p) {
-    if (p.flags && p.wait_slot >= 0) {
-        if (threadIdx.x == 0) {
-            // Every resident block of the consumer polls one word: keep the request rate low (the
-            // word's memory channel also carries 1/N of everybody's weight stream) and touch the
-            // error word only on the slow path.
-            const unsigned *f = p.flags + p.wait_slot * PDL_SLOT_STRIDE;
-            if ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.wait_val) < 0) {
-                const unsigned long long t0 = wall_clock64();
-                unsigned it = 0;
-                for (;;) {
-                    __builtin_amdgcn_s_sleep(PDL_POLL_SLEEP);
-                    if ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.wait_val) >= 0) break;
-                    if ((++it & 63u) == 0u) {
-                        if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // chain already broken
-                        if (wall_clock64() - t0 > p.spin_limit) {
-                            __hip_atomic_store(p.err, 1u + (unsigned)p.wait_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-    }
-}
-// Payload store that is visible to other CUs once vmcnt has drained (write-through).
-__device__ __forceinline__ void pdl_store(float *p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void pdl_store(int *p, int v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// All threads of the block call this after their pdl_store()s (contains a __syncthreads()).
-__device__ __forceinline__ void pdl_signal(const PdlArgs &p) {
-    if (p.flags && p.sig_slot >= 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(p.flags + p.sig_slot * PDL_SLOT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 __device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

@@ -48,21 +48,18 @@ struct GemvArgs {
     float *x_out;              // PRO_EMBED_RMS: residual stream (written by block 0)
     const float *part_o, *part_ml;   // PRO_ATTN: split-K attention partials [heads][nsplit][HD], [..][2]
     int nsplit, attn_hd;
-    PdlArgs pdl;               // overlapped launches (vox_common.h)
     int pos_host;              // k_gemv3 EPI_QKV: logical position of this step (RoPE angle, KV slot)
     const float *wscale, *wscale2;   // fp8 weights (W8): per-row dequantisation scale of W / W2
     int row_base;              // EPI_LOGITS: added to the row index reported in blk_idx (vocabulary halves)
 };
 
-template <int PRO, int EPI, int RPW, bool PDL = false, bool W8 = false>
+template <int PRO, int EPI, int RPW, bool W8 = false>
 __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *xs = smem;                 // [K]
     float *red = smem + a.K;          // [16] scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, N = a.N;
-    if constexpr (PDL) pdl_wait(a.pdl);
-
     // ---- prologue: stage x in LDS, optionally RMS-normalised --------------------
     float ss = 0.f;
     for (int i = tid * 4; i < K; i += 256 * 4) {
@@ -212,11 +209,9 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
             float bv = rv[0]; int bi = ri[0];
             for (int w = 1; w < 4; w++)
                 if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
-            if constexpr (PDL) { pdl_store(a.blk_val + blockIdx.x, bv); pdl_store(a.blk_idx + blockIdx.x, bi); }
-            else { a.blk_val[blockIdx.x] = bv; a.blk_idx[blockIdx.x] = bi; }
+            a.blk_val[blockIdx.x] = bv; a.blk_idx[blockIdx.x] = bi;
         }
     }
-    if constexpr (PDL) pdl_signal(a.pdl);
 }
 
 
@@ -438,11 +433,10 @@ __global__ __launch_bounds__(256) void k_quant_fp8_rows(const uint16_t *W, uint8
 // One block of 256 threads.
 __global__ __launch_bounds__(256) void k_argmax_finish(const float *blk_val, const int *blk_idx, int nblk,
                                                        DecState *st, int *tokens_out, int eos_token,
-                                                       int advance, const PdlArgs pdl) {
+                                                       int advance) {
     __shared__ float sv[256];
     __shared__ int si[256];
     const int tid = threadIdx.x;
-    pdl_wait(pdl);
     float bv = -3.0e38f; int bi = 0x7fffffff;
     for (int i = tid; i < nblk; i += 256) {
         const float v = blk_val[i]; const int ix = blk_idx[i];
@@ -464,19 +458,16 @@ __global__ __launch_bounds__(256) void k_argmax_finish(const float *blk_val, con
         int tok = si[0];
         if (tok < 0 || tok == 0x7fffffff) tok = 0;
         if (!st->stop) {
-            // write-through stores: under overlapped launches the next step's first kernel may
-            // already be resident on the other half of the chip
-            pdl_store(tokens_out + st->n_out, tok);
-            pdl_store(&st->n_out, st->n_out + 1);
-            pdl_store(&st->token, tok);
+            tokens_out[st->n_out] = tok;
+            st->n_out = st->n_out + 1;
+            st->token = tok;
             if (advance) {
-                pdl_store(&st->pos, st->pos + 1);
-                __hip_atomic_store(&st->adapter_row, st->adapter_row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                st->pos = st->pos + 1;
+                st->adapter_row = st->adapter_row + 1;
             }
-            if (tok == eos_token) pdl_store(&st->stop, 1);
+            if (tok == eos_token) st->stop = 1;
         }
     }
-    pdl_signal(pdl);
 }
 
 // Start of a decode step: RoPE row for the current position and (optionally) the
@@ -518,7 +509,7 @@ __global__ __launch_bounds__(256) void k_step_begin(const DecState *st, const fl
 //   5. prologue math in LDS, then the dot products piece by piece as the weights land.
 // K is a template constant (CPL * KS * 512).
 // ---------------------------------------------------------------------------------------
-template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW, bool PDL, bool W8 = false>
+template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW, bool W8 = false>
 __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int EPP = W8 ? 16 : 8;  // weights per 16-byte piece (fp8 e4m3 : bf16)
@@ -623,38 +614,19 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
         }
     };
 
-    PdlProbe probe(a.pdl);
-    if constexpr (!PDL) {
-        // plain launch: everything this kernel reads is final.  Activation side first (it is
-        // needed first and a CU's memory path is in-order), then the weight stream.
-        load_epilogue_operands();
-        load_activation_registers();
-        __builtin_amdgcn_sched_barrier(0);
-        issue_lds_dma();
-        __builtin_amdgcn_sched_barrier(0);
-        issue_weight_loads();
-        __builtin_amdgcn_sched_barrier(0);
-        // the older loads have landed once at most NW (the weights) are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
-    } else {
-        // overlapped launch: the predecessor may still be running.  Its output is the activation
-        // side, so the weight stream goes first and the wait sits between the two.
-        probe.mark();                                   // 0: kernel start
-        load_epilogue_operands();
-        __builtin_amdgcn_sched_barrier(0);
-        issue_weight_loads();
-        __builtin_amdgcn_sched_barrier(0);
-        probe.mark();                                   // 1: weights issued
-        pdl_wait(a.pdl);
-        probe.mark();                                   // 2: predecessor done, acquired
-        load_activation_registers();
-        __builtin_amdgcn_sched_barrier(0);
-        issue_lds_dma();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        probe.mark();                                   // 3: weights + activations landed
-    }
+    // Everything this kernel reads is final (in-order launches).  Activation side first (it is
+    // needed first and a CU's memory path is in-order), then the weight stream.
+    load_epilogue_operands();
+    load_activation_registers();
+    __builtin_amdgcn_sched_barrier(0);
+    issue_lds_dma();
+    __builtin_amdgcn_sched_barrier(0);
+    issue_weight_loads();
+    __builtin_amdgcn_sched_barrier(0);
+    // the older loads have landed once at most NW (the weights) are outstanding
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
 
-    // ---- prologue math (plain launch: under the weight stream) ---------------------------------
+    // ---- prologue math (under the weight stream) ---------------------------------
     if constexpr (PRO == PRO_EMBED_RMS) {
 #pragma unroll
         for (int j = 0; j < NX; j++) {
@@ -733,7 +705,6 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
         }
     }
 
-    if constexpr (PDL) probe.mark();                    // 4: prologue done
     // ---- dot products, in arrival order ----------------------------------------------------------
     float acc[NMAT][RPW];
 #pragma unroll
@@ -788,11 +759,8 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
         }
     }
 
-    if constexpr (PDL) probe.mark();                    // 5: dots + reductions done
-    // ---- epilogue (no loads left).  Overlapped launches publish with write-through stores ------
-    auto put = [&](float *p, float v) {
-        if constexpr (PDL) pdl_store(p, v); else *p = v;
-    };
+    // ---- epilogue (no loads left) ------------------------------------------------------------------
+    auto put = [&](float *p, float v) { *p = v; };
     if (lane == 0 && kp == 0) {
         if constexpr (EPI == EPI_RESID) {
 #pragma unroll
@@ -828,11 +796,6 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
                 }
             }
         }
-    }
-    if constexpr (PDL) {
-        probe.mark();                                   // 6: stores issued
-        pdl_signal(a.pdl);
-        probe.mark();                                   // 7: drained + signalled
     }
 }
 

@@ -25,7 +25,7 @@
 #include "vox_gemm.h"
 #include "vox_misc.h"
 #include "vox_attn.h"
-#include "vox_persist.h"
+#include "vox_kernel_api.h"
 
 using namespace vox;
 
@@ -46,6 +46,15 @@ static void set_err(const char *what, hipError_t e, const char *file, int line) 
         hipError_t _e = (call);                                         \
         if (_e != hipSuccess) { set_err(#call, _e, __FILE__, __LINE__); } \
     } while (0)
+
+// One check per enqueued unit of work (decode step, encoder chunk, prefill): a refused launch
+// (bad grid, LDS request, ...) must surface as an error return, not as a wrong token at the next sync.
+static int launch_check(const char *what, const char *file, int line) {
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { set_err(what, le, file, line); return -1; }
+    return 0;
+}
+#define LAUNCH_CHECK(what) do { if (launch_check(what, __FILE__, __LINE__)) return -1; } while (0)
 
 namespace {
 
@@ -113,29 +122,15 @@ struct vox_hip_engine {
     DecState *d_st = nullptr;
     float *dx = nullptr, *dq = nullptr, *dattn = nullptr, *dh = nullptr, *dlogits = nullptr;
     float *blk_val = nullptr; int *blk_idx = nullptr; int logits_grid = 0;
-    unsigned long long *d_trace = nullptr;
     unsigned skip_kinds = 0;            // timing experiments only: PK_* launches left out of a step
     bool use_fp8 = false;               // decode GEMVs stream the fp8 copies (vox_hip_quantize_decoder_fp8)
     uint8_t *tok_emb8 = nullptr; float *stok = nullptr;
-    // overlapped decode chain
-    bool use_pdl = false, pdl_first = true;
-    hipStream_t pdl_stream[2] = {nullptr, nullptr};
-    hipEvent_t pdl_ev[3] = {nullptr, nullptr, nullptr};
-    unsigned *d_pdl = nullptr;          // completion counters at [0], [STRIDE]; error word at [2*STRIDE]
-    unsigned pdl_g = 0, pdl_cum[2] = {0, 0};
-    int pdl_runs = 0, pdl_failures = 0;
-    unsigned long long *d_pdl_trace = nullptr; bool pdl_trace_on = false; int pdl_trace_k = 0;
     int *d_tokens = nullptr;
     float *dpart_o = nullptr, *dpart_ml = nullptr;   // decode-step split-K partials (max splits)
     int dec_max_split = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     vox_hip_timing_t timing{};
-    // persistent decode kernel (vox_persist.h)
-    bool use_persist = false;
-    PersistLayer *d_players = nullptr;
-    unsigned *d_bar = nullptr;
-    int persist_runs = 0, persist_failures = 0;
     // multi-GPU shard in flight (vox_hip_shard_*)
     float *shard_x = nullptr; int shard_n = 0;
     // per-kernel profiling of the decode step (HIP events between launches)
@@ -209,11 +204,11 @@ static inline int grid1d(size_t work, int per_block = 256, int cap = 4096) {
 // ------------------------------------------------------------------------------------
 static int ensure(vox_hip_engine *e, Buf &b, size_t bytes);
 // mode: 0 = best available, 1 = scalar reference kernel, 2 = f32-input MFMA kernel
-static void launch_gemm(vox_hip_engine *e, const float *X, int ldx, const uint16_t *W, float *Y, int ldy,
-                        int M, int N, int K, const float *bias, const float *resid, int ldr, int act,
-                        int mode = 0) {
+static int launch_gemm(vox_hip_engine *e, const float *X, int ldx, const uint16_t *W, float *Y, int ldy,
+                       int M, int N, int K, const float *bias, const float *resid, int ldr, int act,
+                       int mode = 0) {
     GemmArgs a{X, ldx, W, Y, ldy, M, N, K, bias, resid, ldr, act, 1, 0, nullptr};
-    if (M <= 0 || N <= 0) return;
+    if (M <= 0 || N <= 0) return 0;
     const bool aligned = (K % GB_K == 0) && (ldx % 4 == 0) && ((size_t)X % 16 == 0);
     if (e->use_mfma && aligned && mode != 1) {
         // bf16 matrix pipe (3 exact bf16 terms per f32 activation) when K allows 64-wide slices
@@ -230,7 +225,8 @@ static void launch_gemm(vox_hip_engine *e, const float *X, int ldx, const uint16
             ksplit = std::min(std::min((512 + tm * tn - 1) / (tm * tn), nk / min_slices), 16);
             if (ksplit < 2) ksplit = 1;
         }
-        if (ksplit > 1 && ensure(e, e->ssplitk, (size_t)ksplit * M * N * 4) == 0) {
+        if (ksplit > 1) {
+            if (ensure(e, e->ssplitk, (size_t)ksplit * M * N * 4)) return -1;     // out of HBM: an error, not a silent un-split
             a.ksplit = ksplit; a.kper = (nk + ksplit - 1) / ksplit; a.partial = (float *)e->ssplitk.p;
             a.ksplit = (nk + a.kper - 1) / a.kper;          // drop empty trailing splits
             dim3 grid(tn, tm, a.ksplit);
@@ -245,6 +241,7 @@ static void launch_gemm(vox_hip_engine *e, const float *X, int ldx, const uint16
         dim3 grid((N + 63) / 64, (M + 3) / 4);
         hipLaunchKernelGGL(k_gemm_scalar, grid, dim3(256), 0, e->stream, a);
     }
+    return 0;
 }
 
 static int gemv_grid(int N, int rpb) {
@@ -264,24 +261,24 @@ static void launch_gemv(vox_hip_engine *e, const GemvArgs &a, int grid_override 
 
 // Generic y = x.W^T (+bias) for M rows on device buffers; M == 1 streams the weights with
 // the GEMV kernel, M > 1 uses the MFMA GEMM.
-static void linear_dev(vox_hip_engine *e, float *y, int ldy, const float *x, int ldx, const uint16_t *W,
-                       const float *bias, int M, int K, int N, int act, const float *resid, int ldr,
-                       int impl) {
+static int linear_dev(vox_hip_engine *e, float *y, int ldy, const float *x, int ldx, const uint16_t *W,
+                      const float *bias, int M, int K, int N, int act, const float *resid, int ldr,
+                      int impl) {
     const bool gemv_ok = (K % 8 == 0) && act == ACT_NONE;
     if ((impl == 1 || (impl == 0 && M == 1)) && gemv_ok) {
         for (int m = 0; m < M; m++) {
             GemvArgs a{};
             a.W = W; a.x = x + (size_t)m * ldx; a.y = y + (size_t)m * ldy; a.bias = bias; a.N = N; a.K = K;
             if (resid) {
-                if (resid != y) HCV(hipMemcpyAsync(a.y, resid + (size_t)m * ldr, (size_t)N * 4, hipMemcpyDeviceToDevice, e->stream));
+                if (resid != y) HC(hipMemcpyAsync(a.y, resid + (size_t)m * ldr, (size_t)N * 4, hipMemcpyDeviceToDevice, e->stream));
                 launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
             } else {
                 launch_gemv<PRO_NONE, EPI_STORE, 2>(e, a);
             }
         }
-    } else {
-        launch_gemm(e, x, ldx, W, y, ldy, M, N, K, bias, resid, ldr, act, impl == 3);
+        return 0;
     }
+    return launch_gemm(e, x, ldx, W, y, ldy, M, N, K, bias, resid, ldr, act, impl == 3);
 }
 
 // ------------------------------------------------------------------------------------
@@ -417,54 +414,6 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
     e->adapter_cap = 4096;
     if (dalloc(e, &e->adapter, (size_t)e->adapter_cap * DD)) return fail();
 
-    // persistent decode kernel: only for the exact 4B decoder geometry on a 256-CU part
-    {
-        hipDeviceProp_t prop;
-        int coop = 0;
-        hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device);
-        const bool geom = d.dec_dim == pk::D && e->dec_qd == pk::DQ && e->dec_kvd == pk::DKV && d.dec_hidden == pk::DH &&
-                          d.dec_head_dim == pk::HD && d.vocab == pk::VOCAB && d.dec_window <= 8192;
-        // Measured on MI355X (profiles/r01_run3_persistent_*): 4.4 ms/token vs 1.87 ms for the
-        // multi-launch path — every control-plane access (result stores, release, arrive, poll,
-        // acquire, activation staging) queues behind the CU's own in-flight weight stream, so a
-        // phase costs ~6 queue drains.  Kept as an opt-in experiment (VOX_HIP_PERSIST=1).
-        if (geom && coop && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount == pk::NB &&
-            getenv("VOX_HIP_PERSIST") && !getenv("VOX_HIP_NO_PERSIST")) {
-            std::vector<PersistLayer> pl(d.dec_layers);
-            for (int l = 0; l < d.dec_layers; l++) {
-                DecLayer &L = e->dec[l];
-                pl[l] = PersistLayer{L.wqkv, L.wo, L.w13, L.w2, L.n1, L.n2, L.ada, L.kring, L.vring};
-            }
-            if (dalloc(e, &e->d_players, pl.size()) == 0 && dalloc(e, &e->d_bar, 16) == 0 &&
-                hipMemcpy(e->d_players, pl.data(), pl.size() * sizeof(PersistLayer), hipMemcpyHostToDevice) == hipSuccess &&
-                hipFuncSetAttribute((const void *)k_decode_persist, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    pk::LDS_FLOATS * 4) == hipSuccess)
-                e->use_persist = true;
-        }
-    }
-
-    // overlapped decode chain: two streams, each restricted to one half of the CUs.
-    // Measured on MI355X (profiles/r01_pdl_*): correct, kernels do overlap, but a software hand-off
-    // (poll + acquire + activation fetch + write-through publish + counter add) costs 9-10 us per
-    // kernel with 2 blocks/CU and ~19 us with 4 blocks/CU, against ~4.5 us of boundary + ramp for
-    // plain in-order launches: 3.3-3.6 ms/token vs 1.62.  Opt-in experiment (VOX_HIP_PDL=1).
-    {
-        hipDeviceProp_t prop;
-        const bool geom = d.dec_dim == 3072 && e->dec_qd == 4096 && e->dec_kvd == 1024 && d.dec_hidden == 9216 &&
-                          d.dec_head_dim == 128 && d.vocab % 32768 == 0;
-        if (geom && getenv("VOX_HIP_PDL") && !getenv("VOX_HIP_NO_PDL") && hipGetDeviceProperties(&prop, device) == hipSuccess &&
-            prop.multiProcessorCount == 256) {
-            uint32_t lo[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0, 0};
-            uint32_t hi[8] = {0, 0, 0, 0, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-            bool ok = hipExtStreamCreateWithCUMask(&e->pdl_stream[0], 8, lo) == hipSuccess &&
-                      hipExtStreamCreateWithCUMask(&e->pdl_stream[1], 8, hi) == hipSuccess;
-            for (int i = 0; i < 3 && ok; i++) ok = hipEventCreateWithFlags(&e->pdl_ev[i], hipEventDisableTiming) == hipSuccess;
-            ok = ok && dalloc(e, &e->d_pdl, 3 * PDL_SLOT_STRIDE) == 0 && hipMemset(e->d_pdl, 0, 3 * PDL_SLOT_STRIDE * 4) == hipSuccess;
-            if (ok) e->use_pdl = true;
-            else { (void)hipGetLastError(); fprintf(stderr, "vox_hip: CU-masked streams unavailable; plain decode launches\n"); }
-        }
-    }
-
     // state-carrying stream buffers (zero = "start of sequence" left padding)
     if (ensure_keep(e, e->conv_in0, (size_t)(2 + 1024) * d.mel_bins * 4, 0)) return fail();
     if (ensure_keep(e, e->conv_in1, (size_t)(2 + 1024) * ED * 4, 0)) return fail();
@@ -489,14 +438,12 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     F(e->tok_emb8); F(e->stok);
     F(e->hann); F(e->cosT); F(e->sinT); F(e->filtT); F(e->enc_inv_freq); F(e->dec_inv_freq); F(e->dec_rope);
     F(e->d_st); F(e->dx); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
-    F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_players); F(e->d_bar); F(e->d_pdl);
+    F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter);
     Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
                    &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml, &e->ssplitk};
     for (Buf *b : bufs) F(b->p);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
-    for (int i = 0; i < 3; i++) if (e->pdl_ev[i]) hipEventDestroy(e->pdl_ev[i]);
-    for (int i = 0; i < 2; i++) if (e->pdl_stream[i]) hipStreamDestroy(e->pdl_stream[i]);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -629,7 +576,7 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
     // 1. attention_norm
     hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, s, xn, c.D, x, c.D, n1, (const float *)nullptr, c.D, c.eps);
     // 2. merged QKV projection (+ q/v bias on the encoder, voxtral_encoder.c:542-544)
-    launch_gemm(e, xn, c.D, wqkv, qkv, N3, n, N3, c.D, bqkv, nullptr, 0, ACT_NONE);
+    if (launch_gemm(e, xn, c.D, wqkv, qkv, N3, n, N3, c.D, bqkv, nullptr, 0, ACT_NONE)) return -1;
     // 3. RoPE on q and k columns (table built once per chunk by the caller)
     hipLaunchKernelGGL(k_rope_apply, dim3(grid1d((size_t)n * (c.QD + c.KVD) / 2)), dim3(256), 0, s,
                        qkv, N3, n, c.QD + c.KVD, c.hd, tab);
@@ -688,13 +635,13 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
                                (const float *)a.part_o, (const float *)a.part_ml, c.heads, nsplit);
     }
     // 5. x += attn.Wo^T (+bo)
-    launch_gemm(e, attn, c.QD, wo, x, c.D, n, c.D, c.QD, bo, x, c.D, ACT_NONE);
+    if (launch_gemm(e, attn, c.QD, wo, x, c.D, n, c.D, c.QD, bo, x, c.D, ACT_NONE)) return -1;
     // 6. ffn_norm (+ ada scaling on the decoder)
     hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, s, xn, c.D, x, c.D, n2, ada, c.D, c.eps);
     // 7. SwiGLU: merged W1;W3 GEMM, gate, W2 (+b2) + residual
-    launch_gemm(e, xn, c.D, w13, gu, 2 * c.H, n, 2 * c.H, c.D, nullptr, nullptr, 0, ACT_NONE);
+    if (launch_gemm(e, xn, c.D, w13, gu, 2 * c.H, n, 2 * c.H, c.D, nullptr, nullptr, 0, ACT_NONE)) return -1;
     hipLaunchKernelGGL(k_silu_mul, dim3(grid1d((size_t)n * c.H / 4)), dim3(256), 0, s, h, gu, n, c.H);
-    launch_gemm(e, h, c.H, w2, x, c.D, n, c.D, c.H, b2, x, c.D, ACT_NONE);
+    if (launch_gemm(e, h, c.H, w2, x, c.D, n, c.D, c.H, b2, x, c.D, ACT_NONE)) return -1;
     return 0;
 }
 
@@ -723,6 +670,7 @@ static int encoder_rows_dev(vox_hip_engine *e, float *x, int n, float *out) {
     hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, e->stream, out, c.D, x, c.D, e->enc_final_norm,
                        (const float *)nullptr, c.D, c.eps);
     e->enc_pos += n;
+    LAUNCH_CHECK("encoder chunk launches");
     return 0;
 }
 
@@ -731,8 +679,9 @@ static int adapter_dev(vox_hip_engine *e, const float *in, int m, float *out) {
     const int DD = e->d.dec_dim, K0 = e->d.enc_dim * 4;
     if (ensure(e, e->smid, (size_t)m * DD * 4)) return -1;
     float *mid = (float *)e->smid.p;
-    launch_gemm(e, in, K0, e->adapter0, mid, DD, m, DD, K0, nullptr, nullptr, 0, ACT_GELU);
-    launch_gemm(e, mid, DD, e->adapter1, out, DD, m, DD, DD, nullptr, nullptr, 0, ACT_NONE);
+    if (launch_gemm(e, in, K0, e->adapter0, mid, DD, m, DD, K0, nullptr, nullptr, 0, ACT_GELU)) return -1;
+    if (launch_gemm(e, mid, DD, e->adapter1, out, DD, m, DD, DD, nullptr, nullptr, 0, ACT_NONE)) return -1;
+    LAUNCH_CHECK("adapter launches");
     return 0;
 }
 
@@ -787,7 +736,7 @@ static int conv_stem_dev(vox_hip_engine *e, int n, float **xout) {
     float *col = (float *)e->sim2col.p;
     hipLaunchKernelGGL(k_im2col3, dim3(grid1d((size_t)n * MB * 3)), dim3(256), 0, s, col, (const float *)in0, n, MB, 1);
     float *c0_new = in1 + (size_t)(1 + e->c0_carry) * ED;
-    launch_gemm(e, col, MB * 3, e->conv0_w, c0_new, ED, n, ED, MB * 3, e->conv0_b, nullptr, 0, ACT_GELU);
+    if (launch_gemm(e, col, MB * 3, e->conv0_w, c0_new, ED, n, ED, MB * 3, e->conv0_b, nullptr, 0, ACT_GELU)) return -1;
     // roll the mel history: rows 0,1 <- last two frames seen. n == 1 reproduces the
     // reference's tail update, which zeroes the older slot (voxtral.c:604-609, tc == 1).
     if (n >= 2) {
@@ -817,7 +766,7 @@ static int conv_stem_dev(vox_hip_engine *e, int n, float **xout) {
         hipLaunchKernelGGL(k_im2col3, dim3(grid1d((size_t)nq * ED * 3)), dim3(256), 0, s, col, (const float *)in1, nq, ED, 2);
         if (ensure(e, e->sx, (size_t)nq * ED * 4)) return -1;
         float *x = (float *)e->sx.p;
-        launch_gemm(e, col, ED * 3, e->conv1_w, x, ED, nq, ED, ED * 3, e->conv1_b, nullptr, 0, ACT_GELU);
+        if (launch_gemm(e, col, ED * 3, e->conv1_w, x, ED, nq, ED, ED * 3, e->conv1_b, nullptr, 0, ACT_GELU)) return -1;
         *xout = x;
         // history row <- last consumed conv0 frame; carry row <- odd leftover
         HC(hipMemcpyAsync(in1, in1 + (size_t)(2 * nq) * ED, (size_t)ED * 4, hipMemcpyDeviceToDevice, s));
@@ -846,6 +795,32 @@ extern "C" int vox_hip_conv_stem(vox_hip_engine_t *e, const float *mel_new, int 
     }
     HC(hipStreamSynchronize(e->stream));
     return rows;
+}
+
+// The reference's BATCH conv stem (vox_encoder_forward -> vox_causal_conv1d, voxtral_encoder.c:135-176,
+// voxtral_kernels.c:293-340) right-pads an odd number of conv0 frames with one zero frame, so it
+// emits ceil(L/2) rows where the stream path keeps the unpaired frame waiting.  This computes that
+// last row from the carried frame and a zero partner; out_row [enc_dim] (host).  Returns 1 if a row
+// was produced, 0 if nothing was pending, -1 on error.
+extern "C" int vox_hip_conv_stem_pad_odd(vox_hip_engine_t *e, float *out_row) {
+    if (!e) return -1;
+    HC(hipSetDevice(e->device));
+    if (!e->c0_carry) return 0;
+    const int ED = e->d.enc_dim;
+    hipStream_t s = e->stream;
+    if (ensure_keep(e, e->conv_in1, (size_t)3 * ED * 4, (size_t)2 * ED * 4)) return -1;
+    float *in1 = (float *)e->conv_in1.p;
+    HC(hipMemsetAsync(in1 + (size_t)2 * ED, 0, (size_t)ED * 4, s));
+    if (ensure(e, e->sim2col, (size_t)ED * 3 * 4)) return -1;
+    if (ensure(e, e->sx, (size_t)ED * 4)) return -1;
+    float *col = (float *)e->sim2col.p, *x = (float *)e->sx.p;
+    hipLaunchKernelGGL(k_im2col3, dim3(grid1d((size_t)ED * 3)), dim3(256), 0, s, col, (const float *)in1, 1, ED, 2);
+    if (launch_gemm(e, col, ED * 3, e->conv1_w, x, ED, 1, ED, ED * 3, e->conv1_b, nullptr, 0, ACT_GELU)) return -1;
+    HC(hipMemcpyAsync(in1, in1 + (size_t)2 * ED, (size_t)ED * 4, hipMemcpyDeviceToDevice, s));   // history <- the zero frame
+    e->c0_carry = 0;
+    if (out_row) HC(hipMemcpyAsync(out_row, x, (size_t)ED * 4, hipMemcpyDeviceToHost, s));
+    HC(hipStreamSynchronize(s));
+    return 1;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1118,6 +1093,7 @@ static int decoder_prefill_dev(vox_hip_engine *e, float *x, int n) {
         }
         e->dec_pos += m;
     }
+    LAUNCH_CHECK("decoder prefill launches");
     return 0;
 }
 
@@ -1160,11 +1136,11 @@ static void launch_gemv3(vox_hip_engine *e, const GemvArgs &a) {
     size_t fl = K + 64;
     if (PRO == PRO_RMS || PRO == PRO_EMBED_RMS) fl += 2 * (size_t)K;
     if (PRO == PRO_ATTN) fl += 256;
-    hipLaunchKernelGGL((k_gemv3<PRO, EPI, RPW, CPL, KS, MINW, false, W8>), dim3(grid), dim3(256), fl * sizeof(float), e->stream, a);
+    hipLaunchKernelGGL((k_gemv3<PRO, EPI, RPW, CPL, KS, MINW, W8>), dim3(grid), dim3(256), fl * sizeof(float), e->stream, a);
 }
 
 // Enqueue one decode step. kv_pos = logical position of this token (host mirror of st->pos).
-static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *logits_dst, int eos, int advance) {
+static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *logits_dst, int eos, int advance) {
     const vox_hip_dims_t &d = e->d;
     const int DD = d.dec_dim, DQ = e->dec_qd, DKV = e->dec_kvd, DH = d.dec_hidden, HD = d.dec_head_dim;
     hipStream_t s = e->stream;
@@ -1273,131 +1249,17 @@ static void enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float 
         a.N = d.vocab; a.K = DD; a.blk_val = e->blk_val; a.blk_idx = e->blk_idx;
         if (fast && e->use_fp8) {
             a.W = reinterpret_cast<const uint16_t *>(e->tok_emb8); a.wscale = e->stok;
-            hipLaunchKernelGGL((k_gemv<PRO_RMS, EPI_LOGITS, 4, false, true>), dim3(e->logits_grid), dim3(256),
+            hipLaunchKernelGGL((k_gemv<PRO_RMS, EPI_LOGITS, 4, true>), dim3(e->logits_grid), dim3(256),
                                ((size_t)DD + 16) * sizeof(float), s, a);
         } else
             launch_gemv<PRO_RMS, EPI_LOGITS, 4>(e, a, e->logits_grid);
         prof_mark(e, PK_LOGITS);
         hipLaunchKernelGGL(k_argmax_finish, dim3(1), dim3(256), 0, s, (const float *)e->blk_val, (const int *)e->blk_idx,
-                           e->logits_grid, e->d_st, e->d_tokens, eos, advance, PdlArgs{});
+                           e->logits_grid, e->d_st, e->d_tokens, eos, advance);
         prof_mark(e, PK_ARGMAX);
     }
-}
-
-// ------------------------------------------------------------------------------------
-// Overlapped decode chain (vox_common.h, PdlArgs): kernels alternate between two CU-masked
-// streams (one half of the chip each); kernel g waits in-kernel for kernel g-1's completion
-// counter after it has issued its own weight loads.
-// ------------------------------------------------------------------------------------
-static hipStream_t pdl_next(vox_hip_engine *e, int blocks, PdlArgs &p) {
-    const unsigned g = e->pdl_g++;
-    p.flags = e->d_pdl; p.err = e->d_pdl + 2 * PDL_SLOT_STRIDE; p.spin_limit = 2000000ull;       // 20 ms @ 100 MHz
-    if (e->pdl_first) { p.wait_slot = -1; p.wait_val = 0; e->pdl_first = false; }
-    else { p.wait_slot = (int)((g - 1) & 1u); p.wait_val = e->pdl_cum[(g - 1) & 1u]; }
-    p.sig_slot = (int)(g & 1u);
-    p.trace = nullptr;
-    if (e->d_pdl_trace && e->pdl_trace_on && e->pdl_trace_k < 160) p.trace = e->d_pdl_trace + 32 * (e->pdl_trace_k++);
-    e->pdl_cum[g & 1u] += (unsigned)blocks;
-    return e->pdl_stream[g & 1u];
-}
-static int pdl_begin(vox_hip_engine *e) {            // fork: both halves wait for the engine stream
-    HC(hipEventRecord(e->pdl_ev[2], e->stream));
-    HC(hipStreamWaitEvent(e->pdl_stream[0], e->pdl_ev[2], 0));
-    HC(hipStreamWaitEvent(e->pdl_stream[1], e->pdl_ev[2], 0));
-    e->pdl_first = true;
+    LAUNCH_CHECK("decode step launches");
     return 0;
-}
-static int pdl_end(vox_hip_engine *e) {              // join: the engine stream waits for both halves
-    HC(hipEventRecord(e->pdl_ev[0], e->pdl_stream[0]));
-    HC(hipEventRecord(e->pdl_ev[1], e->pdl_stream[1]));
-    HC(hipStreamWaitEvent(e->stream, e->pdl_ev[0], 0));
-    HC(hipStreamWaitEvent(e->stream, e->pdl_ev[1], 0));
-    return 0;
-}
-
-template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW>
-static void launch_gemv3_pdl(vox_hip_engine *e, GemvArgs &a) {
-    constexpr int K = CPL * KS * 512;
-    const int rows_per_block = (4 / KS) * RPW;
-    const int grid = (a.N + rows_per_block - 1) / rows_per_block;
-    size_t fl = K + 64;
-    if (PRO == PRO_RMS || PRO == PRO_EMBED_RMS) fl += 2 * (size_t)K;
-    if (PRO == PRO_ATTN) fl += 256;
-    hipStream_t s = pdl_next(e, grid, a.pdl);
-    hipLaunchKernelGGL((k_gemv3<PRO, EPI, RPW, CPL, KS, MINW, true>), dim3(grid), dim3(256), fl * sizeof(float), s, a);
-}
-
-// One decode step of the 4B geometry as an overlapped chain (between pdl_begin / pdl_end).
-static void enqueue_step_pdl(vox_hip_engine *e, int kv_pos, float *logits_dst, int eos, int advance) {
-    const vox_hip_dims_t &d = e->d;
-    const int DD = d.dec_dim, DQ = e->dec_qd, DKV = e->dec_kvd, DH = d.dec_hidden, HD = d.dec_head_dim;
-    const int kv_len = std::min(kv_pos + 1, d.dec_window);
-    int split_keys = dec_split_keys(kv_len);
-    while ((kv_len + split_keys - 1) / split_keys > 8) split_keys *= 2;     // the Wo prologue merges <= 8 slices
-    const int nsplit = (kv_len + split_keys - 1) / split_keys;
-    const float scale = 1.0f / sqrtf((float)HD);
-    for (int l = 0; l < d.dec_layers; l++) {
-        DecLayer &L = e->dec[l];
-        {
-            GemvArgs a{};
-            a.W = L.wqkv; a.x = e->dx; a.norm_w = L.n1; a.ada = nullptr; a.eps = d.dec_eps; a.y = e->dq;
-            a.N = DQ + 2 * DKV; a.K = DD; a.q_rows = DQ; a.k_rows = DKV; a.head_dim = HD; a.rope = e->dec_rope;
-            a.kcache = L.kring; a.vcache = L.vring; a.kv_cap = e->dec_ring_cap; a.kv_dim = DKV; a.st = e->d_st;
-            a.inv_freq = e->dec_inv_freq; a.adapter = e->adapter; a.tok_emb = e->tok_emb; a.x_out = e->dx;
-            a.pos_host = kv_pos;
-            if (l == 0) launch_gemv3_pdl<PRO_EMBED_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
-            else launch_gemv3_pdl<PRO_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
-        }
-        {
-            AttnArgs a{};
-            a.out = e->dattn; a.ldo = DQ; a.q = e->dq; a.ldq = DQ; a.n_q = 1; a.qpos0 = kv_pos;
-            a.posB0 = INT_MAX; a.last_key = kv_pos; a.kA = L.kring; a.vA = L.vring; a.capA = e->dec_ring_cap; a.ldA = DKV;
-            a.n_heads = d.dec_heads; a.n_kv_heads = d.dec_kv_heads; a.scale = scale; a.window = d.dec_window;
-            a.st = nullptr; a.split_keys = split_keys; a.part_o = e->dpart_o; a.part_ml = e->dpart_ml;
-            a.force_partials = 1;
-            hipStream_t s = pdl_next(e, d.dec_kv_heads * nsplit, a.pdl);
-            if (e->use_dpp)
-                hipLaunchKernelGGL((k_attn_dec<128, 4, true, true>), dim3(d.dec_kv_heads, nsplit, 1), dim3(256), 0, s, a, nsplit);
-            else
-                hipLaunchKernelGGL((k_attn_dec<128, 4, false, true>), dim3(d.dec_kv_heads, nsplit, 1), dim3(256), 0, s, a, nsplit);
-        }
-        {
-            GemvArgs a{};
-            a.W = L.wo; a.x = e->dattn; a.y = e->dx; a.N = DD; a.K = DQ;
-            a.part_o = e->dpart_o; a.part_ml = e->dpart_ml; a.nsplit = nsplit; a.attn_hd = HD;
-            launch_gemv3_pdl<PRO_ATTN, EPI_RESID, 3, 8, 1, 1>(e, a);
-        }
-        {
-            GemvArgs a{};
-            a.W = L.w13; a.W2 = L.w13 + (size_t)DH * DD; a.x = e->dx; a.norm_w = L.n2; a.ada = L.ada; a.eps = d.dec_eps;
-            a.y = e->dh; a.N = DH; a.K = DD;
-            launch_gemv3_pdl<PRO_RMS, EPI_SWIGLU, 3, 6, 1, 3>(e, a);
-        }
-        {
-            GemvArgs a{};
-            a.W = L.w2; a.x = e->dh; a.y = e->dx; a.N = DD; a.K = DH;
-            launch_gemv3_pdl<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
-        }
-    }
-    // tied-embedding logits: one vocabulary half per CU half, then the argmax over all partials
-    const int half_rows = d.vocab / 2, half_grid = e->logits_grid / 2;
-    for (int hf = 0; hf < 2; hf++) {
-        GemvArgs a{};
-        a.W = e->tok_emb + (size_t)hf * half_rows * DD; a.x = e->dx; a.norm_w = e->dec_final_norm; a.eps = d.dec_eps;
-        a.y = logits_dst + (size_t)hf * half_rows; a.N = half_rows; a.K = DD;
-        a.blk_val = e->blk_val + hf * half_grid; a.blk_idx = e->blk_idx + hf * half_grid; a.row_base = hf * half_rows;
-        hipStream_t s = pdl_next(e, half_grid, a.pdl);
-        if (hf == 1) {                               // both halves depend on the last w2 launch (g-2 for this one):
-            a.pdl.wait_slot = -1;                    // it precedes this launch on the same stream
-        }
-        hipLaunchKernelGGL((k_gemv<PRO_RMS, EPI_LOGITS, 4, true>), dim3(half_grid), dim3(256), ((size_t)DD + 16) * sizeof(float), s, a);
-    }
-    {
-        PdlArgs p{};
-        hipStream_t s = pdl_next(e, 1, p);
-        hipLaunchKernelGGL(k_argmax_finish, dim3(1), dim3(256), 0, s, (const float *)e->blk_val, (const int *)e->blk_idx,
-                           e->logits_grid, e->d_st, e->d_tokens, eos, advance, p);
-    }
 }
 
 static int set_state(vox_hip_engine *e, int pos, int token, int64_t adapter_phys_row) {
@@ -1413,7 +1275,7 @@ extern "C" int vox_hip_decoder_step(vox_hip_engine_t *e, const float *embed, flo
     HC(hipSetDevice(e->device));
     HC(hipMemcpyAsync(e->dx, embed, (size_t)e->d.dec_dim * 4, hipMemcpyHostToDevice, e->stream));
     if (set_state(e, e->dec_pos, 0, 0)) return -1;
-    enqueue_step(e, e->dec_pos, false, e->dlogits, -1, 1);
+    if (enqueue_step(e, e->dec_pos, false, e->dlogits, -1, 1)) return -1;
     int tok = -1;
     HC(hipMemcpyAsync(&tok, e->d_tokens, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     if (logits) HC(hipMemcpyAsync(logits, e->dlogits, (size_t)e->d.vocab * 4, hipMemcpyDeviceToHost, e->stream));
@@ -1438,7 +1300,7 @@ extern "C" int vox_hip_decoder_prefill_stream(vox_hip_engine_t *e, int64_t first
     HC(hipMemcpyAsync(e->dx, x + (size_t)(n_prompt - 1) * DD, (size_t)DD * 4, hipMemcpyDeviceToDevice, s));
     if (n_prompt > 1 && decoder_prefill_dev(e, x, n_prompt - 1)) return -1;
     if (set_state(e, e->dec_pos, 0, 0)) return -1;
-    enqueue_step(e, e->dec_pos, false, e->dlogits, -1, 1);
+    if (enqueue_step(e, e->dec_pos, false, e->dlogits, -1, 1)) return -1;
     int tok = -1;
     HC(hipMemcpyAsync(&tok, e->d_tokens, sizeof(int), hipMemcpyDeviceToHost, s));
     if (logits) HC(hipMemcpyAsync(logits, e->dlogits, (size_t)e->d.vocab * 4, hipMemcpyDeviceToHost, s));
@@ -1468,68 +1330,8 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
             if (ensure(e, e->stmp_out, (size_t)batch * V * 4)) return -1;
             lg = (float *)e->stmp_out.p;
         }
-        bool launched = false;
-        if (e->use_persist) {
-            // one cooperative launch for the whole batch (vox_persist.h)
-            PersistArgs pa{};
-            pa.layers = e->d_players; pa.n_layers = e->d.dec_layers; pa.tok_emb = e->tok_emb;
-            pa.final_norm = e->dec_final_norm; pa.inv_freq = e->dec_inv_freq; pa.adapter = e->adapter;
-            pa.st = e->d_st; pa.x = e->dx; pa.q = e->dq; pa.h = e->dh; pa.part_o = e->dpart_o; pa.part_ml = e->dpart_ml;
-            pa.logits = lg; pa.blk_val = e->blk_val; pa.blk_idx = e->blk_idx; pa.tokens_out = e->d_tokens; pa.bar = e->d_bar;
-            pa.n_steps = batch; pa.eos = eos_token; pa.kv_cap = e->dec_ring_cap; pa.window = e->d.dec_window; pa.eps = e->d.dec_eps;
-            pa.logits_stride = logits_out ? (long long)V : 0; pa.spin_limit = 5000000ull;   // 50 ms @ 100 MHz
-            HC(hipMemsetAsync(e->d_bar, 0, 16 * sizeof(unsigned), s));
-            const char *trace_path = getenv("VOX_HIP_PERSIST_TRACE");
-            if (trace_path) {
-                if (!e->d_trace && hipMalloc(&e->d_trace, 2 * 4096 * 8) != hipSuccess) e->d_trace = nullptr;
-                if (e->d_trace) HC(hipMemsetAsync(e->d_trace, 0, 2 * 4096 * 8, s));
-                pa.trace = e->d_trace;
-            }
-            void *kargs[] = {&pa};
-            hipError_t le = hipLaunchCooperativeKernel((const void *)k_decode_persist, dim3(pk::NB), dim3(pk::THREADS), kargs,
-                                                       pk::LDS_FLOATS * 4, s);
-            if (le == hipSuccess) {
-                unsigned errw = 0;
-                HC(hipMemcpyAsync(&errw, e->d_bar + 9, sizeof errw, hipMemcpyDeviceToHost, s));
-                HC(hipStreamSynchronize(s));
-                e->persist_runs++;
-                if (trace_path && e->d_trace) {
-                    std::vector<unsigned long long> h(2 * 4096);
-                    HC(hipMemcpy(h.data(), e->d_trace, h.size() * 8, hipMemcpyDeviceToHost));
-                    if (FILE *f = fopen(trace_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-                }
-                if (errw == 0) launched = true;
-                else {
-                    fprintf(stderr, "vox_hip: WARNING persistent decode kernel timed out at barrier %u; falling back to the multi-launch path\n", errw);
-                    e->use_persist = false; e->persist_failures++;
-                    if (set_state(e, e->dec_pos, prev_token, first_row + done - e->adapter_row0)) return -1;
-                }
-            } else {
-                (void)hipGetLastError();
-                fprintf(stderr, "vox_hip: WARNING cooperative launch refused (%s); using the multi-launch decode path\n", hipGetErrorString(le));
-                e->use_persist = false; e->persist_failures++;
-            }
-        }
-        if (!launched && e->use_pdl) {
-            HC(hipMemsetAsync(e->d_pdl + 2 * PDL_SLOT_STRIDE, 0, sizeof(unsigned), s));
-            if (pdl_begin(e)) return -1;
-            for (int i = 0; i < batch; i++)
-                enqueue_step_pdl(e, e->dec_pos + i, logits_out ? lg + (size_t)i * V : lg, eos_token, 1);
-            if (pdl_end(e)) return -1;
-            unsigned errw = 0;
-            HC(hipMemcpyAsync(&errw, e->d_pdl + 2 * PDL_SLOT_STRIDE, sizeof errw, hipMemcpyDeviceToHost, s));
-            HC(hipStreamSynchronize(s));
-            e->pdl_runs++;
-            if (errw == 0) launched = true;
-            else {
-                fprintf(stderr, "vox_hip: WARNING overlapped decode chain timed out (code %u); falling back to plain launches\n", errw);
-                e->use_pdl = false; e->pdl_failures++;
-                if (set_state(e, e->dec_pos, prev_token, first_row + done - e->adapter_row0)) return -1;
-            }
-        }
-        if (!launched)
-            for (int i = 0; i < batch; i++)
-                enqueue_step(e, e->dec_pos + i, true, logits_out ? lg + (size_t)i * V : lg, eos_token, 1);
+        for (int i = 0; i < batch; i++)
+            if (enqueue_step(e, e->dec_pos + i, true, logits_out ? lg + (size_t)i * V : lg, eos_token, 1)) return -1;
         DecState st{};
         HC(hipMemcpyAsync(&st, e->d_st, sizeof st, hipMemcpyDeviceToHost, s));
         HC(hipStreamSynchronize(s));
@@ -1596,7 +1398,7 @@ extern "C" int vox_hip_linear_bf16(vox_hip_engine_t *e, float *y, const float *x
     HC(hipMemcpy(dx, x, (size_t)M * K * 4, hipMemcpyHostToDevice));
     HC(hipMemcpy(dw, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
     if (bias) { HC(hipMalloc((void **)&db, (size_t)N * 4)); HC(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice)); }
-    linear_dev(e, dy, N, dx, K, dw, db, M, K, N, ACT_NONE, nullptr, 0, impl);
+    if (linear_dev(e, dy, N, dx, K, dw, db, M, K, N, ACT_NONE, nullptr, 0, impl)) return -1;
     HC(hipStreamSynchronize(e->stream));
     HC(hipGetLastError());
     HC(hipMemcpy(y, dy, (size_t)M * N * 4, hipMemcpyDeviceToHost));
@@ -1626,7 +1428,7 @@ extern "C" int vox_hip_causal_attention(vox_hip_engine_t *e, float *out, const f
     int rc = 0;
     if (head_dim == 64 && e->use_attn_mfma && n_heads == n_kv_heads) {
         hipLaunchKernelGGL(k_attn_enc_mfma, dim3((seq_q + 127) / 128, n_heads), dim3(256), 0, e->stream, a);
-    } else if (head_dim == 64) {
+    } else if (head_dim == 64 && n_heads == n_kv_heads) {
         hipLaunchKernelGGL((k_attn_rows<64>), dim3((seq_q + 127) / 128, n_heads), dim3(128), 0, e->stream, a);
     } else if (head_dim == 128 && n_heads == 4 * n_kv_heads) {
         const int max_len = std::min(q_offset + seq_q, a.window);
@@ -1643,6 +1445,10 @@ extern "C" int vox_hip_causal_attention(vox_hip_engine_t *e, float *out, const f
         if (nsplit > 1)
             hipLaunchKernelGGL((k_attn_combine<128>), dim3(n_heads, seq_q), dim3(128), 0, e->stream, dout, a.ldo,
                                (const float *)po, (const float *)pml, n_heads, nsplit);
+    } else if (head_dim <= 256 && n_kv_heads > 0 && n_heads % n_kv_heads == 0) {
+        // any other geometry: the generic kernel of the kernel-level API (vox_kernel_api.h)
+        hipLaunchKernelGGL(k_attn_generic, dim3(seq_q, n_heads), dim3(64), 0, e->stream, dout, (const float *)dq, (const float *)dk,
+                           (const float *)dv, seq_q, seq_k, n_heads, n_kv_heads, head_dim, scale, window, q_offset);
     } else {
         g_err = "vox_hip_causal_attention: unsupported head geometry"; rc = -1;
     }
@@ -1668,29 +1474,7 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
         hipMemsetAsync(e->adapter, 0, (size_t)e->d.dec_dim * 4, e->stream);
     }
     if (set_state(e, pos, 1, 0)) return -1.0;
-    if (e->use_pdl) {
-        pdl_begin(e);
-        for (int i = 0; i < 3; i++) enqueue_step_pdl(e, pos, e->dlogits, -1, 0);  // warm-up
-        pdl_end(e);
-        hipEventRecord(e->ev0, e->stream);
-        const char *tp = getenv("VOX_HIP_PDL_TRACE");
-        if (tp && !e->d_pdl_trace) { if (hipMalloc((void **)&e->d_pdl_trace, 160 * 32 * 8) != hipSuccess) e->d_pdl_trace = nullptr; }
-        if (e->d_pdl_trace) hipMemsetAsync(e->d_pdl_trace, 0, 160 * 32 * 8, e->stream);
-        pdl_begin(e);
-        for (int i = 0; i < iters; i++) {
-            e->pdl_trace_on = (tp && i == iters - 1); e->pdl_trace_k = 0;
-            enqueue_step_pdl(e, pos, e->dlogits, -1, 0);
-        }
-        e->pdl_trace_on = false;
-        pdl_end(e);
-        hipEventRecord(e->ev1, e->stream);
-        if (tp && e->d_pdl_trace) {
-            hipStreamSynchronize(e->stream);
-            std::vector<unsigned long long> h(160 * 32);
-            hipMemcpy(h.data(), e->d_pdl_trace, h.size() * 8, hipMemcpyDeviceToHost);
-            if (FILE *f = fopen(tp, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-        }
-    } else if (getenv("VOX_HIP_GRAPH_TIMING")) {
+    if (getenv("VOX_HIP_GRAPH_TIMING")) {
         // experiment: the same step captured once into a hipGraph and replayed (no host launch cost)
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
         for (int i = 0; i < 3; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);
@@ -1770,13 +1554,10 @@ extern "C" double vox_hip_time_empty_launches_graph(vox_hip_engine_t *e, int n, 
 extern "C" int vox_hip_time_decoder_step_without(vox_hip_engine_t *e, int iters, int kv_len, int kind,
                                                  double *full_s, double *skipped_s) {
     if (!e || kind <= 0 || kind >= PK_LOGITS) return -1;
-    const bool pdl = e->use_pdl;
-    e->use_pdl = false;
     const double a = vox_hip_time_decoder_step(e, iters, kv_len);
     e->skip_kinds = 1u << kind;
     const double b = vox_hip_time_decoder_step(e, iters, kv_len);
     e->skip_kinds = 0;
-    e->use_pdl = pdl;
     if (full_s) *full_s = a;
     if (skipped_s) *skipped_s = b;
     return (a > 0 && b > 0) ? 0 : -1;
@@ -1844,17 +1625,9 @@ extern "C" int vox_hip_quantize_decoder_fp8(vox_hip_engine_t *e) {
     HC(hipStreamSynchronize(e->stream));
     HC(hipGetLastError());
     e->use_fp8 = true;
-    e->use_persist = false; e->use_pdl = false;      // the experiments only know the bf16 layout
     return 0;
 }
 extern "C" int vox_hip_weight_format(vox_hip_engine_t *e) { return e ? (e->use_fp8 ? 1 : 0) : -1; }
-
-// Which decode path vox_hip_decoder_run uses: 0 = plain launches, 1 = overlapped chain on two
-// CU-masked streams, 2 = persistent kernel (opt-in experiment).
-extern "C" int vox_hip_decode_path(vox_hip_engine_t *e) {
-    if (!e) return -1;
-    return e->use_persist ? 2 : (e->use_pdl ? 1 : 0);
-}
 
 // Experiment hook: time `iters` passes over the five decode kernels of ONE layer (233 MB of
 // weights, which fit the 256 MB Infinity Cache) to see what the same launches cost when the
@@ -1890,7 +1663,8 @@ static int self_test(vox_hip_engine *e) {
     HC(hipStreamSynchronize(e->stream));
     bool ok = true;
     for (int i = 0; i < 64; i++) if (fabsf(ha[i] - hb[i]) > 1e-3f * fabsf(hb[i])) ok = false;
-    if (!ok) { fprintf(stderr, "vox_hip: WARNING DPP row reduction self-test failed; using __shfl reductions\n"); e->use_dpp = false; }
+    int failed = 0;
+    if (!ok) { fprintf(stderr, "vox_hip: DPP row reduction self-test FAILED\n"); e->use_dpp = false; failed++; }
     hipFree(d_a); hipFree(d_b);
     if (getenv("VOX_HIP_NO_DPP")) e->use_dpp = false;
 
@@ -1924,12 +1698,12 @@ static int self_test(vox_hip_engine *e) {
         maxd = std::max(maxd, (double)fabsf(hy1[i] - hy2[i]));
     }
     if (!(maxd0 < 2e-5)) {
-        fprintf(stderr, "vox_hip: WARNING bf16x3 MFMA GEMM self-test failed (max diff %g); using the f32-input MFMA GEMM\n", maxd0);
-        e->use_bf16x3 = false;
+        fprintf(stderr, "vox_hip: bf16x3 MFMA GEMM self-test FAILED (max diff %g)\n", maxd0);
+        e->use_bf16x3 = false; failed++;
     }
     if (!(maxd < 2e-5)) {
-        fprintf(stderr, "vox_hip: WARNING MFMA GEMM self-test failed (max diff %g); using the scalar HIP GEMM\n", maxd);
-        e->use_mfma = false;
+        fprintf(stderr, "vox_hip: f32-input MFMA GEMM self-test FAILED (max diff %g)\n", maxd);
+        e->use_mfma = false; failed++;
     }
     if (getenv("VOX_HIP_NO_BF16X3")) e->use_bf16x3 = false;
 
@@ -1962,8 +1736,8 @@ static int self_test(vox_hip_engine *e) {
         double md = 0;
         for (size_t i = 0; i < r1.size(); i++) md = std::max(md, (double)fabsf(r1[i] - r2[i]));
         if (!(md < 1e-4)) {
-            fprintf(stderr, "vox_hip: WARNING MFMA attention self-test failed (max diff %g); using the VALU attention kernel\n", md);
-            e->use_attn_mfma = false;
+            fprintf(stderr, "vox_hip: MFMA attention self-test FAILED (max diff %g)\n", md);
+            e->use_attn_mfma = false; failed++;
         }
         hipFree(dq); hipFree(dk); hipFree(dv); hipFree(do1); hipFree(do2);
         if (getenv("VOX_HIP_NO_ATTN_MFMA")) e->use_attn_mfma = false;
@@ -1973,5 +1747,178 @@ static int self_test(vox_hip_engine *e) {
     if (getenv("VOX_HIP_NO_GEMV3")) e->use_gemv3 = false;
     if (getenv("VOX_HIP_NO_SPLITK")) e->use_splitk = false;
     hipFree(dx); hipFree(dy0); hipFree(dy1); hipFree(dy2); hipFree(dw); hipFree(dbias);
+    if (failed) {
+        // A production kernel disagreeing with its plain cross-check is a broken build or device, not a
+        // tuning matter: refuse to load unless the operator explicitly accepts the slower plain kernels.
+        if (!getenv("VOX_HIP_ALLOW_FALLBACK")) {
+            g_err = "vox_hip: start-up self-test failed (see stderr); set VOX_HIP_ALLOW_FALLBACK=1 to run on the plain HIP kernels";
+            fprintf(stderr, "%s\n", g_err.c_str());
+            return -1;
+        }
+        fprintf(stderr, "vox_hip: WARNING continuing on the plain HIP variants of the failed kernels (VOX_HIP_ALLOW_FALLBACK); "
+                        "vox_hip_active_paths() reports which\n");
+    }
+    return 0;
+}
+
+// Which kernel families the engine runs (bit set = production variant live).  Tests assert the full
+// mask on gfx950 so that a silent downgrade cannot pass; bench.py prints it.
+extern "C" unsigned vox_hip_active_paths(const vox_hip_engine_t *e) {
+    if (!e) return 0;
+    const vox_hip_dims_t &d = e->d;
+    const bool fast_geom = d.dec_dim == 3072 && e->dec_qd == 4096 && e->dec_kvd == 1024 && d.dec_hidden == 9216;
+    unsigned m = 0;
+    if (e->use_mfma) m |= VOX_PATH_GEMM_MFMA_F32;
+    if (e->use_mfma && e->use_bf16x3) m |= VOX_PATH_GEMM_MFMA_BF16X3;
+    if (e->use_attn_mfma) m |= VOX_PATH_ATTN_ENC_MFMA;
+    if (e->use_dpp) m |= VOX_PATH_ATTN_DEC_DPP;
+    if (e->use_splitk) m |= VOX_PATH_GEMM_SPLITK;
+    if (fast_geom && e->use_gemv2 && e->use_gemv3) m |= VOX_PATH_GEMV3;
+    if (e->use_fp8) m |= VOX_PATH_FP8_DECODE;
+    return m;
+}
+
+// ------------------------------------------------------------------------------------
+// Kernel-level API of the reference (voxtral_kernels.h:18-159) on host buffers: the device side
+// of host/vox_kernels.c.  Generic shapes, synchronous, one temporary allocation per call: a
+// correctness / compatibility surface, not a hot path (vox_kernel_api.h).
+// ------------------------------------------------------------------------------------
+namespace {
+struct Tmp {                      // device temporaries of one call, freed on scope exit
+    std::vector<void *> ps;
+    ~Tmp() { for (void *p : ps) hipFree(p); }
+    template <typename T> T *get(size_t n) {
+        void *p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        ps.push_back(p);
+        return (T *)p;
+    }
+    template <typename T> T *up(const T *h, size_t n) {
+        T *d = get<T>(n);
+        if (d && h && hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return d;
+    }
+};
+}  // namespace
+#define KNULL(p) do { if (!(p)) { g_err = "vox_hip kernel API: device allocation / upload failed"; return -1; } } while (0)
+
+extern "C" int vox_hip_k_eltwise(vox_hip_engine_t *e, float *a, const float *b, float s, size_t n, int op) {
+    if (!e || !a) return -1;
+    if (n == 0) return 0;
+    HC(hipSetDevice(e->device));
+    Tmp t;
+    float *da = t.up(a, n); KNULL(da);
+    float *db = nullptr;
+    if (b) { db = t.up(b, n); KNULL(db); }
+    hipLaunchKernelGGL(k_eltwise, dim3(grid1d(n)), dim3(256), 0, e->stream, da, (const float *)db, s, n, op);
+    LAUNCH_CHECK("k_eltwise");
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMemcpy(a, da, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// C[M,N] = A[M,K] . B (+bias[n]);  b_is_nk: B is [N,K] (C = A B^T), else [K,N].
+extern "C" int vox_hip_k_sgemm(vox_hip_engine_t *e, float *C, const float *A, const float *B, const float *bias,
+                               int M, int K, int N, int b_is_nk) {
+    if (!e || !C || !A || !B || M <= 0 || N <= 0 || K <= 0) return -1;
+    HC(hipSetDevice(e->device));
+    Tmp t;
+    float *dA = t.up(A, (size_t)M * K), *dB = t.up(B, (size_t)N * K), *dC = t.get<float>((size_t)M * N);
+    KNULL(dA); KNULL(dB); KNULL(dC);
+    float *db = nullptr;
+    if (bias) { db = t.up(bias, (size_t)N); KNULL(db); }
+    hipLaunchKernelGGL(k_sgemm, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, e->stream, dC, N, (const float *)dA, K,
+                       (const float *)dB, (long)(b_is_nk ? 1 : N), (long)(b_is_nk ? K : 1), M, N, K, (const float *)db,
+                       (const float *)nullptr);
+    LAUNCH_CHECK("k_sgemm");
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// 1-D convolution on channel-major data: in [C_in, L], weight [C_out, C_in*ks], out [C_out, L_out]
+// (vox_conv1d / vox_causal_conv1d, voxtral_kernels.c:255-340): im2col + GEMM, like the reference.
+extern "C" int vox_hip_k_conv1d(vox_hip_engine_t *e, float *out, const float *in, const float *weight, const float *bias,
+                                int c_in, int c_out, int length, int ks, int stride, int pad_left, int out_len) {
+    if (!e || !out || !in || !weight || c_in <= 0 || c_out <= 0 || length <= 0 || ks <= 0 || stride <= 0) return -1;
+    if (out_len <= 0) return 0;
+    HC(hipSetDevice(e->device));
+    Tmp t;
+    const int K = c_in * ks;
+    float *din = t.up(in, (size_t)c_in * length), *dw = t.up(weight, (size_t)c_out * K);
+    float *col = t.get<float>((size_t)K * out_len), *dout = t.get<float>((size_t)c_out * out_len);
+    KNULL(din); KNULL(dw); KNULL(col); KNULL(dout);
+    float *db = nullptr;
+    if (bias) { db = t.up(bias, (size_t)c_out); KNULL(db); }
+    hipLaunchKernelGGL(k_conv_im2col, dim3(grid1d((size_t)K * out_len)), dim3(256), 0, e->stream, col, (const float *)din, c_in,
+                       length, ks, stride, pad_left, out_len);
+    // out[C_out, L_out] = W[C_out, K] . col[K, L_out] + bias[oc] (a per-ROW bias)
+    hipLaunchKernelGGL(k_sgemm, dim3((out_len + 63) / 64, (c_out + 63) / 64), dim3(256), 0, e->stream, dout, out_len,
+                       (const float *)dw, K, (const float *)col, (long)out_len, 1L, c_out, out_len, K, (const float *)nullptr,
+                       (const float *)db);
+    LAUNCH_CHECK("conv1d");
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMemcpy(out, dout, (size_t)c_out * out_len * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int vox_hip_k_rms_norm(vox_hip_engine_t *e, float *out, const float *x, const float *w, int seq, int hidden, float eps) {
+    if (!e || !out || !x || !w || seq <= 0 || hidden <= 0) return -1;
+    HC(hipSetDevice(e->device));
+    Tmp t;
+    float *dx = t.up(x, (size_t)seq * hidden), *dw = t.up(w, (size_t)hidden), *dout = t.get<float>((size_t)seq * hidden);
+    KNULL(dx); KNULL(dw); KNULL(dout);
+    if (hidden % 4 == 0)
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(seq), dim3(256), 0, e->stream, dout, hidden, (const float *)dx, hidden,
+                           (const float *)dw, (const float *)nullptr, hidden, eps);
+    else
+        hipLaunchKernelGGL(k_rmsnorm_generic, dim3(seq), dim3(256), 0, e->stream, dout, (const float *)dx, (const float *)dw, hidden, eps);
+    LAUNCH_CHECK("rms_norm");
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMemcpy(out, dout, (size_t)seq * hidden * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int vox_hip_k_softmax(vox_hip_engine_t *e, float *x, int rows, int cols) {
+    if (!e || !x || rows <= 0 || cols <= 0) return -1;
+    HC(hipSetDevice(e->device));
+    Tmp t;
+    float *dx = t.up(x, (size_t)rows * cols); KNULL(dx);
+    hipLaunchKernelGGL(k_softmax_rows, dim3(rows), dim3(256), 0, e->stream, dx, cols);
+    LAUNCH_CHECK("softmax");
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMemcpy(x, dx, (size_t)rows * cols * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int vox_hip_k_rope_freqs(vox_hip_engine_t *e, float *freqs, const int *pos, int seq, int dim, float theta) {
+    if (!e || !freqs || !pos || seq <= 0 || dim < 2) return -1;
+    HC(hipSetDevice(e->device));
+    Tmp t;
+    std::vector<float> f;
+    host_inv_freq(f, dim, theta);
+    int *dpos = t.up(pos, (size_t)seq);
+    float *df = t.up(f.data(), f.size()), *dout = t.get<float>((size_t)seq * (dim / 2) * 2);
+    KNULL(dpos); KNULL(df); KNULL(dout);
+    hipLaunchKernelGGL(k_rope_freqs, dim3(grid1d((size_t)seq * (dim / 2))), dim3(256), 0, e->stream, dout, (const int *)dpos, seq,
+                       dim / 2, (const float *)df);
+    LAUNCH_CHECK("rope_freqs");
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMemcpy(freqs, dout, (size_t)seq * (dim / 2) * 2 * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int vox_hip_k_apply_rope(vox_hip_engine_t *e, float *x, const float *freqs, int seq, int heads, int head_dim) {
+    if (!e || !x || !freqs || seq <= 0 || heads <= 0 || head_dim < 2) return -1;
+    HC(hipSetDevice(e->device));
+    Tmp t;
+    const int hidden = heads * head_dim;
+    float *dx = t.up(x, (size_t)seq * hidden), *df = t.up(freqs, (size_t)seq * (head_dim / 2) * 2);
+    KNULL(dx); KNULL(df);
+    hipLaunchKernelGGL(k_rope_apply, dim3(grid1d((size_t)seq * hidden / 2)), dim3(256), 0, e->stream, dx, hidden, seq, hidden,
+                       head_dim, (const float *)df);
+    LAUNCH_CHECK("apply_rope");
+    HC(hipStreamSynchronize(e->stream));
+    HC(hipMemcpy(x, dx, (size_t)seq * hidden * 4, hipMemcpyDeviceToHost));
     return 0;
 }

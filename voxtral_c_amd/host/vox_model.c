@@ -60,6 +60,7 @@ static int update_time_conditioning(vox_ctx_t *ctx) {
         ctx->t_cond[i + half] = sinf(e);
     }
     float *hid = (float *)malloc((size_t)A * sizeof(float));
+    if (!hid) { fprintf(stderr, "vox: out of memory in time conditioning\n"); return -1; }
     for (int l = 0; l < L; l++) {
         for (int i = 0; i < A; i++) {
             const float *row = ctx->ada_down[l] + (size_t)i * D;
@@ -374,8 +375,8 @@ float *vox_adapter_forward(vox_ctx_t *ctx, const float *enc_out, int enc_seq_len
 }
 
 /* Batch encoder incl. its own conv stem (reference vox_encoder_forward, voxtral_encoder.c:135).
- * The reference's batch conv right-pads odd inputs; the stream path never does, and this
- * entry point is not on the stream/CLI path — odd inputs drop the unpaired last frame. */
+ * Like the reference's batch conv (vox_causal_conv1d, voxtral_kernels.c:293-340) an odd number of
+ * frames is right-padded with one zero frame: ceil(mel_frames / 2) rows come out. */
 float *vox_encoder_forward(vox_ctx_t *ctx, const float *mel, int mel_frames, int *out_seq_len) {
     if (out_seq_len) *out_seq_len = 0;
     if (!ctx || mel_frames <= 0) return NULL;
@@ -385,7 +386,13 @@ float *vox_encoder_forward(vox_ctx_t *ctx, const float *mel, int mel_frames, int
     const int rows_cap = mel_frames / 2 + 1;
     float *x = (float *)malloc((size_t)rows_cap * ctx->dims.enc_dim * sizeof(float));
     if (!x) return NULL;
-    const int rows = vox_hip_conv_stem(e, mel, mel_frames, x, rows_cap);
+    int rows = vox_hip_conv_stem(e, mel, mel_frames, x, rows_cap);
+    if (rows < 0) { free(x); return NULL; }
+    if (mel_frames & 1) {
+        const int extra = vox_hip_conv_stem_pad_odd(e, x + (size_t)rows * ctx->dims.enc_dim);
+        if (extra < 0) { free(x); return NULL; }
+        rows += extra;
+    }
     if (rows <= 0) { free(x); return NULL; }
     int n = 0;
     float *out = vox_encoder_forward_incremental(ctx, x, rows, &n);

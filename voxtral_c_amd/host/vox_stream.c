@@ -68,9 +68,11 @@ struct vox_stream {
     double enc_ms, dec_ms, prefill_ms;
     int n_generated, n_text;
 
-    /* extensions: id history + optional logit recording */
-    int *ids; int n_ids, ids_cap;
+    /* extensions (tests, tooling): opt-in id history, logit recording, teacher forcing */
+    int *ids; int n_ids, ids_cap, ids_on;
     float *rec; int rec_rows, rec_cap;
+    int n_steps;                /* decoder steps since vox_stream_init (restarts do not reset it) */
+    const int *forced; int n_forced;
 };
 
 static double now_ms(void) {
@@ -91,7 +93,7 @@ static void q_push(vox_stream_t *s, const char *alts[VOX_MAX_ALT]) {
     if (next == s->q_head) {
         const int ncap = s->q_cap * 2;
         const char **nq = (const char **)calloc((size_t)ncap * VOX_MAX_ALT, sizeof(char *));
-        if (!nq) return;
+        if (!nq) { fprintf(stderr, "vox_stream: out of memory growing the token queue; a token was dropped\n"); return; }
         int n = 0;
         for (int i = s->q_head; i != s->q_tail; i = (i + 1) % s->q_cap, n++)
             memcpy(&nq[n * VOX_MAX_ALT], &s->q[i * VOX_MAX_ALT], VOX_MAX_ALT * sizeof(char *));
@@ -136,24 +138,32 @@ static void fill_alts(vox_stream_t *s, int best, const char *alts[VOX_MAX_ALT]) 
 }
 
 static int want_logits(const vox_stream_t *s) { return s->n_alt > 1 || s->rec_cap > 0; }
+/* the host must see every token before the next step is enqueued */
+static int step_by_step(const vox_stream_t *s) { return want_logits(s) || s->n_steps < s->n_forced; }
 
-static void note_token(vox_stream_t *s, int id) {
-    if (s->n_ids == s->ids_cap) {
-        const int nc = s->ids_cap ? s->ids_cap * 2 : 1024;
-        int *t = (int *)realloc(s->ids, (size_t)nc * sizeof(int));
-        if (!t) return;
-        s->ids = t; s->ids_cap = nc;
+/* Records the engine's own greedy id of this step (opt-in) and returns the id the stream carries
+ * forward: the engine's, or the caller's under teacher forcing (vox_stream_force_tokens). */
+static int note_token(vox_stream_t *s, int id) {
+    if (s->ids_on) {
+        if (s->n_ids == s->ids_cap) {
+            const int nc = s->ids_cap ? s->ids_cap * 2 : 1024;
+            int *t = (int *)realloc(s->ids, (size_t)nc * sizeof(int));
+            if (t) { s->ids = t; s->ids_cap = nc; }
+        }
+        if (s->n_ids < s->ids_cap) s->ids[s->n_ids++] = id;
     }
-    s->ids[s->n_ids++] = id;
     if (s->rec_cap > 0 && s->rec_rows < s->rec_cap && s->logits)
         memcpy(s->rec + (size_t)s->rec_rows++ * s->ctx->dims.vocab, s->logits, (size_t)s->ctx->dims.vocab * sizeof(float));
+    const int step = s->n_steps++;
+    return step < s->n_forced ? s->forced[step] : id;
 }
 
-/* Book-keeping shared by the prefill token and every loop token. Returns the class. */
-static tok_class_t account_token(vox_stream_t *s, int id) {
+/* Book-keeping shared by the prefill token and every loop token. Returns the class; *id becomes
+ * the token the stream carries forward (differs from the engine's only under teacher forcing). */
+static tok_class_t account_token(vox_stream_t *s, int *idp) {
     s->n_generated++;
     s->last_decode_sample = s->samples_fed;
-    note_token(s, id);
+    const int id = *idp = note_token(s, *idp);
     const tok_class_t cls = classify(s, id);
     if (cls == CLS_TEXT) {
         const char *alts[VOX_MAX_ALT];
@@ -231,13 +241,13 @@ static void run_decoder(vox_stream_t *s) {
         extern void vox_hip_reset_decoder_kv(vox_hip_engine_t *);
         vox_hip_reset_decoder_kv(s->eng);
         ctx->kv_cache_len = 0; ctx->kv_pos_offset = 0;
-        const int tok = vox_hip_decoder_prefill_stream(s->eng, s->adapter_base, prompt_len, TOK_BOS, TOK_STREAMING_PAD,
-                                                       want_logits(s) ? s->logits : NULL);
+        int tok = vox_hip_decoder_prefill_stream(s->eng, s->adapter_base, prompt_len, TOK_BOS, TOK_STREAMING_PAD,
+                                                 want_logits(s) ? s->logits : NULL);
         if (tok < 0) { fprintf(stderr, "vox_stream: prefill failed: %s\n", vox_hip_last_error()); return; }
         vox_kv_mirror_prefill(ctx, prompt_len - 1);
         vox_kv_mirror_step(ctx);
+        const tok_class_t cls = account_token(s, &tok);
         s->prev_token = tok;
-        const tok_class_t cls = account_token(s, tok);
         if (cls != CLS_TEXT && cls != CLS_EOS) s->nontext_streak++;
         if (tok == TOK_EOS) s->eos_seen = 1;
         s->gen_pos = s->adapter_base + prompt_len;
@@ -257,7 +267,7 @@ static void run_decoder(vox_stream_t *s) {
              * previous token never leaves HBM); with alternatives / logit recording the
              * host needs each row, so go one position at a time. */
             int batch = s->total_adapter - s->gen_pos;
-            if (want_logits(s)) batch = 1;
+            if (step_by_step(s)) batch = 1;
             if (batch > s->tok_scratch_cap) {
                 free(s->tok_scratch);
                 s->tok_scratch = (int *)malloc((size_t)batch * sizeof(int));
@@ -269,10 +279,10 @@ static void run_decoder(vox_stream_t *s) {
             if (got <= 0) { fprintf(stderr, "vox_stream: decode failed: %s\n", vox_hip_last_error()); break; }
             (void)V;
             for (int i = 0; i < got; i++) {
-                const int tok = s->tok_scratch[i];
-                s->prev_token = tok;
+                int tok = s->tok_scratch[i];
                 vox_kv_mirror_step(ctx);
-                const tok_class_t cls = account_token(s, tok);
+                const tok_class_t cls = account_token(s, &tok);
+                s->prev_token = tok;
                 if (cls == CLS_TEXT) n_text++;
                 else if (cls == CLS_CONTROL) { s->nontext_streak++; n_ctrl++; }
                 else if (cls == CLS_INVALID) { s->nontext_streak++; n_inval++; }
@@ -460,6 +470,11 @@ int vox_stream_token_ids(vox_stream_t *s, int *out_ids, int max) {
     if (out_ids && n > 0) memcpy(out_ids, s->ids, (size_t)n * sizeof(int));
     return out_ids ? n : s->n_ids;
 }
+void vox_stream_record_ids(vox_stream_t *s, int enable) { if (s) s->ids_on = enable != 0; }
+void vox_stream_force_tokens(vox_stream_t *s, const int *ids, int n) {
+    if (!s) return;
+    s->forced = ids; s->n_forced = ids && n > 0 ? n : 0;
+}
 void vox_stream_record_logits(vox_stream_t *s, int max_rows) {
     if (!s || max_rows <= 0) return;
     free(s->rec);
@@ -482,34 +497,48 @@ static void trim(char *t) {
     t[n - a] = 0;
 }
 
-typedef struct { char *p; size_t len, cap; } sbuf_t;
+typedef struct { char *p; size_t len, cap; int oom; } sbuf_t;
+static int sb_init(sbuf_t *b) {
+    b->p = (char *)malloc(1024); b->len = 0; b->cap = 1024; b->oom = 0;
+    if (!b->p) return -1;
+    b->p[0] = 0;
+    return 0;
+}
 static void sb_drain(sbuf_t *b, vox_stream_t *s) {
     const char *tk[64];
     int n;
     while ((n = vox_stream_get(s, tk, 64)) > 0)
-        for (int i = 0; i < n; i++) {
+        for (int i = 0; i < n && !b->oom; i++) {
             const size_t l = strlen(tk[i]);
             if (b->len + l + 1 > b->cap) {
-                while (b->len + l + 1 > b->cap) b->cap *= 2;
-                b->p = (char *)realloc(b->p, b->cap);
+                size_t nc = b->cap;
+                while (b->len + l + 1 > nc) nc *= 2;
+                char *t = (char *)realloc(b->p, nc);
+                if (!t) { b->oom = 1; break; }
+                b->p = t; b->cap = nc;
             }
             memcpy(b->p + b->len, tk[i], l);
             b->len += l;
             b->p[b->len] = 0;
         }
 }
+/* the transcript, or NULL (and nothing leaked) if memory ran out while collecting it */
+static char *sb_finish(sbuf_t *b) {
+    if (b->oom) { fprintf(stderr, "vox_transcribe: out of memory\n"); free(b->p); return NULL; }
+    trim(b->p);
+    return b->p;
+}
 
 char *vox_transcribe_audio(vox_ctx_t *ctx, const float *samples, int n_samples) {
     vox_stream_t *s = vox_stream_init(ctx);
     if (!s) return NULL;
+    sbuf_t b;
+    if (sb_init(&b)) { vox_stream_free(s); return NULL; }
     vox_stream_feed(s, samples, n_samples);
     vox_stream_finish(s);
-    sbuf_t b = {(char *)malloc(1024), 0, 1024};
-    b.p[0] = 0;
     sb_drain(&b, s);
     vox_stream_free(s);
-    trim(b.p);
-    return b.p;
+    return sb_finish(&b);
 }
 
 char *vox_transcribe(vox_ctx_t *ctx, const char *wav_path) {
@@ -558,8 +587,8 @@ char *vox_transcribe_stdin(vox_ctx_t *ctx) {
         const float f[2] = {v[0] / 32768.0f, v[1] / 32768.0f};
         vox_stream_feed(s, f, 2);
     }
-    sbuf_t b = {(char *)malloc(1024), 0, 1024};
-    b.p[0] = 0;
+    sbuf_t b;
+    if (sb_init(&b)) { vox_stream_free(s); return NULL; }
     int16_t raw[4096];
     float fb[4096];
     for (;;) {
@@ -570,6 +599,5 @@ char *vox_transcribe_stdin(vox_ctx_t *ctx) {
         sb_drain(&b, s);
     }
     vox_stream_free(s);
-    trim(b.p);
-    return b.p;
+    return sb_finish(&b);
 }

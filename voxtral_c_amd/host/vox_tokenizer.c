@@ -10,6 +10,7 @@
 extern int vox_verbose;
 
 #define TEKKEN_SPECIAL 1000
+#define TEKKEN_MAX_VOCAB 130072   /* reference MAX_VOCAB (voxtral_tokenizer.c:23): 131072 - 1000 */
 #define PIECE_MAX 256
 
 struct vox_tokenizer {
@@ -134,17 +135,24 @@ static void parse_entries(jc_t *c, const char *field, vox_tokenizer_t *tok, int 
         if (*c->p == '}') c->p++;
         if (rank < 0 || !val[0]) continue;
         if (is_vocab) {
+            /* same bound as the reference (rank < MAX_VOCAB = 131072 - 1000, voxtral_tokenizer.c:263):
+             * a hostile rank must neither overflow the capacity doubling nor ask for gigabytes */
+            if (rank >= TEKKEN_MAX_VOCAB) continue;
             if (rank >= tok->cap_vocab) {
                 int ncap = tok->cap_vocab ? tok->cap_vocab : 1 << 17;
                 while (ncap <= rank) ncap *= 2;
-                tok->vocab = (char **)realloc(tok->vocab, (size_t)ncap * sizeof(char *));
+                char **nv = (char **)realloc(tok->vocab, (size_t)ncap * sizeof(char *));
+                if (!nv) continue;
+                tok->vocab = nv;
                 memset(tok->vocab + tok->cap_vocab, 0, (size_t)(ncap - tok->cap_vocab) * sizeof(char *));
                 tok->cap_vocab = ncap;
             }
             char piece[PIECE_MAX];
             int n = b64_decode(val, piece, sizeof piece);
+            char *np = (char *)malloc((size_t)n + 1);
+            if (!np) continue;
             free(tok->vocab[rank]);
-            tok->vocab[rank] = (char *)malloc((size_t)n + 1);
+            tok->vocab[rank] = np;
             memcpy(tok->vocab[rank], piece, (size_t)n + 1);
             if (rank >= tok->n_vocab) tok->n_vocab = (int)rank + 1;
         } else if (rank < TEKKEN_SPECIAL) {

@@ -33,7 +33,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 PK_NAMES = ["step_begin", "gemv_qkv_rope_kv", "attn_dec", "attn_combine", "gemv_wo_resid", "gemv_swiglu",
             "gemv_w2_resid", "gemv_logits_argmax", "argmax_finish"]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (≈6.3 TB/s achievable)
-DOM_KERNEL_SUBSTR = "k_gemv3<1, 3, 3, 6, 1, 3"     # the W1;W3 + SwiGLU decode GEMV as rocprofv3 prints it
+# the W1;W3 + SwiGLU decode GEMV as rocprofv3 prints it: fused chain / launch-per-GEMV chain
+DOM_KERNEL_FUSED, DOM_KERNEL_CHAIN = "k_gemv_w13x", "k_gemv3<1, 3, 3, 6, 1, 3"
+PK_NAMES_FUSED = {"gemv_qkv_rope_kv": "fused_qkv_attn_wo"}
 
 
 def decode_bytes(d, kv_len):
@@ -164,6 +166,8 @@ def cpu_baseline(model_dir_full, preset_dims):
 
 
 def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True):
+    fused = "dec_fused" in model.active_paths()[1]
+    DOM_KERNEL_SUBSTR = DOM_KERNEL_FUSED if fused else DOM_KERNEL_CHAIN
     """roofline object of the JSON line: dominant decode kernel (w1;w3 GEMV) measured live with HIP
     events on the engine stream, plus the per-kernel table and the whole-step figure."""
     # ---- roofline of the dominant kernel, measured live with HIP events --------------------
@@ -179,9 +183,14 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True):
     v.hip.vox_hip_time_layer_repeat.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     avg_c = (C.c_double * 9)(); cnt_c = (C.c_int * 9)()
     v.hip.vox_hip_time_layer_repeat(model.engine, 100, kv_len, avg_c, cnt_c)
-    cached = {PK_NAMES[i]: round(avg_c[i], 2) for i in range(9) if cnt_c[i]}
+    cached = {(PK_NAMES_FUSED.get(PK_NAMES[i], PK_NAMES[i]) if fused else PK_NAMES[i]): round(avg_c[i], 2) for i in range(9) if cnt_c[i]}
     kernels = {}
+    if fused:      # one launch covers attention_norm .. wo: 37.7 MB of qkv rows + 25.2 MB of wo + the KV window
+        kern_bytes = dict(kern_bytes)
+        kern_bytes["fused_qkv_attn_wo"] = kern_bytes["gemv_qkv_rope_kv"] + kern_bytes["gemv_wo_resid"] + kern_bytes["attn_dec"]
     for i, name in enumerate(PK_NAMES):
+        if fused:
+            name = PK_NAMES_FUSED.get(name, name)
         if cnt[i]:
             ent = {"launches_per_token": cnt[i], "avg_us": round(avg[i], 2)}
             if name in kern_bytes:
@@ -232,7 +241,8 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True):
     floor_us = {f"eager_{g}": round(v.hip.vox_hip_time_empty_launches(model.engine, 2000, g) * 1e6, 2) for g in (256, 768)}
     floor_us.update({f"graph_{g}": round(v.hip.vox_hip_time_empty_launches_graph(model.engine, 2000, g) * 1e6, 2) for g in (256, 768)})
     roofline = {
-        "bound": "hbm", "kernel": "k_gemv3<PRO_RMS,EPI_SWIGLU,3,6,1,3> (decoder W1;W3 GEMV, 43% of the weight bytes of a token)",
+        "bound": "hbm", "kernel": ("k_gemv_w13x" if fused else "k_gemv3<PRO_RMS,EPI_SWIGLU,3,6,1,3>") +
+                                  " (decoder W1;W3 GEMV, 43% of the weight bytes of a token)",
         "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_ach / HBM_PEAK_GBS, 4),
         "bytes_per_launch": kern_bytes[dom] // (2 if weights == "fp8" else 1), "avg_us_per_launch": round(dom_us, 2),
         "method": "HIP events on the engine stream around 50 decode steps with and without the 26 launches of this kernel; "
@@ -324,6 +334,11 @@ def main():
         if world == 1 and args.gpus > 1 and os.environ.get("VOX_FORCE_DIST") != "1":
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
 
+    if world > 1 or os.environ.get("VOX_FORCE_DIST") == "1":
+        # torch ships its own HIP runtime: bring it up before the engine's (loaded RTLD_LOCAL) so that the process
+        # ends up with one initialised runtime for both
+        import torch
+        torch.cuda.init()
     import voxtral_c_amd as v
     from audio_util import synth_speech
     from conftest import model_dir

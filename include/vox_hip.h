@@ -168,6 +168,18 @@ void *vox_hip_device_alloc(vox_hip_engine_t *e, size_t bytes);
 void vox_hip_device_free(vox_hip_engine_t *e, void *p);
 int vox_hip_memcpy(vox_hip_engine_t *e, void *dst, const void *src, size_t bytes, int kind); /* 0 H2D, 1 D2H, 2 D2D */
 
+/* ---- several GPUs in one process (libvoxtral VOX_DEVICES): stream-ordered peer hand-offs ----------
+ * A hand-off = peer copy on the producer's stream + event + hipStreamWaitEvent on the consumer's stream: the
+ * host only enqueues, there is no host synchronisation per layer.  Both engines may sit on one device (tests). */
+int vox_hip_enable_peer(vox_hip_engine_t *a, vox_hip_engine_t *b);
+int vox_hip_clone_encoder_weights(vox_hip_engine_t *dst, vox_hip_engine_t *src);           /* load time, synchronous */
+int vox_hip_mel_queue_push(vox_hip_engine_t *src, vox_hip_engine_t *dst, int frame0, int n); /* synchronous (chunk set-up) */
+int vox_hip_mel_queue_drop(vox_hip_engine_t *e, int n);
+int vox_hip_shard_kv_push(vox_hip_engine_t *src, vox_hip_engine_t *dst, int layer, int pos_first, int n);
+int64_t vox_hip_adapter_extend(vox_hip_engine_t *e, int n_rows);                           /* first new logical row or -1 */
+int vox_hip_shard_end_push(vox_hip_engine_t *src, vox_hip_engine_t *owner, int64_t first_row);
+int vox_hip_encoder_state_push(vox_hip_engine_t *src, vox_hip_engine_t *dst);
+
 /* ---- state ---------------------------------------------------------------------- */
 void vox_hip_reset_encoder(vox_hip_engine_t *e);   /* mel queue, conv tails, encoder KV, 4x residual */
 void vox_hip_reset_decoder(vox_hip_engine_t *e);   /* decoder KV + adapter buffer */
@@ -227,9 +239,10 @@ enum vox_hip_path {
     VOX_PATH_GEMV3            = 1u << 5,   /* decode GEMVs: k_gemv3 (LDS-DMA activations, ordered queue)   */
     VOX_PATH_FP8_DECODE       = 1u << 6,   /* fp8 decode weights in use (config 5 only)                    */
     VOX_PATH_SKINNY_ENC       = 1u << 7,   /* streaming encoder chunks (<= 32 rows) on the weight-streaming kernels */
+    VOX_PATH_DEC_FUSED        = 1u << 8,   /* decode step: qkv + attention + wo as one launch (k_dec_attn_fused), 3 launches per layer */
 };
 #define VOX_PATH_ALL_BF16 (VOX_PATH_GEMM_MFMA_BF16X3 | VOX_PATH_GEMM_MFMA_F32 | VOX_PATH_GEMM_SPLITK | \
-                           VOX_PATH_ATTN_ENC_MFMA | VOX_PATH_ATTN_DEC_DPP | VOX_PATH_GEMV3)
+                           VOX_PATH_ATTN_ENC_MFMA | VOX_PATH_ATTN_DEC_DPP | VOX_PATH_GEMV3 | VOX_PATH_DEC_FUSED | VOX_PATH_SKINNY_ENC)
 unsigned vox_hip_active_paths(const vox_hip_engine_t *e);
 
 /* Experiment: seconds per pass over ONE decoder layer's five kernels run back to back (weights

@@ -57,6 +57,8 @@ extern "C" {
 #define VOX_MAX_ALT          4
 
 /* Geometry discovered from consolidated.safetensors at load time. */
+#define VOX_MAX_DEVICES 8
+
 typedef struct vox_model_dims {
     int mel_bins;
     int enc_dim, enc_layers, enc_heads, enc_head_dim, enc_hidden, enc_window;
@@ -83,6 +85,11 @@ typedef struct vox_ctx {
     int enc_kv_cache_len, enc_kv_pos_offset;
     int use_bf16;               /* always 1: weights stay bf16 in HBM */
     void *tokenizer;            /* vox_tokenizer_t shared by the streams of this model (parsed once) */
+    /* Extra GPUs of a multi-device model (vox_load_opts_t.devices / VOX_DEVICES=0,1,...): encoder-only engines that take
+     * contiguous position ranges of a large first chunk (exact context parallelism, host/vox_multi.c).  engine above is
+     * shard_engines[0]'s peer on devices[0] and runs everything else (streaming chunks, prefill, decode). */
+    void *shard_engines[VOX_MAX_DEVICES];
+    int n_shard_engines;        /* engines taking part in a sharded chunk, including `engine` (1 = single GPU) */
 } vox_ctx_t;
 
 /* Optional load parameters (vox_load uses the defaults; the environment variables
@@ -93,6 +100,10 @@ typedef struct vox_load_opts {
     int dec_window;    /* decoder sliding window, default 8192 */
     int weight_format; /* 0 = bf16 as stored (default); 1 = fp8 e4m3 copies of the decoder matrices for
                           the decode GEMVs (BASELINE config 5; env VOX_WEIGHTS=fp8) */
+    int n_devices;     /* > 1: BASELINE config 4 - devices[0] runs the stream (= device above when n_devices <= 1), the others
+                          join it for the encoder of a large first chunk (env VOX_DEVICES=0,1,2,...).  Entries may repeat
+                          (several engines on one GPU: how a 1-GPU box tests the path). */
+    int devices[VOX_MAX_DEVICES];
 } vox_load_opts_t;
 
 /* ---- model lifetime (reference voxtral.h:217-223) ------------------------------- */

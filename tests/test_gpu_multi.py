@@ -62,6 +62,35 @@ def test_one_clip_per_rank_sharded_encoders_parallel_decoders(tmp_path, preset, 
             assert np.array_equal(got, single), rank
 
 
+@pytest.mark.parametrize("preset,seconds,devices", [("small", 40.0, "0,0"), ("small", 70.0, "0,0,0"), ("tiny", 30.0, "0,0,0,0")])
+def test_in_library_multi_device_encoder_matches_single_gpu(preset, seconds, devices):
+    """libvoxtral's own multi-GPU path (VOX_DEVICES / vox_load_opts_t.devices, host/vox_multi.c): no Python, no torch -
+    N engines in one process, the first chunk's encoder positions split over them, K/V tails pushed engine to engine
+    behind each layer (peer copy + event, stream-ordered), adapter rows written into the stream engine's buffer, encoder
+    state handed back for the incremental tail.  On a 1-GPU box all engines sit on device 0 (the hand-offs are then plain
+    D2D copies; events, ordering and bookkeeping are those of N GPUs).  Token ids must equal the single-engine run, for one
+    big feed and for a feed pattern whose first chunk is large and whose later chunks are incremental."""
+    import voxtral_c_amd as v
+    audio = synth_speech(seconds, 55)
+    win = {} if preset != "tiny" else dict(enc_window=48, dec_window=64)
+    with v.Model(model_dir(preset), **win) as m:
+        want = m.transcribe(audio)["tokens"]
+        half = len(audio) // 2
+        want2 = m.transcribe(audio, feed_sizes=[half, 16000, 16000, len(audio)])["tokens"]
+    os.environ["VOX_DEVICES"] = devices
+    try:
+        with v.Model(model_dir(preset), **win) as mm:
+            assert mm.ctx.n_shard_engines == len(devices.split(","))
+            got = mm.transcribe(audio)["tokens"]
+            got_again = mm.transcribe(audio)["tokens"]
+            got2 = mm.transcribe(audio, feed_sizes=[half, 16000, 16000, len(audio)])["tokens"]
+    finally:
+        del os.environ["VOX_DEVICES"]
+    assert len(want) > 100
+    assert np.array_equal(got, want) and np.array_equal(got_again, want)
+    assert np.array_equal(got2, want2) and np.array_equal(want2, want)
+
+
 def test_rccl_backend_single_rank_bench_path(tmp_path):
     """The RCCL ("nccl") code path of bench.py --gpus N (GPU-resident staging tensors handed to
     the engine by data_ptr, device-side adapter append, all_reduce of the timing) with the only

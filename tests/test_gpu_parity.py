@@ -202,7 +202,8 @@ def test_full_shape_layers_match_live_reference(small, ref_small):
     try:
         small.reset_encoder()
         errs = []
-        for n in (160, 37, 700, 120):          # 1017 rows > window 750: rolling window in play
+        # 1075 rows > window 750: rolling window in play; 25 / 1 / 32 rows take the weight-streaming path of vox_skinny.h
+        for n in (160, 25, 37, 700, 1, 32, 120):
             x = rng.standard_normal((n, d.enc_dim)).astype(np.float32)
             r = ref_small.encoder_forward_incremental(ctx, x, d.enc_dim)
             e = small.encoder_forward_incremental(x)
@@ -450,6 +451,34 @@ def test_fast_decode_kernels_at_long_context_and_ring_wrap(vox, n_prompt, window
     assert f0 == f1
     assert same >= min(n_steps, 95), same          # the wrap (step 88) is inside the compared range
     assert err < LOGIT_TOL, err
+
+
+def test_fused_decode_step_matches_the_launch_per_gemv_chain(vox):
+    """k_dec_attn_fused + k_gemv_w13x (3 launches per layer, in-kernel hand-offs inside a KV-head group) against
+    the 5-launch chain it replaces (VOX_HIP_NO_FUSED=1), full geometry: same ids, logits equal up to the changed
+    summation order of the K-split output projection and of the partial merge.  The golden tests pin the fused
+    path to the reference; this pins it to the chain on an input with no golden, with the batched launch pattern
+    (no per-step host sync) and with per-step recording."""
+    audio = synth_speech(14.0, 123)
+    with vox.Model(model_dir("full")) as m:
+        assert "dec_fused" in m.active_paths()[1]
+        a = m.transcribe(audio, record_logits=256)
+        b = m.transcribe(audio)
+        assert "dec_fused" in m.active_paths()[1], "a hand-off timed out: the engine fell back to the chain"
+    os.environ["VOX_HIP_NO_FUSED"] = "1"
+    try:
+        with vox.Model(model_dir("full")) as m2:
+            assert "dec_fused" not in m2.active_paths()[1]
+            c = m2.transcribe(audio, record_logits=256)
+    finally:
+        del os.environ["VOX_HIP_NO_FUSED"]
+    n = min(len(a["tokens"]), len(c["tokens"]))
+    same = int(np.argmax(a["tokens"][:n] != c["tokens"][:n])) if (a["tokens"][:n] != c["tokens"][:n]).any() else n
+    err = float(np.abs(a["logits"][:same + 1] - c["logits"][:same + 1]).max())
+    diag("fused_vs_chain", steps=int(n), same_steps=same, max_logit_diff=err)
+    assert n > 150 and np.array_equal(a["tokens"], b["tokens"])
+    assert err < 2e-4, err
+    assert same == n, (same, n)
 
 
 def test_production_kernels_are_the_ones_running(vox, small):

@@ -126,23 +126,28 @@ int main(int argc, char **argv) {
     int eq = d.enc_heads * d.enc_head_dim;
     int dq = d.dec_heads * d.dec_head_dim, dkv = d.dec_kv_heads * d.dec_head_dim;
 #define STD(fan) (1.0f / sqrtf((float)(fan)))
-    /* Residual-branch gains and attention sharpness.  With unit gains a 32 + 26 layer random-init
-     * stack collapses: near-uniform attention adds the same mean-V vector to every position in every
-     * layer, the per-position signal drowns, and the greedy stream degenerates to one or two ids
-     * (round-1 checkpoint: 2 distinct tokens in 61 steps), which makes token-id parity vacuous.
-     * A smaller attention output projection (x0.3) keeps the per-position signal alive through the
-     * depth and 4x larger query weights make the softmax peaky, so attention transports position-
-     * specific content; the position-wise FFN branch keeps unit gain.  Measured with the reference
-     * (oracle/_ref) on the 30 s night1968 clip at the "deep" geometry: 356 distinct ids in 386 steps
-     * (5 with unit gains); the distinct count and the margin histogram of every golden are stored in
-     * the fixture (tools/make_golden.py).
-     * Overridable through the environment for tuning only (tests and goldens use the defaults). */
-    const float enc_gain = getenv("SYNTH_ENC_GAIN") ? (float)atof(getenv("SYNTH_ENC_GAIN")) : 1.0f;
-    const float dec_gain = getenv("SYNTH_DEC_GAIN") ? (float)atof(getenv("SYNTH_DEC_GAIN")) : 1.0f;
-    const float enc_wo = getenv("SYNTH_ENC_WO") ? (float)atof(getenv("SYNTH_ENC_WO")) : 0.3f;
-    const float dec_wo = getenv("SYNTH_DEC_WO") ? (float)atof(getenv("SYNTH_DEC_WO")) : 0.3f;
-    const float enc_qk = getenv("SYNTH_ENC_QK") ? (float)atof(getenv("SYNTH_ENC_QK")) : 4.0f;
-    const float dec_qk = getenv("SYNTH_DEC_QK") ? (float)atof(getenv("SYNTH_DEC_QK")) : 4.0f;
+    /* Residual-branch gains and attention sharpness.  Two failure modes bracket the choice:
+     *  - unit gains: a 32 + 26 layer random-init stack collapses - near-uniform attention adds the same
+     *    mean-V vector to every position in every layer, the per-position signal drowns and the greedy
+     *    stream degenerates (round-1 checkpoint: 2 distinct ids in 61 steps), so id parity is vacuous;
+     *  - sharp attention + unit FFN gain (wo x0.3, wq x4): 356 distinct ids in 386 steps, but the stack is
+     *    chaotic - a 1e-6 relative perturbation of the audio moves the reference's OWN logits by 2e-2 at
+     *    the full depth, so no two summation orders can agree to 1e-3 (measured with oracle/_ref, "deep" geometry, 30 s night1968 clip).
+     * In between: shallow stacks (<= 4 layers: the tiny / small presets) take wo x0.3, wq x2 (peaky
+     * attention that exercises the window logic, amplification ~4e2 at worst); deep stacks take a nearly
+     * linear residual stream (wo x0.05, w2 x0.15, wq x1): the argmax follows the audio through conv stem,
+     * encoder and adapter (64 distinct ids in 386 steps at the deep geometry), the worst-step
+     * amplification of a 1e-6 input perturbation is 9e2 (median 3e1), top-2 margins stay >= 2e-3.
+     * The distinct-id count and the margin histogram of every golden are stored in the fixture
+     * (tools/make_golden.py).  Overridable through the environment for tuning only. */
+    const int enc_deep = d.enc_layers > 4, dec_deep = d.dec_layers > 4;
+    #define GAIN_ENV(name, dflt) (getenv(name) ? (float)atof(getenv(name)) : (dflt))
+    const float enc_gain = GAIN_ENV("SYNTH_ENC_GAIN", enc_deep ? 0.15f : 1.0f);
+    const float dec_gain = GAIN_ENV("SYNTH_DEC_GAIN", dec_deep ? 0.15f : 1.0f);
+    const float enc_wo = GAIN_ENV("SYNTH_ENC_WO", enc_deep ? 0.05f : 0.3f);
+    const float dec_wo = GAIN_ENV("SYNTH_DEC_WO", dec_deep ? 0.05f : 0.3f);
+    const float enc_qk = GAIN_ENV("SYNTH_ENC_QK", enc_deep ? 1.0f : 2.0f);
+    const float dec_qk = GAIN_ENV("SYNTH_DEC_QK", dec_deep ? 1.0f : 2.0f);
     /* tok_embeddings: logits std ~3 (realistic range); adapter output is scaled to a
      * comparable norm below so that the previous-token feedback visibly steers the
      * greedy sequence (a constant-token sequence would make id parity vacuous). */

@@ -38,11 +38,12 @@ class _Ctx(C.Structure):
                 ("t_cond", f32p), ("ada_scale", f32p), ("ada_down", C.c_void_p), ("ada_up", C.c_void_p),
                 ("kv_cache_len", C.c_int), ("kv_cache_max", C.c_int), ("kv_pos_offset", C.c_int),
                 ("enc_kv_cache_len", C.c_int), ("enc_kv_pos_offset", C.c_int), ("use_bf16", C.c_int),
-                ("tokenizer", C.c_void_p)]
+                ("tokenizer", C.c_void_p), ("shard_engines", C.c_void_p * 8), ("n_shard_engines", C.c_int)]
 
 
 class _LoadOpts(C.Structure):
-    _fields_ = [("device", C.c_int), ("enc_window", C.c_int), ("dec_window", C.c_int), ("weight_format", C.c_int)]
+    _fields_ = [("device", C.c_int), ("enc_window", C.c_int), ("dec_window", C.c_int), ("weight_format", C.c_int),
+                ("n_devices", C.c_int), ("devices", C.c_int * 8)]
 
 
 class _Timing(C.Structure):
@@ -148,8 +149,8 @@ def _fp(a):
 
 # vox_hip.h enum vox_hip_path
 PATHS = {"gemm_mfma_bf16x3": 1 << 0, "gemm_mfma_f32": 1 << 1, "gemm_splitk": 1 << 2, "attn_enc_mfma": 1 << 3,
-         "attn_dec_dpp": 1 << 4, "gemv3": 1 << 5, "fp8_decode": 1 << 6, "skinny_enc": 1 << 7}
-PATH_ALL_BF16 = sum(v for k, v in PATHS.items() if k not in ("fp8_decode", "skinny_enc"))
+         "attn_dec_dpp": 1 << 4, "gemv3": 1 << 5, "fp8_decode": 1 << 6, "skinny_enc": 1 << 7, "dec_fused": 1 << 8}
+PATH_ALL_BF16 = sum(v for k, v in PATHS.items() if k != "fp8_decode")
 
 
 def device_count():
@@ -174,8 +175,12 @@ def load_wav(path):
 class Model:
     """vox_load / vox_free (+ the stage-level functions of voxtral.h:309-328)."""
 
-    def __init__(self, model_dir, device=0, enc_window=0, dec_window=0, weights="bf16"):
+    def __init__(self, model_dir, device=0, enc_window=0, dec_window=0, weights="bf16", devices=None):
         opts = _LoadOpts(device, enc_window, dec_window, 1 if weights == "fp8" else 0)
+        if devices:
+            opts.n_devices = len(devices)
+            for i, dv in enumerate(devices):
+                opts.devices[i] = dv
         self._ctx = lib.vox_load_ex(os.fsencode(model_dir), C.byref(opts))
         if not self._ctx:
             raise VoxError(f"vox_load failed for {model_dir}: {hip.vox_hip_last_error().decode()}")

@@ -1,0 +1,605 @@
+// vox_decfuse.h — the attention half of a decoder step as ONE launch (4B geometry).
+//
+// Replaces, per layer and per token, three launches of the launch-per-GEMV chain
+//     k_gemv3<RMS,QKV> (37.7 MB)  ->  k_attn_dec (KV window)  ->  k_gemv3<ATTN,RESID> Wo (25.2 MB)
+// (reference voxtral_decoder.c:653-676: attention_norm, wq/wk/wv, RoPE, KV append, attention, wo).
+// Measured in round 1 (profiles/r01_run7_kernel_stats.csv): 9.6 + 6.3 + 9.0 us for 63 MB = 2.5 TB/s —
+// these three short kernels carry most of the decode step's distance to the HBM roofline, because each
+// pays a kernel boundary, a first-byte latency and a drain for 4-6 us of actual streaming.
+//
+// What makes one launch possible without a grid-wide barrier: the chain is all-to-all only at its two
+// ends.  In between it splits into 8 independent strands, one per KV head g:
+//     q heads 4g..4g+3 (512 rows of Wq), k / v head g (128 rows each)  ->  attention of those 4 heads
+//     ->  their 512 columns of Wo (a K-split of the output projection).
+// A strand is run by a group of 32 workgroups (grid = 8 x 32 = 256 = one workgroup per CU, group =
+// blockIdx % 8 so that a group sits on one XCD when placement follows the usual b % 8 rule — for speed
+// only, nothing depends on it).  Inside a group two hand-offs are needed: the 768 q/k/v values every
+// member needs for its key slice, and the split-K attention partials every member needs to merge.  Both
+// use data-tagged 8-byte {epoch, value} granules written with one write-through (sc1) store and swept
+// with L1-bypassing loads until every tag matches (MI355X_MICROARCH.md, visibility section, form R2):
+// no flag, no fence, the data is the flag.  The epoch is the engine's launch counter, so buffers are
+// reused launch after launch without clearing.
+//
+// Memory queue of a workgroup (a CU returns loads in issue order, so order = schedule):
+//   t0  inv_freq, x, norm weights                by LDS-DMA   (needed first)
+//       6 weight rows per wave (36 x 16 B/lane)  registers, non-temporal, piece-major
+//       first half of this workgroup's Wo slice  by LDS-DMA   (96 rows x 512 columns = 96 KB in LDS)
+//   t1  (weights consumed piece by piece as they land: explicit s_waitcnt vmcnt(N); the weight loads
+//        are inline asm so that the compiler's own wait counting cannot over-wait on the younger DMA)
+//       second half of the Wo slice, publish q/k/v, sweep the group's q/k/v  (lands behind the Wo
+//        stream: by then every producer has long published), attention over this workgroup's key
+//        slice, publish the partial, sweep the partials, merge, Wo partial product from LDS.
+// Output: wo_part[g][3072], the 8 K-split partial sums of the projection; the next launch
+// (k_gemv_w13x, below) adds them to the residual stream in a fixed order in its prologue.
+//
+// Every spin is bounded (wall clock); a timeout sets *err and the host re-runs the batch on the
+// launch-per-GEMV chain and keeps it (vox_hip_active_paths loses VOX_PATH_DEC_FUSED).
+#pragma once
+#include "vox_common.h"
+
+namespace vox {
+
+constexpr int DF_GROUPS = 8, DF_BPG = 32, DF_BLOCKS = DF_GROUPS * DF_BPG;
+constexpr int DF_D = 3072, DF_DQ = 4096, DF_DKV = 1024, DF_HD = 128;
+constexpr int DF_NQ = 512;                    // q values per group (4 heads x 128)
+constexpr int DF_GQ = DF_NQ + 2 * DF_HD;      // granules of the q/k/v hand-off per group
+constexpr int DF_GP = 4 * DF_HD + 8;          // granules of one attention partial: o[4][128], (m, l)[4]
+constexpr int DF_WO_ROWS = DF_D / DF_BPG;     // 96 rows of Wo per workgroup
+
+typedef unsigned long long u64;
+
+struct DecFuseArgs {
+    const uint16_t *wqkv;      // [6144][3072] bf16: q rows, then k rows, then v rows
+    const uint16_t *wo;        // [3072][4096] bf16
+    const float *x;            // [3072] residual stream (layers > 0)
+    const float *norm_w;       // [3072] attention_norm
+    float eps;
+    const float *inv_freq;     // [64], allocation padded to 1 KiB
+    float *kring, *vring;      // [kv_cap][1024]
+    int kv_cap, pos, window;
+    float scale;
+    // layer 0: x = adapter[st->adapter_row] + tok_emb[st->token]  (voxtral.c:1057-1061), also written to x_out
+    const float *adapter; const uint16_t *tok_emb; const DecState *st; float *x_out;
+    u64 *gq;                   // [8][DF_GQ]
+    u64 *gp;                   // [8][32][DF_GP]
+    float *wo_part;            // [8][3072]
+    unsigned epoch;
+    int split_keys, nsplit;    // keys per slice (multiple of 64), active slices (<= 32)
+    unsigned *err;
+    unsigned long long spin_limit;   // wall_clock64 ticks
+    unsigned long long *trace;       // optional (tuning): [2 blocks][16] wall-clock stamps of the phases, blocks 0 and 255
+};
+// stamps stay in registers until the end: a store in the middle would shift the hand-counted s_waitcnt vmcnt values
+#define DF_MARK(k) do { if (a.trace) df_stamp[k] = wall_clock64(); } while (0)
+
+__device__ __forceinline__ void df_store_granule(u64 *g, unsigned epoch, float v) {
+    __hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 df_load_granule(const u64 *g) {
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Re-read one granule until its tag is this launch's epoch (bounded).  Returns the payload.
+__device__ __forceinline__ float df_wait_granule(const u64 *g, unsigned epoch, const DecFuseArgs &a, unsigned code) {
+    u64 v = df_load_granule(g);
+    if ((unsigned)(v >> 32) != epoch) {
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
+            __builtin_amdgcn_s_sleep(2);
+            v = df_load_granule(g);
+            if ((unsigned)(v >> 32) == epoch) break;
+            if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    return __uint_as_float((unsigned)v);
+}
+
+// 16-byte non-temporal weight load the compiler does not count (see the header comment).
+__device__ __forceinline__ void df_ld_weight(u32x4 &dst, const void *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+
+// Wave-wide sum: four DPP row steps, then the four row sums through readlane (no LDS traffic, unlike ds_bpermute
+// butterflies: measured 2.8 us for 24 of those per wave at the end of this kernel).  Result is wave-uniform.
+template <bool USE_DPP>
+__device__ __forceinline__ float df_wave_sum(float v) {
+    if constexpr (USE_DPP) {
+        v = row16_sum<true>(v);
+        const int iv = __float_as_int(v);
+        return __int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16)) +
+               __int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+    } else {
+        return wave_sum(v);
+    }
+}
+
+template <bool USE_DPP>
+__device__ __forceinline__ float df_wave_max(float v) {
+    if constexpr (USE_DPP) {
+        int x;
+        x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);  v = fmaxf(v, __int_as_float(x));
+        x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);  v = fmaxf(v, __int_as_float(x));
+        x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true); v = fmaxf(v, __int_as_float(x));
+        x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true); v = fmaxf(v, __int_as_float(x));
+        const int iv = __float_as_int(v);
+        return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16))),
+                     fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48))));
+    } else {
+        return wave_max(v);
+    }
+}
+
+constexpr int DF_THREADS = 512, DF_WAVES = 8;
+constexpr int DF_TILE = 64;                       // keys per K/V tile in LDS
+constexpr int DF_TILE_BYTES = DF_TILE * 512;      // one of K or V: 64 keys x 128 f32
+// LDS: [xs | nw] 24 KB (scratch after the projections) | K/V tiles, double buffered 2 x (32 + 32) KB | inv_freq | red
+constexpr int DF_LDS_BYTES = 2 * DF_D * 4 + 4 * DF_TILE_BYTES + 1024 + 512;
+#define DF_WAIT3(N, A, B, C) asm volatile("s_waitcnt vmcnt(%[cnt])" : "+v"(A), "+v"(B), "+v"(C) : [cnt] "n"(N) : "memory")
+#define DF_TIE4(A, B, C, D) asm volatile("" : "+v"(A), "+v"(B), "+v"(C), "+v"(D))
+
+// One K/V tile (keys t0 .. t0+63 of KV head g, clamped to last) from the ring into LDS by LDS-DMA: 8 instructions per
+// wave (4 for K, 4 for V), each moving two 512-byte head rows.  K is stored with its 16-byte chunks XOR-swizzled by the
+// key index (the DMA destination is linear, but which global chunk a lane fetches is free) so that the score phase, where
+// a lane owns a key and walks its row, reads conflict-free; V stays linear (the PV phase walks keys with lanes on dims).
+// Op k of a wave's 8 (k >> 1 = key pair, k & 1 = V).  `real` false (workgroups without a key slice) turns the op into a
+// 16-byte broadcast read of one valid address, so that every workgroup issues the same number of memory operations and
+// the hand-counted s_waitcnt values below hold for all of them.
+__device__ __forceinline__ void df_tile_op(const DecFuseArgs &a, int g, int t0, int last, unsigned kt_lds, unsigned vt_lds, int wave, int lane,
+                                           int k, bool real) {
+    const int pair = 4 * wave + (k >> 1);
+    const int key = 2 * pair + (lane >> 5);
+    int t = t0 + key; if (t > last) t = last;
+    const size_t row = (size_t)(t % a.kv_cap) * DF_DKV + g * DF_HD;
+    const int cs = lane & 31;
+    const float *src = (k & 1) ? a.vring + row + (cs << 2) : a.kring + row + ((cs ^ (key & 31)) << 2);
+    if (!real) src = a.kring;
+    glds16(src, ((k & 1) ? vt_lds : kt_lds) + (unsigned)pair * 1024u);
+}
+__device__ __forceinline__ void df_tile_dma(const DecFuseArgs &a, int g, int t0, int last, unsigned kt_lds, unsigned vt_lds, int wave, int lane) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) df_tile_op(a, g, t0, last, kt_lds, vt_lds, wave, lane, k, true);
+}
+
+template <bool EMBED, bool USE_DPP>
+__global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *xs = reinterpret_cast<float *>(smem_raw);                           // [3072] x, then [3072] norm weights (contiguous)
+    float *nw = xs + DF_D;
+    unsigned char *tiles = smem_raw + 2 * DF_D * 4;                            // [2 buffers][K tile | V tile]
+    float *frq = reinterpret_cast<float *>(tiles + 4 * DF_TILE_BYTES);         // [256] inv_freq (64 valid)
+    float *red = frq + 256;                                                    // [128]: wave sums, the 24 row results
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x % DF_GROUPS, j = blockIdx.x / DF_GROUPS;
+    const unsigned epoch = a.epoch;
+    const int pos = a.pos;
+    unsigned long long df_stamp[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    DF_MARK(0);
+
+    // ---- this workgroup's 24 weight rows: 16 of Wq, 4 of Wk, 4 of Wv; wave w streams rows 3w .. 3w+2 -------------
+    const unsigned char *rp[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int lr = 3 * wave + i;
+        const int row = lr < 16 ? DF_NQ * g + 16 * j + lr
+                      : lr < 20 ? DF_DQ + DF_HD * g + 4 * j + (lr - 16)
+                                : DF_DQ + DF_DKV + DF_HD * g + 4 * j + (lr - 20);
+        rp[i] = reinterpret_cast<const unsigned char *>(a.wqkv) + (size_t)row * (DF_D * 2) + lane * 16;
+    }
+    // ---- this workgroup's key slice ---------------------------------------------------------------------------------
+    const int ns = a.nsplit;
+    int lo = pos - a.window + 1; if (lo < 0) lo = 0;
+    const int s_lo = lo + j * a.split_keys;
+    int s_hi = s_lo + a.split_keys - 1; if (s_hi > pos) s_hi = pos;
+    const bool att_block = j < ns;
+    const int n_tiles = att_block ? (s_hi - s_lo + DF_TILE) / DF_TILE : 0;
+
+    // ---- t0: everything this workgroup will read, in the order it is needed.  A CU's memory path is one FIFO for all of
+    // its waves, so the barrier below keeps every wave's projection weights ahead of anybody's K/V tile and Wo slice. ------
+    glds16(reinterpret_cast<const unsigned char *>(a.inv_freq) + lane * 16, lds_addr(frq));     // same 1 KiB from every wave
+    if constexpr (!EMBED) {
+        // [x | norm_w] = 24 KB as three 8 KB rounds into the contiguous [xs | nw]
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const int e = p * 2048 + tid * 4;
+            const float *src = e < DF_D ? a.x + e : a.norm_w + (e - DF_D);
+            glds16(src, lds_addr(xs) + (unsigned)(p * 8192 + wave * 1024));
+        }
+    }
+    // The CU issues its waves oldest first: without this barrier wave 0 would put all of its weight loads into the CU's
+    // memory FIFO before wave 7 has issued its share of the activation vector (measured: activations landing at 4.7 us
+    // instead of ~2, and at 15 us in the 12-wave k_gemv_w13x below).
+    __builtin_amdgcn_s_barrier();
+    u32x4 w[3][6];
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) df_ld_weight(w[i][c], rp[i] + c * 1024);
+    // The first K/V tile (it does not depend on this step's q) and this workgroup's slice of Wo (registers: row i =
+    // Wo[96 j + i][512 g .. 512 g + 511] = 1 KiB, 12 rows per wave) follow the projection weights in the queue.  They are
+    // issued four at a time behind each weight piece as it lands: a wave that tried to issue them all up front would sit in
+    // the issue stage behind the CU's full memory queue instead of doing the RMSNorm and the dot products (measured: +4 us).
+    // (Issuing Wo only after the first hand-off sweep was measured too: the sweep is gated by the slowest of the group's 32
+    // producers, ~3 us behind the median, and Wo streaming during that wait is worth more than a shorter sweep.)
+    u32x4 wv[12];
+    const unsigned char *wo_src = reinterpret_cast<const unsigned char *>(a.wo) + ((size_t)(DF_WO_ROWS * j + 12 * wave) * DF_DQ + DF_NQ * g) * 2 + lane * 16;
+    const int tile_last = att_block ? s_hi : 0;
+    DF_MARK(1);
+
+    // ---- the activation vector -----------------------------------------------------------------------------------
+    if constexpr (EMBED) {
+        // layer 0: compiler-counted loads issued behind the weight stream (they wait for all of it; it is needed before
+        // the dot products anyway); the Wo slice goes after them
+        const float *arow = a.adapter + (size_t)a.st->adapter_row * DF_D;
+        const uint16_t *erow = a.tok_emb + (size_t)a.st->token * DF_D;
+        for (int e = tid * 4; e < DF_D; e += DF_THREADS * 4) {
+            float4 v = *reinterpret_cast<const float4 *>(arow + e);
+            const uint2 eb = *reinterpret_cast<const uint2 *>(erow + e);
+            v.x += bf16_lo(eb.x); v.y += bf16_hi(eb.x); v.z += bf16_lo(eb.y); v.w += bf16_hi(eb.y);
+            *reinterpret_cast<float4 *>(xs + e) = v;
+            *reinterpret_cast<float4 *>(nw + e) = *reinterpret_cast<const float4 *>(a.norm_w + e);
+            if (blockIdx.x == 0) *reinterpret_cast<float4 *>(a.x_out + e) = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) df_tile_op(a, g, s_lo, tile_last, lds_addr(tiles), lds_addr(tiles + DF_TILE_BYTES), wave, lane, k, att_block);
+#pragma unroll
+        for (int i = 0; i < 12; i++) df_ld_weight(wv[i], wo_src + (size_t)i * (DF_DQ * 2));
+        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");          // only the 18 weight loads are younger than the activation DMAs
+    }
+    __syncthreads();
+    DF_MARK(2);
+    {   // RMSNorm (voxtral_kernels.c:346-363), under the weight stream
+        float ss = 0.f;
+        for (int e = tid * 4; e < DF_D; e += DF_THREADS * 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(xs + e);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        ss = df_wave_sum<USE_DPP>(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < DF_WAVES; i++) tot += red[i];
+        const float inv = 1.0f / sqrtf(tot / (float)DF_D + a.eps);
+        for (int e = tid * 4; e < DF_D; e += DF_THREADS * 4) {
+            const float4 gw = *reinterpret_cast<const float4 *>(nw + e);
+            float4 o = *reinterpret_cast<const float4 *>(xs + e);
+            o.x = o.x * inv * gw.x; o.y = o.y * inv * gw.y; o.z = o.z * inv * gw.z; o.w = o.w * inv * gw.w;
+            *reinterpret_cast<float4 *>(xs + e) = o;
+        }
+        __syncthreads();
+    }
+    DF_MARK(3);
+
+    // RoPE factors of the 10 rotated row pairs (8 of q, 2 of k), computed by the 12 threads that will publish them while
+    // the weights are still landing: angle = pos * inv_freq, accurate cosf / sinf (voxtral_kernels.c:488-500)
+    float rope_c = 1.f, rope_s = 0.f;
+    if (tid < 10) {
+        const int in_head = tid < 8 ? (16 * j + 2 * tid) % DF_HD : 4 * j + 2 * (tid - 8);
+        const float ang = (float)pos * frq[in_head >> 1];
+        rope_c = cosf(ang); rope_s = sinf(ang);
+    }
+
+    // ---- dot products, piece by piece as the weights land ------------------------------------------------------------
+    float acc[3] = {0.f, 0.f, 0.f};
+#define DF_PIECE(C, N)                                                                                   \
+    {                                                                                                    \
+        DF_WAIT3(N, w[0][C], w[1][C], w[2][C]);                                                          \
+        const float4 x0 = *reinterpret_cast<const float4 *>(xs + (C * 64 + lane) * 8);                   \
+        const float4 x1 = *reinterpret_cast<const float4 *>(xs + (C * 64 + lane) * 8 + 4);               \
+        _Pragma("unroll") for (int i = 0; i < 3; i++)                                                    \
+            acc[i] = dot8_bf16(make_uint4(w[i][C].x, w[i][C].y, w[i][C].z, w[i][C].w), x0, x1, acc[i]);  \
+    }
+#define DF_LATE_TILE(K0)                                                                                 \
+    if constexpr (!EMBED) { _Pragma("unroll") for (int k = K0; k < K0 + 4; k++)                          \
+        df_tile_op(a, g, s_lo, tile_last, lds_addr(tiles), lds_addr(tiles + DF_TILE_BYTES), wave, lane, k, att_block); }
+#define DF_LATE_WO(I0)                                                                                   \
+    if constexpr (!EMBED) { _Pragma("unroll") for (int i = I0; i < I0 + 4; i++) df_ld_weight(wv[i], wo_src + (size_t)i * (DF_DQ * 2)); }
+    // wait for piece c = remaining weight loads 3 (5 - c) + late operations issued so far 4 c
+    // (EMBED: everything was issued and has landed already; the waits then only tie the registers to the asm loads)
+    DF_PIECE(0, 15) DF_LATE_TILE(0)
+    DF_PIECE(1, 16) DF_LATE_TILE(4)
+    DF_PIECE(2, 17) DF_LATE_WO(0)
+    DF_PIECE(3, 18) DF_LATE_WO(4)
+    DF_PIECE(4, 19) DF_LATE_WO(8)
+    DF_PIECE(5, 20)
+#undef DF_PIECE
+#undef DF_LATE_TILE
+#undef DF_LATE_WO
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float sres = df_wave_sum<USE_DPP>(acc[i]);
+        if (lane == 0) red[16 + 3 * wave + i] = sres;
+    }
+    DF_MARK(4);
+    __syncthreads();
+
+    // ---- RoPE, KV append, publish q/k/v: 12 threads, one (even, odd) row pair each ---------------------------------------
+    u64 *gq = a.gq + (size_t)g * DF_GQ;
+    if (tid < 12) {
+        const int p = tid;
+        float e0 = red[16 + 2 * p], e1 = red[16 + 2 * p + 1];
+        if (p < 10) {          // q pairs 0..7, k pairs 8..9: interleaved-pair RoPE at this position (voxtral_kernels.c:502-526)
+            const float r0 = e0 * rope_c - e1 * rope_s, r1 = e0 * rope_s + e1 * rope_c;
+            e0 = r0; e1 = r1;
+        }
+        if (p < 8) {
+            df_store_granule(gq + 16 * j + 2 * p, epoch, e0); df_store_granule(gq + 16 * j + 2 * p + 1, epoch, e1);
+        } else {
+            const bool isk = p < 10;
+            const int kl = 4 * j + 2 * (isk ? p - 8 : p - 10);
+            const size_t slot = (size_t)(pos % a.kv_cap) * DF_DKV + DF_HD * g + kl;
+            float *ring = isk ? a.kring : a.vring;
+            ring[slot] = e0; ring[slot + 1] = e1;                                   // for the following steps
+            const int gi = DF_NQ + (isk ? 0 : DF_HD) + kl;
+            df_store_granule(gq + gi, epoch, e0); df_store_granule(gq + gi + 1, epoch, e1);
+        }
+    }
+    __syncthreads();                       // xs / nw are dead from here on: 24 KB of scratch for the attention stage
+    DF_MARK(5);
+
+    float *qs = xs;                        // [512] the group's q
+    float *kvn = xs + 512;                 // [256] this step's k | v of head g
+    float *att = xs + 768;                 // [512] merged attention output of the group's 4 heads
+    float *sc = xs + 1280;                 // [4 heads][2 halves][64 keys] partial scores
+    float *pt = xs + 1792;                 // [4 heads][64 keys] softmax numerators of the current tile
+    float *cr = xs + 2048;                 // [4] rescale of the running output, [4] running max, [4] running sum
+
+    // ---- hand-off 1: sweep the group's 768 granules ------------------------------------------------------------------
+    {
+        u64 gv[2];
+        gv[0] = df_load_granule(gq + tid);
+        if (tid < 256) gv[1] = df_load_granule(gq + 512 + tid);
+        qs[tid] = (unsigned)(gv[0] >> 32) == epoch ? __uint_as_float((unsigned)gv[0]) : df_wait_granule(gq + tid, epoch, a, 1u);
+        if (tid < 256)
+            kvn[tid] = (unsigned)(gv[1] >> 32) == epoch ? __uint_as_float((unsigned)gv[1]) : df_wait_granule(gq + 512 + tid, epoch, a, 1u);
+    }
+    __syncthreads();
+    DF_MARK(6);
+
+    // ---- attention over this workgroup's key slice, 64-key tiles through LDS -------------------------------------------
+    //   scores: wave -> (head, half of the 128 dims), lane -> key: a 64-term dot per thread, halves added through LDS;
+    //   softmax: online over tiles, one wave per head reduces max / sum over its 64 keys;
+    //   PV: thread -> (head, dim), walks the tile's keys.  Arithmetic of voxtral_kernels.c:412-482 up to summation order.
+    u64 *gp = a.gp + ((size_t)g * DF_BPG) * DF_GP;
+    if (att_block) {
+        const int hs = wave >> 1, half = wave & 1;       // score phase
+        const int ho = tid >> 7, dd = tid & 127;         // PV phase
+        float o_acc = 0.f;
+        if (tid < 4) { cr[4 + tid] = -1e30f; cr[8 + tid] = 0.f; }
+        for (int ti = 0; ti < n_tiles; ti++) {
+            unsigned char *kt = tiles + (ti & 1) * 2 * DF_TILE_BYTES, *vt = kt + DF_TILE_BYTES;
+            const int t0 = s_lo + ti * DF_TILE;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this tile (and everything older) has landed
+            __syncthreads();
+            if (ti + 1 < n_tiles)                                    // next tile into the other buffer, under this tile's math
+                df_tile_dma(a, g, t0 + DF_TILE, s_hi, lds_addr(tiles + ((ti + 1) & 1) * 2 * DF_TILE_BYTES),
+                            lds_addr(tiles + ((ti + 1) & 1) * 2 * DF_TILE_BYTES + DF_TILE_BYTES), wave, lane);
+            if (t0 + DF_TILE > pos && t0 <= pos) {
+                // this step's own K/V row is not visible in the ring to other CUs yet: patch it in from the hand-off
+                const int key = pos - t0;
+                if (tid < 32) *reinterpret_cast<float4 *>(kt + key * 512 + ((tid ^ (key & 31)) << 4)) = *reinterpret_cast<const float4 *>(kvn + tid * 4);
+                else if (tid < 64) *reinterpret_cast<float4 *>(vt + key * 512 + ((tid - 32) << 4)) = *reinterpret_cast<const float4 *>(kvn + DF_HD + (tid - 32) * 4);
+                __syncthreads();
+            }
+            {   // partial scores: this thread's key x 64 dims of head hs
+                const unsigned char *krow = kt + lane * 512;
+                const float *qh = qs + hs * DF_HD + half * 64;
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    const float4 kv4 = *reinterpret_cast<const float4 *>(krow + (((half * 16 + c) ^ (lane & 31)) << 4));
+                    const float4 q4 = *reinterpret_cast<const float4 *>(qh + c * 4);
+                    s = fmaf(q4.x, kv4.x, s); s = fmaf(q4.y, kv4.y, s); s = fmaf(q4.z, kv4.z, s); s = fmaf(q4.w, kv4.w, s);
+                }
+                sc[(hs * 2 + half) * 64 + lane] = s;
+            }
+            __syncthreads();
+            if (half == 0) {   // one wave per head: online softmax over this tile's keys
+                float s = (sc[(hs * 2) * 64 + lane] + sc[(hs * 2 + 1) * 64 + lane]) * a.scale;
+                if (t0 + lane > s_hi) s = -INFINITY;
+                const float m_old = cr[4 + hs], l_old = cr[8 + hs];
+                const float m_new = fmaxf(m_old, df_wave_max<USE_DPP>(s));
+                const float p = expf(s - m_new);
+                const float corr = expf(m_old - m_new);
+                const float l_new = l_old * corr + df_wave_sum<USE_DPP>(p);
+                pt[hs * 64 + lane] = p;
+                if (lane == 0) { cr[hs] = corr; cr[4 + hs] = m_new; cr[8 + hs] = l_new; }
+            }
+            __syncthreads();
+            {   // PV: out[ho][dd] = out * corr + sum_k p[ho][k] * V[k][dd]
+                const float *pr = pt + ho * 64;
+                const float *vcol = reinterpret_cast<const float *>(vt) + dd;
+                float accv = 0.f;
+#pragma unroll 16
+                for (int k = 0; k < DF_TILE; k++) accv = fmaf(pr[k], vcol[k * 128], accv);
+                o_acc = o_acc * cr[ho] + accv;
+            }
+        }
+        __syncthreads();
+        {   // this slice's partial, published as granules: thread -> (head, dim)
+            u64 *mine = gp + (size_t)j * DF_GP;
+            df_store_granule(mine + ho * DF_HD + dd, epoch, o_acc);
+            if (dd == 0) { df_store_granule(mine + 4 * DF_HD + 2 * ho, epoch, cr[4 + ho]); df_store_granule(mine + 4 * DF_HD + 2 * ho + 1, epoch, cr[8 + ho]); }
+        }
+    }
+    DF_MARK(7);
+
+    // ---- hand-off 2: sweep the group's partials and merge them in slice order (thread -> head, dim) ---------------------
+    {
+        const int h = tid >> 7, d = tid & 127;
+        float M = -1e30f, L = 0.f, O = 0.f;
+        for (int s0 = 0; s0 < ns; s0 += 4) {           // 4 slices = 12 loads in flight per thread, then check the tags
+            u64 gv[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const u64 *part = gp + (size_t)min(s0 + u, ns - 1) * DF_GP;
+                gv[u][0] = df_load_granule(part + h * DF_HD + d);
+                gv[u][1] = df_load_granule(part + 4 * DF_HD + 2 * h);
+                gv[u][2] = df_load_granule(part + 4 * DF_HD + 2 * h + 1);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (s0 + u >= ns) break;
+                const u64 *part = gp + (size_t)(s0 + u) * DF_GP;
+                const u64 *src[3] = {part + h * DF_HD + d, part + 4 * DF_HD + 2 * h, part + 4 * DF_HD + 2 * h + 1};
+                float val[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    val[k] = (unsigned)(gv[u][k] >> 32) == epoch ? __uint_as_float((unsigned)gv[u][k]) : df_wait_granule(src[k], epoch, a, 2u);
+                const float mn = fmaxf(M, val[1]);
+                const float c0 = expf(M - mn), c1 = expf(val[1] - mn);
+                L = L * c0 + val[2] * c1;
+                O = O * c0 + val[0] * c1;
+                M = mn;
+            }
+        }
+        att[h * DF_HD + d] = L > 0.f ? O / L : 0.f;
+    }
+    DF_MARK(8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the Wo slice has landed in its registers
+    DF_TIE4(wv[0], wv[1], wv[2], wv[3]); DF_TIE4(wv[4], wv[5], wv[6], wv[7]); DF_TIE4(wv[8], wv[9], wv[10], wv[11]);
+    __syncthreads();
+    DF_MARK(9);
+
+    // ---- this workgroup's 96 rows of  Wo[:, 512 g .. 512 g + 511] . att  (12 per wave) ---------------------------------------
+    {
+        const float4 x0 = *reinterpret_cast<const float4 *>(att + lane * 8);
+        const float4 x1 = *reinterpret_cast<const float4 *>(att + lane * 8 + 4);
+        float mine = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const float s = df_wave_sum<USE_DPP>(dot8_bf16(make_uint4(wv[i].x, wv[i].y, wv[i].z, wv[i].w), x0, x1, 0.f));
+            if (lane == i) mine = s;
+        }
+        if (lane < 12) a.wo_part[(size_t)g * DF_D + DF_WO_ROWS * j + 12 * wave + lane] = mine;
+    }
+    DF_MARK(10);
+    if (a.trace && tid == 0 && (blockIdx.x == 0 || blockIdx.x == DF_BLOCKS - 1)) {
+#pragma unroll
+        for (int k = 0; k < 11; k++) a.trace[(blockIdx.x ? 16 : 0) + k] = df_stamp[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_gemv_w13x — the FFN up-projection of a decoder step behind k_dec_attn_fused:
+//     x' = x + sum_g wo_part[g]  (fixed order)  ->  ffn_norm, ada scaling  ->  silu(W1 x) * (W3 x)
+// (voxtral_decoder.c:676-687).  Same memory-queue discipline as k_gemv3, but ONE 768-thread workgroup per
+// CU (12 waves, 3 row pairs of W1/W3 each: 36 x 16 B per lane in flight) instead of three 256-thread ones,
+// so that the nine 12 KB vectors of the prologue are staged once per CU (LDS-DMA, 132 KB).  Block 0 writes
+// x' back (the W2 launch reads it as its residual).
+// ---------------------------------------------------------------------------------------------------------
+struct W13xArgs {
+    const uint16_t *w1, *w3;   // [9216][3072] each
+    const float *x;            // [3072]
+    const float *wo_part;      // [8][3072]
+    const float *norm_w, *ada; // [3072]
+    float eps;
+    float *x_out;              // [3072] x' (may alias x)
+    float *h;                  // [9216]
+    unsigned long long *trace; // optional (tuning): [2 blocks][16] stamps, written at +32
+};
+constexpr int W13X_THREADS = 768;
+constexpr int W13X_LDS_BYTES = (9 + 2 + 1) * DF_D * 4 + 256;
+
+__global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *stage = smem;                 // [9][3072]: x, wo_part[0..7]
+    float *nws = smem + 9 * DF_D;        // [3072] norm weights
+    float *ads = nws + DF_D;             // [3072] ada
+    float *xs = ads + DF_D;              // [3072]
+    float *red = xs + DF_D;              // [16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wofs = (unsigned)wave * 1024u;        // 12 waves x 1 KiB = one 12 KB vector per DMA round
+    unsigned long long df_stamp[6] = {0, 0, 0, 0, 0, 0};
+    DF_MARK(0);
+
+    glds16(a.x + tid * 4, lds_addr(stage) + wofs);
+#pragma unroll
+    for (int gi = 0; gi < 8; gi++) glds16(a.wo_part + (size_t)gi * DF_D + tid * 4, lds_addr(stage + (gi + 1) * DF_D) + wofs);
+    glds16(a.norm_w + tid * 4, lds_addr(nws) + wofs);
+    glds16(a.ada + tid * 4, lds_addr(ads) + wofs);
+    __builtin_amdgcn_sched_barrier(0);
+    // Weight stream in three rounds of two 1 KiB pieces per row.  A CU's memory queue holds far less than this kernel's
+    // 574 KB per CU, and a wave that issues more than fits waits IN the issue stage: with everything issued up front the
+    // slowest of the 12 waves reached the prologue barrier only after ~15 us (measured), so the sum / RMSNorm and all dot
+    // products ran after the stream instead of under it.  Round 0 (144 KB per CU) is issued before the prologue and covers
+    // it; rounds 1 and 2 are issued as the previous round's dot products retire.
+    uint4 w[2][3][6];
+    const int pair0 = blockIdx.x * 36 + wave * 3;
+    const uint4 *p1[3], *p3[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        p1[r] = reinterpret_cast<const uint4 *>(a.w1 + (size_t)(pair0 + r) * DF_D) + lane;
+        p3[r] = reinterpret_cast<const uint4 *>(a.w3 + (size_t)(pair0 + r) * DF_D) + lane;
+    }
+#define W13_ISSUE(C)                                                                    \
+    { _Pragma("unroll") for (int r = 0; r < 3; r++) w[0][r][C] = ld_stream(p1[r] + (C) * 64); \
+      _Pragma("unroll") for (int r = 0; r < 3; r++) w[1][r][C] = ld_stream(p3[r] + (C) * 64); }
+    W13_ISSUE(0) W13_ISSUE(1)
+    __builtin_amdgcn_sched_barrier(0);
+    DF_MARK(1);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // the 11 DMAs are in; round 0 of the weights still streams
+    __syncthreads();
+    DF_MARK(2);
+    {
+        float4 v = *reinterpret_cast<const float4 *>(stage + tid * 4);
+#pragma unroll
+        for (int gi = 1; gi <= 8; gi++) {
+            const float4 p = *reinterpret_cast<const float4 *>(stage + gi * DF_D + tid * 4);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        if (blockIdx.x == 0) *reinterpret_cast<float4 *>(a.x_out + tid * 4) = v;
+        float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; i++) tot += red[i];
+        const float inv = 1.0f / sqrtf(tot / (float)DF_D + a.eps);
+        const float4 gw = *reinterpret_cast<const float4 *>(nws + tid * 4);
+        const float4 sc = *reinterpret_cast<const float4 *>(ads + tid * 4);
+        v.x = v.x * inv * gw.x * (1.0f + sc.x); v.y = v.y * inv * gw.y * (1.0f + sc.y);
+        v.z = v.z * inv * gw.z * (1.0f + sc.z); v.w = v.w * inv * gw.w * (1.0f + sc.w);
+        *reinterpret_cast<float4 *>(xs + tid * 4) = v;
+        __syncthreads();
+    }
+    DF_MARK(3);
+    float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#define W13_DOT(C)                                                                      \
+    {                                                                                   \
+        const float4 x0 = *reinterpret_cast<const float4 *>(xs + ((C) * 64 + lane) * 8);     \
+        const float4 x1 = *reinterpret_cast<const float4 *>(xs + ((C) * 64 + lane) * 8 + 4); \
+        _Pragma("unroll") for (int m = 0; m < 2; m++)                                   \
+            _Pragma("unroll") for (int r = 0; r < 3; r++) acc[m][r] = dot8_bf16(w[m][r][C], x0, x1, acc[m][r]); \
+    }
+    W13_ISSUE(2) W13_ISSUE(3)
+    __builtin_amdgcn_sched_barrier(0);
+    W13_DOT(0) W13_DOT(1)
+    __builtin_amdgcn_sched_barrier(0);
+    W13_ISSUE(4) W13_ISSUE(5)
+    __builtin_amdgcn_sched_barrier(0);
+    W13_DOT(2) W13_DOT(3)
+    __builtin_amdgcn_sched_barrier(0);
+    W13_DOT(4) W13_DOT(5)
+#undef W13_ISSUE
+#undef W13_DOT
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) acc[m][r] = wave_sum(acc[m][r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) a.h[pair0 + r] = silu(acc[0][r]) * acc[1][r];      // voxtral_decoder.c:684-687
+    }
+    DF_MARK(4);
+    if (a.trace && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 255)) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) a.trace[32 + (blockIdx.x ? 16 : 0) + k] = df_stamp[k];
+    }
+}
+
+}  // namespace vox

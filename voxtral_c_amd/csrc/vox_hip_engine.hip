@@ -26,6 +26,8 @@
 #include "vox_misc.h"
 #include "vox_attn.h"
 #include "vox_kernel_api.h"
+#include "vox_decfuse.h"
+#include "vox_skinny.h"
 
 using namespace vox;
 
@@ -35,6 +37,7 @@ static void set_err(const char *what, hipError_t e, const char *file, int line) 
     snprintf(buf, sizeof buf, "vox_hip: %s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
     g_err = buf;
     fprintf(stderr, "%s\n", buf);
+    (void)hipGetLastError();      // the runtime's last-error word is sticky: leave it clean for the per-step launch checks
 }
 #define HC(call)                                                        \
     do {                                                                \
@@ -90,6 +93,7 @@ struct vox_hip_engine {
     vox_hip_dims_t d{};
     int enc_qd = 0, dec_qd = 0, dec_kvd = 0;
     size_t mem_used = 0;
+    bool use_skinny = true;
     bool use_dpp = true, use_mfma = true, use_gemv2 = true, use_gemv3 = true, use_splitk = true, use_bf16x3 = true, use_attn_mfma = true;
 
     // weights
@@ -125,13 +129,22 @@ struct vox_hip_engine {
     unsigned skip_kinds = 0;            // timing experiments only: PK_* launches left out of a step
     bool use_fp8 = false;               // decode GEMVs stream the fp8 copies (vox_hip_quantize_decoder_fp8)
     uint8_t *tok_emb8 = nullptr; float *stok = nullptr;
+    // fused attention half of the decode step (vox_decfuse.h)
+    bool use_fused = false;
+    u64 *d_gq = nullptr, *d_gp = nullptr;
+    float *d_wo_part = nullptr;
+    unsigned *d_fuse_err = nullptr;
+    unsigned fuse_epoch = 0;
+    unsigned long long *d_fuse_trace = nullptr;
+    int fuse_failures = 0;
     int *d_tokens = nullptr;
     float *dpart_o = nullptr, *dpart_ml = nullptr;   // decode-step split-K partials (max splits)
     int dec_max_split = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     vox_hip_timing_t timing{};
-    // multi-GPU shard in flight (vox_hip_shard_*)
+    // multi-GPU shard in flight (vox_hip_shard_*), events for cross-engine stream ordering
+    std::vector<hipEvent_t> xev; size_t xev_next = 0;
     float *shard_x = nullptr; int shard_n = 0;
     // per-kernel profiling of the decode step (HIP events between launches)
     bool prof_on = false;
@@ -386,10 +399,11 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
     rc |= dalloc(e, &e->cosT, (size_t)MEL_NFFT * MEL_NFREQ);
     rc |= dalloc(e, &e->sinT, (size_t)MEL_NFFT * MEL_NFREQ);
     rc |= dalloc(e, &e->filtT, (size_t)MEL_NFREQ * d.mel_bins);
-    rc |= dalloc(e, &e->enc_inv_freq, d.enc_head_dim / 2);
-    rc |= dalloc(e, &e->dec_inv_freq, d.dec_head_dim / 2);
+    rc |= dalloc(e, &e->enc_inv_freq, 256);          // padded to 1 KiB: k_dec_attn_fused fetches the table with one LDS-DMA
+    rc |= dalloc(e, &e->dec_inv_freq, 256);
     rc |= dalloc(e, &e->dec_rope, d.dec_head_dim);
     if (rc) return fail();
+    HCV(hipMemset(e->enc_inv_freq, 0, 1024)); HCV(hipMemset(e->dec_inv_freq, 0, 1024));
     {
         std::vector<float> f;
         host_inv_freq(f, d.enc_head_dim, d.rope_theta);
@@ -413,6 +427,30 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
     // adapter buffer: 4096 rows to start with (grows / compacts on demand)
     e->adapter_cap = 4096;
     if (dalloc(e, &e->adapter, (size_t)e->adapter_cap * DD)) return fail();
+
+    // fused attention half of the decode step: exact 4B decoder shapes on a 256-CU part (one workgroup per CU)
+    {
+        hipDeviceProp_t prop;
+        const bool geom = d.dec_dim == DF_D && e->dec_qd == DF_DQ && e->dec_kvd == DF_DKV && d.dec_hidden == 9216 &&
+                          d.dec_head_dim == DF_HD && d.dec_heads == 32 && d.dec_kv_heads == DF_GROUPS;
+        if (geom && !getenv("VOX_HIP_NO_FUSED") && !getenv("VOX_HIP_NO_GEMV3") && !getenv("VOX_HIP_NO_GEMV2") && !getenv("VOX_HIP_CUMASK") &&
+            hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount == DF_BLOCKS) {
+            bool ok = dalloc(e, &e->d_gq, (size_t)DF_GROUPS * DF_GQ) == 0 && dalloc(e, &e->d_gp, (size_t)DF_GROUPS * DF_BPG * DF_GP) == 0 &&
+                      dalloc(e, &e->d_wo_part, (size_t)DF_GROUPS * DF_D) == 0 && dalloc(e, &e->d_fuse_err, 64) == 0;
+            ok = ok && hipMemset(e->d_gq, 0, (size_t)DF_GROUPS * DF_GQ * 8) == hipSuccess &&
+                 hipMemset(e->d_gp, 0, (size_t)DF_GROUPS * DF_BPG * DF_GP * 8) == hipSuccess &&
+                 hipMemset(e->d_fuse_err, 0, 64 * 4) == hipSuccess;
+            ok = ok && hipFuncSetAttribute((const void *)k_dec_attn_fused<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_dec_attn_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_dec_attn_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_dec_attn_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_gemv_w13x, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); fprintf(stderr, "vox_hip: fused decode kernels unavailable; launch-per-GEMV chain\n"); }
+            e->use_fused = ok;
+            if (ok && getenv("VOX_HIP_FUSE_TRACE") && hipMalloc((void **)&e->d_fuse_trace, 64 * 8) == hipSuccess)
+                hipMemset(e->d_fuse_trace, 0, 64 * 8);
+        }
+    }
 
     // state-carrying stream buffers (zero = "start of sequence" left padding)
     if (ensure_keep(e, e->conv_in0, (size_t)(2 + 1024) * d.mel_bins * 4, 0)) return fail();
@@ -438,10 +476,11 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     F(e->tok_emb8); F(e->stok);
     F(e->hann); F(e->cosT); F(e->sinT); F(e->filtT); F(e->enc_inv_freq); F(e->dec_inv_freq); F(e->dec_rope);
     F(e->d_st); F(e->dx); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
-    F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter);
+    F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_gq); F(e->d_gp); F(e->d_wo_part); F(e->d_fuse_err);
     Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
                    &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml, &e->ssplitk};
     for (Buf *b : bufs) F(b->p);
+    for (auto ev : e->xev) if (ev) hipEventDestroy(ev);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -657,11 +696,96 @@ static RowsCfg dec_cfg(const vox_hip_engine *e) {
 }
 
 // Encoder transformer on device rows x[n, enc_dim] (in place), then final norm into out.
+// Encoder attention of a chunk: window tail in the ring + this chunk's K/V in the merged QKV buffer.
+static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float *attn, int n, int pos0, float *kring, float *vring, int ring_cap) {
+    const int N3 = c.QD + 2 * c.KVD;
+    hipStream_t s = e->stream;
+    AttnArgs a{};
+    a.out = attn; a.ldo = c.QD; a.q = qkv; a.ldq = N3; a.n_q = n; a.qpos0 = pos0;
+    a.kB = qkv + c.QD; a.vB = qkv + c.QD + c.KVD; a.ldB = N3; a.posB0 = pos0; a.last_key = pos0 + n - 1;
+    a.kA = kring; a.vA = vring; a.capA = ring_cap; a.ldA = c.KVD;
+    a.n_heads = c.heads; a.n_kv_heads = c.kv_heads; a.scale = 1.0f / sqrtf((float)c.hd); a.window = c.window; a.st = nullptr;
+    const int qt = (n + 127) / 128, blocks = qt * c.heads;
+    const int span = std::min(pos0 + n, c.window + std::min(n, 128));
+    int ks = 1;
+    if (blocks < 256) ks = std::max(1, std::min((512 + blocks - 1) / blocks, (span + 63) / 64));
+    if (ks > 1) {
+        if (ensure(e, e->spart_o, (size_t)n * c.heads * ks * c.hd * 4)) return -1;
+        if (ensure(e, e->spart_ml, (size_t)n * c.heads * ks * 2 * 4)) return -1;
+        a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
+    }
+    if (e->use_attn_mfma && c.hd == 64 && c.heads == c.kv_heads)
+        hipLaunchKernelGGL(k_attn_enc_mfma, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((k_attn_rows<64>), dim3(qt, c.heads, ks), dim3(128), 0, s, a);
+    if (ks > 1)
+        hipLaunchKernelGGL((k_attn_combine<64>), dim3(c.heads, n), dim3(64), 0, s, attn, c.QD,
+                           (const float *)a.part_o, (const float *)a.part_ml, c.heads, ks);
+    return 0;
+}
+
+// Streaming-size chunks (n <= 32 rows): the weight-streaming path of vox_skinny.h, 7-8 launches per layer.
+static bool skinny_ok(const vox_hip_engine *e, int n, const RowsCfg &c) {
+    return e->use_skinny && e->use_mfma && n >= 1 && n <= 32 && c.kv_heads == c.heads && c.hd == 64 &&
+           c.D % 64 == 0 && c.QD % 64 == 0 && c.H % 64 == 0 && c.D % 32 == 0 && (c.QD + 2 * c.KVD) % 32 == 0;
+}
+static int skinny_split(int K) { return std::max(1, std::min(16, (K / 64) / SK_WPB)); }
+
+static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
+    const RowsCfg c = enc_cfg(e);
+    const int N3 = c.QD + 2 * c.KVD, L = e->d.enc_layers, pos0 = e->enc_pos;
+    float *xn = (float *)e->sxn.p, *qkv = (float *)e->sqkv.p, *attn = (float *)e->sattn.p, *h = (float *)e->sh.p, *tab = (float *)e->srope.p;
+    hipStream_t s = e->stream;
+    const int so = skinny_split(c.QD), s2 = skinny_split(c.H);
+    if (ensure(e, e->ssplitk, (size_t)std::max(so, s2) * n * c.D * 4)) return -1;
+    float *part = (float *)e->ssplitk.p;
+    const size_t lds1 = (size_t)SK_WPB * 4096, lds2 = (size_t)SK_WPB * 2 * 4096;
+    if (L > 0)
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, s, xn, c.D, x, c.D, e->enc[0].n1, (const float *)nullptr, c.D, c.eps);
+    for (int l = 0; l < L; l++) {
+        EncLayer &Ly = e->enc[l];
+        {   // attention_norm(x) . [wq; wk; wv]^T + bias, RoPE, K/V into the merged buffer and the rings
+            SkinnyArgs a{};
+            a.X = xn; a.ldx = c.D; a.n = n; a.W = Ly.wqkv; a.N = N3; a.K = c.D; a.bias = Ly.bqkv; a.Y = qkv; a.ldy = N3;
+            a.rope_cols = c.QD + c.KVD; a.head_dim = c.hd; a.rope_tab = tab; a.kring = Ly.kring; a.vring = Ly.vring;
+            a.ring_cap = e->enc_ring_cap; a.kv_dim = c.KVD; a.pos0 = pos0; a.q_cols = c.QD;
+            hipLaunchKernelGGL((k_skinny<SK_QKV, 1>), dim3(N3 / 32, 1), dim3(64 * SK_WPB), lds1, s, a);
+        }
+        if (enc_attention(e, c, qkv, attn, n, pos0, Ly.kring, Ly.vring, e->enc_ring_cap)) return -1;
+        {   // wo as K-split partials, then x += . + bo and ffn_norm in one launch
+            SkinnyArgs a{};
+            a.X = attn; a.ldx = c.QD; a.n = n; a.W = Ly.wo; a.N = c.D; a.K = c.QD; a.partial = part;
+            hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1>), dim3(c.D / 32, so), dim3(64 * SK_WPB), lds1, s, a);
+            hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)part, so, n, c.D, (const float *)Ly.bo,
+                               (const float *)Ly.n2, c.eps, xn, c.D);
+        }
+        {   // silu(xn w1^T) * (xn w3^T)
+            SkinnyArgs a{};
+            a.X = xn; a.ldx = c.D; a.n = n; a.W = Ly.w13; a.W2 = Ly.w13 + (size_t)c.H * c.D; a.N = c.H; a.K = c.D; a.Y = h; a.ldy = c.H;
+            hipLaunchKernelGGL((k_skinny<SK_SWIGLU, 1>), dim3(c.H / 32, 1), dim3(64 * SK_WPB), lds2, s, a);
+        }
+        {   // w2 partials, then x += . + b2 and the next norm (next layer's attention_norm, or the final norm into `out`)
+            SkinnyArgs a{};
+            a.X = h; a.ldx = c.H; a.n = n; a.W = Ly.w2; a.N = c.D; a.K = c.H; a.partial = part;
+            hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1>), dim3(c.D / 32, s2), dim3(64 * SK_WPB), lds1, s, a);
+            const bool last = l + 1 == L;
+            hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)part, s2, n, c.D, (const float *)Ly.b2,
+                               (const float *)(last ? e->enc_final_norm : e->enc[l + 1].n1), c.eps, last ? out : xn, c.D);
+        }
+    }
+    if (L == 0)
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, s, out, c.D, x, c.D, e->enc_final_norm, (const float *)nullptr, c.D, c.eps);
+    e->enc_pos += n;
+    LAUNCH_CHECK("encoder chunk launches (skinny path)");
+    return 0;
+}
+
 static int encoder_rows_dev(vox_hip_engine *e, float *x, int n, float *out) {
     const RowsCfg c = enc_cfg(e);
     if (ensure_rows_scratch(e, n, c)) return -1;
     hipLaunchKernelGGL(k_rope_table, dim3(grid1d((size_t)n * c.hd / 2)), dim3(256), 0, e->stream,
                        (float *)e->srope.p, e->enc_inv_freq, e->enc_pos, n, c.hd / 2);
+    if (skinny_ok(e, n, c)) return encoder_rows_skinny(e, x, n, out);
     for (int l = 0; l < e->d.enc_layers; l++) {
         EncLayer &L = e->enc[l];
         if (run_layer_rows(e, x, n, e->enc_pos, c, L.wqkv, L.bqkv, L.wo, L.bo, L.w13, L.w2, L.b2, L.n1, L.n2,
@@ -1156,8 +1280,54 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     const int nsplit = (kv_len + split_keys - 1) / split_keys;
     const bool fuse_combine = fast && nsplit <= 8;
     const float scale = 1.0f / sqrtf((float)HD);
+    const bool fused = fast && e->use_fused && !e->use_fp8;
+    // fused path: key slices of the attention stage (<= 32 per KV head, multiples of 64 keys)
+    int f_split = 64, f_ns = 1;
+    if (fused) {
+        while ((kv_len + f_split - 1) / f_split > DF_BPG) f_split += 64;
+        f_ns = (kv_len + f_split - 1) / f_split;
+    }
     for (int l = 0; l < d.dec_layers; l++) {
         DecLayer &L = e->dec[l];
+        if (fused) {
+            if (!(e->skip_kinds & (1u << PK_QKV))) {
+                // attention_norm -> wq/wk/wv -> RoPE -> KV append -> attention -> wo (K-split partials): one launch
+                DecFuseArgs a{};
+                a.wqkv = L.wqkv; a.wo = L.wo; a.x = e->dx; a.norm_w = L.n1; a.eps = d.dec_eps; a.inv_freq = e->dec_inv_freq;
+                a.kring = L.kring; a.vring = L.vring; a.kv_cap = e->dec_ring_cap; a.pos = kv_pos; a.window = d.dec_window; a.scale = scale;
+                a.adapter = e->adapter; a.tok_emb = e->tok_emb; a.st = e->d_st; a.x_out = e->dx;
+                a.gq = e->d_gq; a.gp = e->d_gp; a.wo_part = e->d_wo_part;
+                if (++e->fuse_epoch == 0) e->fuse_epoch = 1;
+                a.epoch = e->fuse_epoch; a.split_keys = f_split; a.nsplit = f_ns;
+                a.err = e->d_fuse_err; a.spin_limit = 2000000ull;        // 20 ms at the 100 MHz wall clock
+                a.trace = (l == 13) ? e->d_fuse_trace : nullptr;          // tuning: phase stamps of one mid-stack launch
+                const bool emb = (l == 0 && build_embed);
+                if (e->use_dpp) {
+                    if (emb) hipLaunchKernelGGL((k_dec_attn_fused<true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
+                    else hipLaunchKernelGGL((k_dec_attn_fused<false, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
+                } else {
+                    if (emb) hipLaunchKernelGGL((k_dec_attn_fused<true, false>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
+                    else hipLaunchKernelGGL((k_dec_attn_fused<false, false>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
+                }
+                prof_mark(e, PK_QKV);
+            }
+            if (!(e->skip_kinds & (1u << PK_SWIGLU))) {
+                // x += sum of the wo partials -> ffn_norm * (1 + ada) -> silu(W1 x) * (W3 x)
+                W13xArgs a{};
+                a.w1 = L.w13; a.w3 = L.w13 + (size_t)DH * DD; a.x = e->dx; a.wo_part = e->d_wo_part; a.norm_w = L.n2; a.ada = L.ada;
+                a.eps = d.dec_eps; a.x_out = e->dx; a.h = e->dh;
+                a.trace = (l == 13) ? e->d_fuse_trace : nullptr;
+                hipLaunchKernelGGL(k_gemv_w13x, dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
+                prof_mark(e, PK_SWIGLU);
+            }
+            if (!(e->skip_kinds & (1u << PK_W2))) {
+                GemvArgs a{};
+                a.W = L.w2; a.x = e->dh; a.y = e->dx; a.N = DD; a.K = DH;
+                launch_gemv3<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
+                prof_mark(e, PK_W2);
+            }
+            continue;
+        }
         if (!(e->skip_kinds & (1u << PK_QKV)))
         {   // RMSNorm -> merged QKV GEMV -> RoPE -> KV append   (voxtral_decoder.c:656-665)
             GemvArgs a{};
@@ -1333,8 +1503,18 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
         for (int i = 0; i < batch; i++)
             if (enqueue_step(e, e->dec_pos + i, true, logits_out ? lg + (size_t)i * V : lg, eos_token, 1)) return -1;
         DecState st{};
+        unsigned fuse_err = 0;
         HC(hipMemcpyAsync(&st, e->d_st, sizeof st, hipMemcpyDeviceToHost, s));
+        if (e->use_fused) HC(hipMemcpyAsync(&fuse_err, e->d_fuse_err, sizeof fuse_err, hipMemcpyDeviceToHost, s));
         HC(hipStreamSynchronize(s));
+        if (fuse_err) {
+            // a hand-off inside k_dec_attn_fused timed out (its 256 workgroups were not co-resident?): the batch's
+            // results are void.  Loudly switch to the launch-per-GEMV chain for good and run the batch again.
+            fprintf(stderr, "vox_hip: ERROR fused decode kernel timed out in hand-off %u; switching to the launch-per-GEMV chain\n", fuse_err);
+            e->use_fused = false; e->fuse_failures++;
+            HC(hipMemsetAsync(e->d_fuse_err, 0, sizeof(unsigned), s));
+            continue;
+        }
         const int got = st.n_out;
         if (got > 0) HC(hipMemcpy(tokens_out + done, e->d_tokens, (size_t)got * sizeof(int), hipMemcpyDeviceToHost));
         if (logits_out && got > 0)
@@ -1502,6 +1682,18 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
     float ms = 0.f;
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
     e->dec_pos = saved_pos;
+    if (e->d_fuse_trace) {      // VOX_HIP_FUSE_TRACE: phase stamps (100 MHz wall clock) of the last layer-13 launch, blocks 0 and 255
+        unsigned long long h[64];
+        if (hipMemcpy(h, e->d_fuse_trace, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int b = 0; b < 2; b++) {
+                fprintf(stderr, "fuse trace block %d (us since start):", b ? 255 : 0);
+                for (int k = 1; k <= 10; k++) fprintf(stderr, " %d:%.2f", k, (double)(h[b * 16 + k] - h[b * 16]) / 100.0);
+                fprintf(stderr, "\n  w13x block %d: kernel start %.2f us after the fused kernel's start;", b ? 255 : 0,
+                        (double)(h[32 + b * 16] - h[b * 16]) / 100.0);
+                for (int k = 1; k <= 4; k++) fprintf(stderr, " %d:%.2f", k, (double)(h[32 + b * 16 + k] - h[32 + b * 16]) / 100.0);
+                fprintf(stderr, "\n");
+            }
+    }
     return (double)ms * 1e-3 / iters;
 }
 
@@ -1746,6 +1938,11 @@ static int self_test(vox_hip_engine *e) {
     if (getenv("VOX_HIP_NO_GEMV2")) e->use_gemv2 = false;
     if (getenv("VOX_HIP_NO_GEMV3")) e->use_gemv3 = false;
     if (getenv("VOX_HIP_NO_SPLITK")) e->use_splitk = false;
+    if (getenv("VOX_HIP_NO_SKINNY")) e->use_skinny = false;
+    if (hipFuncSetAttribute((const void *)k_skinny<SK_SWIGLU, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_WPB * 2 * 4096) != hipSuccess) {
+        (void)hipGetLastError();
+        e->use_skinny = false;
+    }
     hipFree(dx); hipFree(dy0); hipFree(dy1); hipFree(dy2); hipFree(dw); hipFree(dbias);
     if (failed) {
         // A production kernel disagreeing with its plain cross-check is a broken build or device, not a
@@ -1775,6 +1972,8 @@ extern "C" unsigned vox_hip_active_paths(const vox_hip_engine_t *e) {
     if (e->use_splitk) m |= VOX_PATH_GEMM_SPLITK;
     if (fast_geom && e->use_gemv2 && e->use_gemv3) m |= VOX_PATH_GEMV3;
     if (e->use_fp8) m |= VOX_PATH_FP8_DECODE;
+    if (fast_geom && e->use_fused && !e->use_fp8) m |= VOX_PATH_DEC_FUSED;
+    if (e->use_skinny && e->use_mfma) m |= VOX_PATH_SKINNY_ENC;
     return m;
 }
 
@@ -1921,4 +2120,176 @@ extern "C" int vox_hip_k_apply_rope(vox_hip_engine_t *e, float *x, const float *
     HC(hipStreamSynchronize(e->stream));
     HC(hipMemcpy(x, dx, (size_t)seq * hidden * 4, hipMemcpyDeviceToHost));
     return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Several GPUs in ONE process (libvoxtral's VOX_DEVICES): stream-ordered peer hand-offs between engines.
+// The exact context-parallel encoder of SURVEY 8(e) / DESIGN.md without a host round trip per layer: a
+// hand-off is a peer copy (xGMI; plain D2D when both engines sit on one device, which is how a 1-GPU box
+// tests this) enqueued on the PRODUCER's stream right behind the kernels that produced the data, an event,
+// and a hipStreamWaitEvent on the CONSUMER's stream.  The host only enqueues.
+// ------------------------------------------------------------------------------------
+static int peer_copy_async(vox_hip_engine *dst, void *dptr, vox_hip_engine *src, const void *sptr, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return 0;
+    if (dst->device == src->device) HC(hipMemcpyAsync(dptr, sptr, bytes, hipMemcpyDeviceToDevice, s));
+    else HC(hipMemcpyPeerAsync(dptr, dst->device, sptr, src->device, bytes, s));
+    return 0;
+}
+// consumer's stream waits for everything enqueued so far on the producer's stream
+static int chain_streams(vox_hip_engine *producer, vox_hip_engine *consumer) {
+    if (producer == consumer) return 0;
+    HC(hipSetDevice(producer->device));
+    if (producer->xev.empty()) {
+        producer->xev.resize(64);
+        for (auto &ev : producer->xev) HC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    hipEvent_t ev = producer->xev[producer->xev_next++ % producer->xev.size()];
+    HC(hipEventRecord(ev, producer->stream));
+    HC(hipStreamWaitEvent(consumer->stream, ev, 0));
+    return 0;
+}
+
+extern "C" int vox_hip_enable_peer(vox_hip_engine_t *a, vox_hip_engine_t *b) {
+    if (!a || !b) return -1;
+    if (a->device == b->device) return 0;
+    int can = 0;
+    HC(hipDeviceCanAccessPeer(&can, a->device, b->device));
+    if (can) {
+        HC(hipSetDevice(a->device));
+        hipError_t r = hipDeviceEnablePeerAccess(b->device, 0);
+        if (r != hipSuccess && r != hipErrorPeerAccessAlreadyEnabled) { set_err("hipDeviceEnablePeerAccess", r, __FILE__, __LINE__); return -1; }
+        (void)hipGetLastError();
+    }
+    return 0;       // without peer access the copies are staged by the runtime: slower, still correct
+}
+
+// Encoder-side weights (conv stem, encoder layers, adapter, final norm, mel tables) of `src` into `dst` (same geometry):
+// the extra GPUs of a multi-device model only ever run encoder shards.  Synchronous (load time).
+extern "C" int vox_hip_clone_encoder_weights(vox_hip_engine_t *dst, vox_hip_engine_t *src) {
+    if (!dst || !src || dst->d.enc_layers != src->d.enc_layers || dst->d.enc_dim != src->d.enc_dim || dst->d.enc_hidden != src->d.enc_hidden ||
+        dst->d.dec_dim != src->d.dec_dim || dst->d.mel_bins != src->d.mel_bins) { g_err = "vox_hip_clone_encoder_weights: geometry mismatch"; return -1; }
+    const vox_hip_dims_t &d = src->d;
+    const size_t ED = d.enc_dim, EQ = src->enc_qd, EH = d.enc_hidden, DD = d.dec_dim;
+    HC(hipSetDevice(src->device));
+    HC(hipStreamSynchronize(src->stream));
+    hipStream_t s = src->stream;
+    auto cp = [&](void *dp, const void *sp, size_t bytes) { return peer_copy_async(dst, dp, src, sp, bytes, s); };
+    int rc = 0;
+    rc |= cp(dst->conv0_w, src->conv0_w, ED * d.mel_bins * 3 * 2); rc |= cp(dst->conv1_w, src->conv1_w, ED * ED * 3 * 2);
+    rc |= cp(dst->conv0_b, src->conv0_b, ED * 4); rc |= cp(dst->conv1_b, src->conv1_b, ED * 4);
+    rc |= cp(dst->adapter0, src->adapter0, DD * ED * 4 * 2); rc |= cp(dst->adapter1, src->adapter1, DD * DD * 2);
+    rc |= cp(dst->enc_final_norm, src->enc_final_norm, ED * 4);
+    rc |= cp(dst->hann, src->hann, MEL_NFFT * 4); rc |= cp(dst->cosT, src->cosT, (size_t)MEL_NFFT * MEL_NFREQ * 4);
+    rc |= cp(dst->sinT, src->sinT, (size_t)MEL_NFFT * MEL_NFREQ * 4); rc |= cp(dst->filtT, src->filtT, (size_t)MEL_NFREQ * d.mel_bins * 4);
+    for (int l = 0; l < d.enc_layers && !rc; l++) {
+        EncLayer &S = src->enc[l], &D = dst->enc[l];
+        rc |= cp(D.wqkv, S.wqkv, 3 * EQ * ED * 2); rc |= cp(D.wo, S.wo, ED * EQ * 2); rc |= cp(D.w13, S.w13, 2 * EH * ED * 2); rc |= cp(D.w2, S.w2, ED * EH * 2);
+        rc |= cp(D.bqkv, S.bqkv, 3 * EQ * 4); rc |= cp(D.bo, S.bo, ED * 4); rc |= cp(D.b2, S.b2, ED * 4); rc |= cp(D.n1, S.n1, ED * 4); rc |= cp(D.n2, S.n2, ED * 4);
+    }
+    if (rc) return -1;
+    HC(hipStreamSynchronize(s));
+    return 0;
+}
+
+// Frames [frame0, frame0 + n) of src's device mel queue, appended to dst's queue.  Synchronous (set-up of a sharded chunk).
+extern "C" int vox_hip_mel_queue_push(vox_hip_engine_t *src, vox_hip_engine_t *dst, int frame0, int n) {
+    if (!src || !dst || n <= 0 || frame0 < 0 || frame0 + n > src->mel_q) { g_err = "vox_hip_mel_queue_push: frames not queued"; return -1; }
+    const int MB = src->d.mel_bins;
+    HC(hipSetDevice(dst->device));
+    if (ensure_keep(dst, dst->conv_in0, (size_t)(2 + dst->mel_q + n) * MB * 4, (size_t)(2 + dst->mel_q) * MB * 4)) return -1;
+    HC(hipSetDevice(src->device));
+    HC(hipStreamSynchronize(src->stream));
+    if (peer_copy_async(dst, (float *)dst->conv_in0.p + (size_t)(2 + dst->mel_q) * MB, src, (const float *)src->conv_in0.p + (size_t)(2 + frame0) * MB,
+                        (size_t)n * MB * 4, src->stream)) return -1;
+    HC(hipStreamSynchronize(src->stream));
+    dst->mel_q += n;
+    return 0;
+}
+
+// Drop the first n queued mel frames (they were handed to other engines).
+extern "C" int vox_hip_mel_queue_drop(vox_hip_engine_t *e, int n) {
+    if (!e || n < 0 || n > e->mel_q) return -1;
+    if (n == 0) return 0;
+    HC(hipSetDevice(e->device));
+    const int MB = e->d.mel_bins, left = e->mel_q - n;
+    float *in0 = (float *)e->conv_in0.p;
+    if (left > 0) {
+        if (ensure(e, e->stmp_in, (size_t)left * MB * 4)) return -1;
+        HC(hipMemcpyAsync(e->stmp_in.p, in0 + (size_t)(2 + n) * MB, (size_t)left * MB * 4, hipMemcpyDeviceToDevice, e->stream));
+        HC(hipMemcpyAsync(in0 + (size_t)2 * MB, e->stmp_in.p, (size_t)left * MB * 4, hipMemcpyDeviceToDevice, e->stream));
+    }
+    e->mel_q = left;
+    return 0;
+}
+
+// Layer-l K/V rows of positions [pos_first, pos_first + n) from src's ring straight into the same slots of dst's ring,
+// behind src's layer-l kernels; dst's stream waits for them before whatever is enqueued next on it.
+extern "C" int vox_hip_shard_kv_push(vox_hip_engine_t *src, vox_hip_engine_t *dst, int layer, int pos_first, int n) {
+    if (!src || !dst || layer < 0 || layer >= src->d.enc_layers || n <= 0 || src->enc_ring_cap != dst->enc_ring_cap) return -1;
+    const int kvd = src->enc_qd, cap = src->enc_ring_cap;
+    if (n > cap) { g_err = "vox_hip_shard_kv_push: more rows than the ring holds"; return -1; }
+    HC(hipSetDevice(src->device));
+    for (int i = 0; i < n;) {
+        const int slot = (pos_first + i) % cap;
+        const int run = std::min(n - i, cap - slot);
+        if (peer_copy_async(dst, dst->enc[layer].kring + (size_t)slot * kvd, src, src->enc[layer].kring + (size_t)slot * kvd, (size_t)run * kvd * 4, src->stream)) return -1;
+        if (peer_copy_async(dst, dst->enc[layer].vring + (size_t)slot * kvd, src, src->enc[layer].vring + (size_t)slot * kvd, (size_t)run * kvd * 4, src->stream)) return -1;
+        i += run;
+    }
+    return chain_streams(src, dst);
+}
+
+// Make room for n_rows more adapter rows on the owner and account for them (their contents arrive through
+// vox_hip_shard_end_push, stream-ordered).  Returns the logical index of the first new row, or -1.
+extern "C" int64_t vox_hip_adapter_extend(vox_hip_engine_t *e, int n_rows) {
+    if (!e || n_rows <= 0) return -1;
+    if (hipSetDevice(e->device) != hipSuccess) return -1;
+    if (adapter_reserve(e, n_rows)) return -1;
+    const int64_t first = e->adapter_total;
+    e->adapter_total += n_rows;
+    return first;
+}
+
+// Final norm + adapter of the shard in flight on src; the rows land in owner's adapter buffer at logical row first_row.
+extern "C" int vox_hip_shard_end_push(vox_hip_engine_t *src, vox_hip_engine_t *owner, int64_t first_row) {
+    if (!src || !owner || !src->shard_x) return -1;
+    HC(hipSetDevice(src->device));
+    const int n = src->shard_n, ED = src->d.enc_dim, DD = src->d.dec_dim;
+    if (n % 4) { g_err = "vox_hip_shard_end_push: shard rows must be a multiple of 4"; return -1; }
+    const int m = n / 4;
+    if (first_row < owner->adapter_row0 || first_row + m > owner->adapter_total) { g_err = "vox_hip_shard_end_push: rows not reserved"; return -1; }
+    if (ensure(src, src->stmp_out, (size_t)n * ED * 4)) return -1;
+    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, src->stream, (float *)src->stmp_out.p, ED, src->shard_x, ED,
+                       src->enc_final_norm, (const float *)nullptr, ED, src->d.enc_eps);
+    float *dst_rows = owner->adapter + (size_t)(first_row - owner->adapter_row0) * DD;
+    if (src == owner) {
+        if (adapter_dev(src, (const float *)src->stmp_out.p, m, dst_rows)) return -1;
+    } else {
+        if (ensure(src, src->stmp_in, (size_t)m * DD * 4)) return -1;
+        if (adapter_dev(src, (const float *)src->stmp_out.p, m, (float *)src->stmp_in.p)) return -1;
+        if (peer_copy_async(owner, dst_rows, src, src->stmp_in.p, (size_t)m * DD * 4, src->stream)) return -1;
+        if (chain_streams(src, owner)) return -1;
+    }
+    src->enc_pos += n;                       // like a streaming chunk: the engine now stands behind its shard
+    src->shard_x = nullptr; src->shard_n = 0;
+    return m;
+}
+
+// Hand the streaming encoder state (KV rings of every layer, conv-stem history rows, 4x-alignment rows, position) of
+// src to dst, so that dst continues the stream where src's shard ended.  Stream-ordered.
+extern "C" int vox_hip_encoder_state_push(vox_hip_engine_t *src, vox_hip_engine_t *dst) {
+    if (!src || !dst || src->enc_ring_cap != dst->enc_ring_cap) return -1;
+    if (src == dst) return 0;
+    const int MB = src->d.mel_bins, ED = src->d.enc_dim;
+    const size_t ring_bytes = (size_t)src->enc_ring_cap * src->enc_qd * 4;
+    HC(hipSetDevice(src->device));
+    for (int l = 0; l < src->d.enc_layers; l++) {
+        if (peer_copy_async(dst, dst->enc[l].kring, src, src->enc[l].kring, ring_bytes, src->stream)) return -1;
+        if (peer_copy_async(dst, dst->enc[l].vring, src, src->enc[l].vring, ring_bytes, src->stream)) return -1;
+    }
+    if (peer_copy_async(dst, dst->conv_in0.p, src, src->conv_in0.p, (size_t)2 * MB * 4, src->stream)) return -1;
+    if (peer_copy_async(dst, dst->conv_in1.p, src, src->conv_in1.p, (size_t)2 * ED * 4, src->stream)) return -1;
+    if (peer_copy_async(dst, dst->enc_out.p, src, src->enc_out.p, (size_t)3 * ED * 4, src->stream)) return -1;
+    dst->enc_pos = src->enc_pos; dst->c0_carry = src->c0_carry; dst->enc_res = src->enc_res;
+    return chain_streams(src, dst);
 }

@@ -1,0 +1,212 @@
+// vox_skinny.h — transformer layer on a FEW rows (streaming encoder chunks: 25 rows at -I 0.5, 50-150 at the CLI's
+// default cadence): y[n, N] = x[n, K] . W[N, K]^T for n <= 64, HBM-bound on the bf16 weights.
+//
+// Replaces, for small n, the large-M path of run_layer_rows (13 launches per layer: 128 x 128 MFMA tiles that are 80 %
+// padding at n = 25, split-K reduce launches, separate RoPE / ring-append / SiLU / RMSNorm kernels).  Measured in round 1
+// (gpurun_out/prof_stream/r1_kernel_stats.csv): ~130 us per layer for a 25-row chunk against 60.3 MB / 6.3 TB/s = 9.6 us.
+// Reference: vox_encoder_forward_incremental, voxtral_encoder.c:452-636 (same arithmetic: exact bf16 weights x f32
+// activations, f32 accumulation; here through the exact 3-term bf16 split of the activations on v_mfma_f32_32x32x16_bf16).
+//
+// One wave = one 32-row tile of W (the MFMA's B operand, 16 bytes per lane straight from global memory in fragment
+// layout: lane (li, lg) reads W[row0 + li][k + 8 lg .. +7]) x all n activation rows (A operand: x[m][k + 8 lg .. +7] as
+// f32 from L2, split into hi / mid / lo bf16 in registers) x a set of 64-wide K chunks.  No LDS staging and no barrier
+// in the main loop: every wave streams independently with the next chunk's loads in flight under the current chunk's
+// MFMAs.  The waves of a workgroup (WPB = 8) share a W tile and split K; their accumulators are added in wave order
+// through LDS (deterministic), then the epilogue runs on the 32 x 32 (or 64 x 32) tile:
+//   EPI_QKV     + bias, interleaved-pair RoPE from the chunk's table, q/k/v to the merged QKV buffer AND k/v straight into
+//               the position-indexed rings (voxtral_encoder.c:542-567)
+//   EPI_SWIGLU  two W tiles per wave (w1 rows and the matching w3 rows): h = silu(x w1^T) * (x w3^T)  (:598-612)
+//   EPI_PARTIAL raw partial sums of a K split (wo, w2: only 40 row tiles, so K is split over blockIdx.y);
+// k_rows_finish then adds the partials in split order + bias + residual and applies the NEXT RMSNorm in the same launch
+// (voxtral_encoder.c:585-596, 614-628).  Per layer: qkv, attention (+ combine), wo, finish, w1;w3, w2, finish = 7-8
+// launches instead of 13.
+#pragma once
+#include "vox_common.h"
+#include "vox_gemm.h"
+
+namespace vox {
+
+enum { SK_PARTIAL = 0, SK_QKV = 1, SK_SWIGLU = 2 };
+constexpr int SK_WPB = 8;                 // waves per workgroup (K splitters of one W tile)
+
+struct SkinnyArgs {
+    const float *X; int ldx; int n;       // [n][K] activations, n <= 32 * MT
+    const uint16_t *W, *W2;               // [N][K] bf16; W2 = up-projection rows (SK_SWIGLU)
+    int N, K;
+    const float *bias;                    // [N] or null (SK_QKV)
+    float *Y; int ldy;                    // SK_QKV: merged qkv [n][N]; SK_SWIGLU: h [n][N]
+    float *partial;                       // SK_PARTIAL: [gridDim.y][n][N]
+    int rope_cols, head_dim;              // SK_QKV: columns [0, rope_cols) are rotated (q then k), pairs (2c, 2c+1)
+    const float *rope_tab;                // [n][head_dim/2][2] cos, sin of this chunk's positions
+    float *kring, *vring; int ring_cap, kv_dim, pos0, q_cols;   // k columns start at q_cols, v columns at q_cols + kv_dim
+};
+
+// x[m][k..k+7] (f32) -> three bf16x8 fragments (hi, mid, lo): exact split, vox_gemm.h split3
+__device__ __forceinline__ void sk_split_frag(const float4 x0, const float4 x1, bf16x8_t &fh, bf16x8_t &fm, bf16x8_t &fl) {
+    const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) split3(xv[i], h[i], m[i], l[i]);
+    union { uint32_t u[4]; bf16x8_t v; } ph, pm, pl;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        ph.u[i] = (h[2 * i] >> 16) | h[2 * i + 1];
+        pm.u[i] = (m[2 * i] >> 16) | m[2 * i + 1];
+        pl.u[i] = (l[2 * i] >> 16) | (l[2 * i + 1] & 0xffff0000u);
+    }
+    fh = ph.v; fm = pm.v; fl = pl.v;
+}
+
+// grid = (N / 32, S); block = 64 * SK_WPB.  MT = 1 (n <= 32) or 2 (n <= 64) row tiles of the activations.
+template <int EPI, int MT>
+__global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
+    constexpr int NB = (EPI == SK_SWIGLU) ? 2 : 1;              // W tiles per wave
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];   // [SK_WPB][NB][MT][1024] accumulators
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lg = lane >> 5;
+    const int row0 = blockIdx.x * 32;
+    const int nchunks = a.K / 64;
+    const int kworkers = gridDim.y * SK_WPB, kw = blockIdx.y * SK_WPB + wave;
+
+    f32x16 acc[NB][MT];
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[b][t][r] = 0.f;
+
+    const uint16_t *wrow[NB];
+    wrow[0] = a.W + (size_t)(row0 + li) * a.K + lg * 8;
+    if constexpr (NB == 2) wrow[1] = a.W2 + (size_t)(row0 + li) * a.K + lg * 8;
+    const float *xrow[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) xrow[t] = a.X + (size_t)min(t * 32 + li, a.n - 1) * a.ldx + lg * 8;
+
+    // double-buffered chunk registers; the buffer index is a compile-time constant (runtime-indexed register arrays
+    // would be demoted to scratch memory)
+    uint4 wq0[NB][4], wq1[NB][4];
+    float4 xq0[MT][4][2], xq1[MT][4][2];
+    auto issue = [&](uint4 (&wq)[NB][4], float4 (&xq)[MT][4][2], int c) {
+        const int k0 = c * 64;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) wq[b][s] = ld_stream(reinterpret_cast<const uint4 *>(wrow[b] + k0 + s * 16));
+#pragma unroll
+            for (int t = 0; t < MT; t++) {
+                xq[t][s][0] = *reinterpret_cast<const float4 *>(xrow[t] + k0 + s * 16);
+                xq[t][s][1] = *reinterpret_cast<const float4 *>(xrow[t] + k0 + s * 16 + 4);
+            }
+        }
+    };
+    auto compute = [&](const uint4 (&wq)[NB][4], const float4 (&xq)[MT][4][2]) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            bf16x8_t fa[MT][3];
+#pragma unroll
+            for (int t = 0; t < MT; t++) sk_split_frag(xq[t][s][0], xq[t][s][1], fa[t][0], fa[t][1], fa[t][2]);
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                union { uint4 u; bf16x8_t v; } fb;
+                fb.u = wq[b][s];
+#pragma unroll
+                for (int p = 2; p >= 0; p--)                   // small terms first
+#pragma unroll
+                    for (int t = 0; t < MT; t++)
+                        acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][p], fb.v, acc[b][t], 0, 0, 0);
+            }
+        }
+    };
+    int c = kw;
+    if (c < nchunks) issue(wq0, xq0, c);
+    while (c < nchunks) {
+        if (c + kworkers < nchunks) issue(wq1, xq1, c + kworkers);
+        compute(wq0, xq0);
+        c += kworkers;
+        if (c >= nchunks) break;
+        if (c + kworkers < nchunks) issue(wq0, xq0, c + kworkers);
+        compute(wq1, xq1);
+        c += kworkers;
+    }
+
+    // ---- add the K splitters of this workgroup in wave order (element e = r * 64 + lane of each 32 x 32 tile) ------------
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) sk_lds[((wave * NB + b) * MT + t) * 1024 + r * 64 + lane] = acc[b][t][r];
+    __syncthreads();
+    float *red = sk_lds;                                            // reduced tiles overwrite wave 0's slots
+    for (int e = tid; e < NB * MT * 1024; e += 64 * SK_WPB) {
+        float v = sk_lds[e];
+#pragma unroll
+        for (int w = 1; w < SK_WPB; w++) v += sk_lds[w * NB * MT * 1024 + e];
+        red[e] = v;                                                 // same index as wave 0's own slot e: no hazard
+    }
+    __syncthreads();
+
+    // ---- epilogue over the tile: e -> (tile t, r, lane) -> row m = 32 t + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31
+    for (int e = tid; e < MT * 1024; e += 64 * SK_WPB) {
+        const int t = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+        const int m = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int col = row0 + (ln & 31);
+        if (m >= a.n) continue;
+        if constexpr (EPI == SK_PARTIAL) {
+            a.partial[((size_t)blockIdx.y * a.n + m) * a.N + col] = red[e];
+        } else if constexpr (EPI == SK_SWIGLU) {
+            a.Y[(size_t)m * a.ldy + col] = silu(red[e]) * red[MT * 1024 + e];          // tile 0 = gate (w1), tile 1 = up (w3)
+        } else {
+            float v = red[e] + (a.bias ? a.bias[col] : 0.f);
+            if (col < a.rope_cols) {
+                const float o = red[e ^ 1] + (a.bias ? a.bias[col ^ 1] : 0.f);          // the pair partner: adjacent lane, same row
+                const int d = (col % a.head_dim) >> 1;
+                const float cs = a.rope_tab[((size_t)m * (a.head_dim / 2) + d) * 2], sn = a.rope_tab[((size_t)m * (a.head_dim / 2) + d) * 2 + 1];
+                v = (col & 1) ? o * sn + v * cs : v * cs - o * sn;                       // (x0 c - x1 s, x0 s + x1 c)
+            }
+            a.Y[(size_t)m * a.ldy + col] = v;
+            if (col >= a.q_cols) {                                                       // k / v also go to the ring slot of their position
+                const int slot = (a.pos0 + m) % a.ring_cap;
+                if (col < a.q_cols + a.kv_dim) a.kring[(size_t)slot * a.kv_dim + (col - a.q_cols)] = v;
+                else a.vring[(size_t)slot * a.kv_dim + (col - a.q_cols - a.kv_dim)] = v;
+            }
+        }
+    }
+}
+
+// x[m] += bias + sum_s partial[s][m]  (split order), then out_norm[m] = rmsnorm(x[m]) * w (+ada) — one block per row.
+// Covers "x += wo(attn) + bo -> ffn_norm" and "x += w2(h) + b2 -> next layer's attention_norm / the final norm".
+__global__ __launch_bounds__(256) void k_rows_finish(float *x, int ldx, const float *partial, int nsplit, int n, int D,
+                                                     const float *bias, const float *norm_w, float eps, float *out_norm, int ldo) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    float *xr = x + (size_t)m * ldx;
+    float ss = 0.f;
+    for (int i = tid * 4; i < D; i += 1024) {
+        float4 v = *reinterpret_cast<const float4 *>(xr + i);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < nsplit; z++) {
+            const float4 p = *reinterpret_cast<const float4 *>(partial + ((size_t)z * n + m) * D + i);
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        if (bias) { const float4 b = *reinterpret_cast<const float4 *>(bias + i); s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w; }
+        v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;                 // x + (proj + bias): the reference's order (vox_add_inplace)
+        *reinterpret_cast<float4 *>(xr + i) = v;
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (!norm_w) return;
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)D + eps);
+    float *orow = out_norm + (size_t)m * ldo;
+    for (int i = tid * 4; i < D; i += 1024) {
+        const float4 v = *reinterpret_cast<const float4 *>(xr + i);      // own elements, written above by this thread
+        const float4 g = *reinterpret_cast<const float4 *>(norm_w + i);
+        *reinterpret_cast<float4 *>(orow + i) = make_float4(v.x * inv * g.x, v.y * inv * g.y, v.z * inv * g.z, v.w * inv * g.w);
+    }
+}
+
+}  // namespace vox

@@ -182,6 +182,18 @@ vox_ctx_t *vox_load_ex(const char *model_dir, const vox_load_opts_t *opts) {
     hd.dec_kv_heads = d->dec_kv_heads; hd.dec_head_dim = d->dec_head_dim; hd.dec_hidden = d->dec_hidden;
     hd.dec_window = d->dec_window; hd.vocab = d->vocab; hd.ada_dim = d->ada_dim;
     hd.enc_eps = VOX_ENC_NORM_EPS; hd.dec_eps = VOX_DEC_NORM_EPS; hd.rope_theta = VOX_ROPE_THETA;
+    /* devices of a multi-GPU model: opts, overridden by VOX_DEVICES=0,1,... (first entry = the stream's device) */
+    int devs[VOX_MAX_DEVICES], n_dev = 0;
+    if (opts && opts->n_devices > 1)
+        for (int i = 0; i < opts->n_devices && i < VOX_MAX_DEVICES; i++) devs[n_dev++] = opts->devices[i];
+    if ((ev = getenv("VOX_DEVICES")) && *ev) {
+        n_dev = 0;
+        for (const char *p = ev; *p && n_dev < VOX_MAX_DEVICES;) {
+            devs[n_dev++] = (int)strtol(p, (char **)&p, 10);
+            while (*p == ',' || *p == ' ') p++;
+        }
+    }
+    if (n_dev > 1) ctx->device = devs[0];
     ctx->engine = vox_hip_engine_create(ctx->device, &hd);
     if (!ctx->engine) {
         fprintf(stderr, "vox_load: cannot create the HIP engine (%s)\n", vox_hip_last_error());
@@ -248,6 +260,29 @@ vox_ctx_t *vox_load_ex(const char *model_dir, const vox_load_opts_t *opts) {
     if (!rc) rc |= update_time_conditioning(ctx);
     if (rc) { fprintf(stderr, "vox_load: failed to load weights\n"); vox_free(ctx); return NULL; }
 
+    ctx->shard_engines[0] = ctx->engine;
+    ctx->n_shard_engines = 1;
+    for (int i = 1; i < n_dev; i++) {
+        /* encoder-only peers: same encoder / adapter geometry, no decoder stack, weights cloned GPU to GPU */
+        vox_hip_dims_t he = hd;
+        he.dec_layers = 0; he.vocab = 32;
+        vox_hip_engine_t *pe = vox_hip_engine_create(devs[i], &he);
+        if (!pe || vox_hip_enable_peer((vox_hip_engine_t *)ctx->engine, pe) || vox_hip_enable_peer(pe, (vox_hip_engine_t *)ctx->engine) ||
+            vox_hip_clone_encoder_weights(pe, (vox_hip_engine_t *)ctx->engine)) {
+            fprintf(stderr, "vox_load: cannot set up device %d for the sharded encoder (%s)\n", devs[i], vox_hip_last_error());
+            if (pe) vox_hip_engine_destroy(pe);
+            vox_free(ctx);
+            return NULL;
+        }
+        for (int k = 1; k < ctx->n_shard_engines; k++) {
+            vox_hip_enable_peer((vox_hip_engine_t *)ctx->shard_engines[k], pe);
+            vox_hip_enable_peer(pe, (vox_hip_engine_t *)ctx->shard_engines[k]);
+        }
+        ctx->shard_engines[ctx->n_shard_engines++] = pe;
+        if (vox_verbose >= 1) fprintf(stderr, "HIP engine: device %d joins the encoder (%.1f MB resident)\n", devs[i],
+                                      (double)vox_hip_memory_used(pe) / (1024.0 * 1024.0));
+    }
+
     ctx->kv_cache_max = 0;
     if (vox_verbose >= 1) {
         fprintf(stderr, "HIP engine: device %d, %.1f MB resident\n", ctx->device,
@@ -273,6 +308,8 @@ vox_ctx_t *vox_load_ex(const char *model_dir, const vox_load_opts_t *opts) {
 
 void vox_free(vox_ctx_t *ctx) {
     if (!ctx) return;
+    for (int i = 1; i < ctx->n_shard_engines; i++)
+        if (ctx->shard_engines[i]) vox_hip_engine_destroy((vox_hip_engine_t *)ctx->shard_engines[i]);
     if (ctx->engine) vox_hip_engine_destroy((vox_hip_engine_t *)ctx->engine);
     if (ctx->ada_down) for (int i = 0; i < ctx->dims.dec_layers; i++) free(ctx->ada_down[i]);
     if (ctx->ada_up) for (int i = 0; i < ctx->dims.dec_layers; i++) free(ctx->ada_up[i]);

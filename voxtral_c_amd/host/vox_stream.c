@@ -210,8 +210,26 @@ static void run_encoder(vox_stream_t *s) {
     if (new_mel <= 0) return;
 
     const double t0 = now_ms();
+    int new_mel_left = new_mel;
+    if (s->ctx->n_shard_engines > 1 && !s->stem_started) {
+        /* a multi-device model: the first chunk of a stream, if large, is encoded by all GPUs together (vox_multi.c);
+         * whatever is left (< 8 frames) and every later chunk runs on the stream's own engine as usual */
+        int mt = 0;
+        const int used = vox_multi_encode_first_chunk(s->ctx, new_mel, &mt);
+        if (used < 0) { fprintf(stderr, "vox_stream: sharded encoder failed: %s\n", vox_hip_last_error()); return; }
+        if (used > 0) {
+            s->mel_cursor += used;
+            s->stem_started = 1;
+            vox_enc_mirror_chunk(s->ctx, used / 2);
+            s->total_adapter += mt;
+            new_mel_left = new_mel - used;
+            if (vox_verbose >= 2)
+                fprintf(stderr, "  Encoder sharded over %d GPUs: %d mel -> %d tokens (total adapter: %d)\n", s->ctx->n_shard_engines, used, mt, s->total_adapter);
+            if (new_mel_left <= 0 || (new_mel_left < s->min_new_mel && !s->finished)) { s->enc_ms += now_ms() - t0; return; }
+        }
+    }
     int conv_rows = 0, residual = 0;
-    const int new_tokens = vox_hip_stream_encode(s->eng, new_mel, &conv_rows, &residual);
+    const int new_tokens = vox_hip_stream_encode(s->eng, new_mel_left, &conv_rows, &residual);
     s->mel_cursor = total_mel;
     s->stem_started = 1;
     if (new_tokens < 0) { fprintf(stderr, "vox_stream: encoder failed: %s\n", vox_hip_last_error()); return; }
@@ -222,7 +240,7 @@ static void run_encoder(vox_stream_t *s) {
     if (vox_monitor) { fputs("\xe2\x96\xb6", stderr); fflush(stderr); }      /* ▶ encoder chunk */
     if (vox_verbose >= 2)
         fprintf(stderr, "  Encoder inc: %d mel -> %d conv -> %d usable (total adapter: %d, residual: %d)\n",
-                new_mel, conv_rows, new_tokens * VOX_DOWNSAMPLE, s->total_adapter, residual);
+                new_mel_left, conv_rows, new_tokens * VOX_DOWNSAMPLE, s->total_adapter, residual);
 }
 
 /* ---- decoder side (reference stream_run_decoder, voxtral.c:969-1188) ----------------- */

@@ -319,6 +319,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=30.0, help="audio seconds per GPU")
     ap.add_argument("--preset", default="full", help="full | small | tiny (full = Voxtral-4B shapes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cold-load", action="store_true",
+                    help="also time vox_load with the checkpoint evicted from the page cache (posix_fadvise DONTNEED): model_load_cold_s")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc FETCH_SIZE sub-run (roofline.traffic)")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: BASELINE config 5 (row-scaled e4m3 decoder weights for the decode GEMVs); not the headline")
@@ -351,8 +353,18 @@ def main():
         from voxtral_c_amd.multi_gpu import run_distributed_bench
         return run_distributed_bench(args, rank, world, local_rank, mdir, None)
 
-    t0 = time.time()
     win = {} if args.preset != "tiny" else dict(enc_window=48, dec_window=64)
+    cold_s = None
+    if args.cold_load:
+        # cold page cache: write back, then drop the checkpoint's pages; vox_load then reads the 8.9 GB from storage
+        os.sync()
+        fd = os.open(os.path.join(mdir, "consolidated.safetensors"), os.O_RDONLY)
+        os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+        os.close(fd)
+        t0 = time.time()
+        v.Model(mdir, device=local_rank, weights=args.weights, **win).close()
+        cold_s = time.time() - t0
+    t0 = time.time()
     model = v.Model(mdir, device=local_rank, weights=args.weights, **win)
     load_s = time.time() - t0
     dims = model.dims            # geometry as read from the checkpoint by vox_load
@@ -400,7 +412,8 @@ def main():
         "parity": parity, "active_paths": path_names,
         "decode_tok_s": round(decode_tok_s, 1), "decode_ms_per_token": round(dec_ms / max(dec_steps, 1), 4),
         "encode_ms": round(enc_ms / args.steps, 2), "prefill_ms": round(pre_ms / args.steps, 2),
-        "decoder_steps_per_pass": n_tok, "model_load_s": round(load_s, 1),
+        "decoder_steps_per_pass": n_tok, "model_load_s": round(load_s, 2),
+        "model_load_cold_s": None if cold_s is None else round(cold_s, 2),
         "hbm_resident_GB": round(model.memory_used() / 1e9, 2),
         "config": {"workload": f"Voxtral-4B ({args.preset} synthetic checkpoint) on 1xMI355X, single {args.seconds:g} s 16 kHz mono clip, "
                                "one vox_stream_feed (batch encoder) + finish, greedy decode",

@@ -381,30 +381,42 @@ def test_stream_full_size_matches_reference_golden(vox):
 
 
 def test_fp8_decode_weights_track_bf16(vox):
-    """BASELINE config 5: fp8 e4m3 copies (one scale per output row) of the decoder matrices for the
-    decode GEMVs.  Not a parity mode (the weights differ by up to 2^-4 relative); the check is that
-    the logits stay close to the bf16 run and that greedy decoding agrees on most steps of the
-    seeded synthetic checkpoint (random weights have far smaller top-2 margins than a trained
-    model, so exact agreement is not expected here; the agreement rate is reported in
-    gpurun_out/diag/fp8_vs_bf16.json)."""
-    audio = synth_speech(10.0, 91)
+    """BASELINE config 5: fp8 e4m3 copies (one f32 scale per output row) of the decoder matrices for the decode GEMVs.
+    Not a parity mode: every weight moves by up to 2^-4 relative, so logits move by ~1e-2 and a greedy id can flip wherever
+    the bf16 top-2 margin is smaller than that.  Checked here: first-step logits stay close to the bf16 run (the prefill
+    uses the bf16 weights, so step 0 sees identical inputs), the decode step is faster, and - with the bf16 ids teacher-
+    forced so that every step is comparable - the ids agree on every step whose bf16 top-2 margin exceeds 6x that step's rms fp8
+    logit error; the agreement rate and the margin-conditioned counts go to gpurun_out/diag/fp8_vs_bf16.json."""
+    g = gold("stream_full_batch.npz")
+    audio = golden_audio(g)
     with vox.Model(model_dir("full")) as m:
-        a = m.transcribe(audio, record_logits=64)
+        a = m.transcribe(audio, record_logits=512)
     with vox.Model(model_dir("full"), weights="fp8") as m8:
         assert vox.hip.vox_hip_weight_format(m8.engine) == 1
-        b = m8.transcribe(audio, record_logits=64)
+        free = m8.transcribe(audio)
+        b = m8.transcribe(audio, record_logits=512, force_tokens=a["tokens"])
         t = m8.time_decoder_step(20, 232)
     la, lb = np.asarray(a["logits"]), np.asarray(b["logits"])
     ta, tb = np.asarray(a["tokens"]), np.asarray(b["tokens"])
-    n = min(len(ta), len(tb))
-    first_div = next((i for i in range(n) if ta[i] != tb[i]), n)
-    # logits of the first step see identical inputs (the prefill uses the bf16 weights)
+    n = min(len(ta), len(tb), len(la), len(lb))
+    srt = np.sort(la[:n], axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    err = np.abs(la[:n] - lb[:n]).max(axis=1)
+    rms = np.sqrt(((la[:n] - lb[:n]) ** 2).mean(axis=1))          # per-step rms logit error over the vocabulary
+    agree = ta[:n] == tb[:n]
     cos0 = float(np.dot(la[0], lb[0]) / (np.linalg.norm(la[0]) * np.linalg.norm(lb[0])))
-    rel0 = float(np.abs(la[0] - lb[0]).max() / (np.abs(la[0]).max() + 1e-30))
-    diag("fp8_vs_bf16", steps=int(n), first_divergence=int(first_div), agree=float((ta[:n] == tb[:n]).mean()),
-         cos_step0=cos0, rel_err_step0=rel0, ms_per_token_fp8=t * 1e3)
-    assert cos0 > 0.995 and rel0 < 0.1, (cos0, rel0)
-    assert t < 1.45e-3, t          # bf16 decode is 1.6 ms/token; half the weight bytes must show
+    safe = margin > 6 * rms                                      # top-2 gap beyond ~4 sigma of the difference of two logit errors
+    tf = np.asarray(free["tokens"])
+    nf = min(len(tf), len(ta))
+    first_div = next((i for i in range(nf) if tf[i] != ta[i]), nf)
+    diag("fp8_vs_bf16", steps=int(n), agree_teacher_forced=float(agree.mean()), free_run_first_divergence=int(first_div),
+         median_max_logit_err=float(np.median(err)), median_rms_logit_err=float(np.median(rms)), cos_step0=cos0,
+         steps_with_safe_margin=int(safe.sum()), disagreements_at_safe_margin=int((~agree & safe).sum()),
+         ms_per_token_fp8=t * 1e3)
+    assert cos0 > 0.995, cos0
+    assert (~agree & safe).sum() == 0, "fp8 flipped an id whose bf16 margin is 6x the rms fp8 logit error"
+    assert agree.mean() > 0.8, float(agree.mean())
+    assert t < 1.30e-3, t          # bf16 decode is ~1.5 ms/token; half the weight bytes must show
 
 
 def _decode_after_long_prefill(vox, n_prompt, n_steps, seed, env=None, **model_kw):
@@ -479,6 +491,27 @@ def test_fused_decode_step_matches_the_launch_per_gemv_chain(vox):
     assert n > 150 and np.array_equal(a["tokens"], b["tokens"])
     assert err < 2e-4, err
     assert same == n, (same, n)
+
+
+def test_two_decoders_sharing_the_gpu_stay_correct(vox):
+    """The fused decode kernel needs its 256 workgroups co-resident (one per CU).  Two models decoding at the same time on
+    one GPU (two host threads, two HIP streams) can split the CUs between their launches; a hand-off that then cannot
+    complete must time out (bounded spins), flag the batch, and the engine must re-run it on the launch-per-GEMV chain -
+    never hang, never return wrong ids."""
+    import threading
+    a1, a2 = synth_speech(20.0, 301), synth_speech(20.0, 302)
+    with vox.Model(model_dir("small")) as m:
+        want1, want2 = m.transcribe(a1)["tokens"], m.transcribe(a2)["tokens"]
+    with vox.Model(model_dir("small")) as m1, vox.Model(model_dir("small")) as m2:
+        out = {}
+
+        def run(model, audio, key):
+            out[key] = [model.transcribe(audio)["tokens"] for _ in range(4)]
+        th = [threading.Thread(target=run, args=(m1, a1, 1)), threading.Thread(target=run, args=(m2, a2, 2))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        diag("two_decoders", fused_after=["dec_fused" in m1.active_paths()[1], "dec_fused" in m2.active_paths()[1]])
+    assert all(np.array_equal(t, want1) for t in out[1]) and all(np.array_equal(t, want2) for t in out[2])
 
 
 def test_production_kernels_are_the_ones_running(vox, small):

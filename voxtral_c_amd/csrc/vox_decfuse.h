@@ -79,14 +79,18 @@ __device__ __forceinline__ u64 df_load_granule(const u64 *g) {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Re-read one granule until its tag is this launch's epoch (bounded).  Returns the payload.
+// Once ANY wait of ANY launch has timed out (*err != 0: e.g. the 256 workgroups were not co-resident because another
+// process or stream held CUs), every later wait gives up at once: the launches already queued behind the failure then
+// drain in microseconds instead of one time-out each, and the host re-runs the batch on the launch-per-GEMV chain.
 __device__ __forceinline__ float df_wait_granule(const u64 *g, unsigned epoch, const DecFuseArgs &a, unsigned code) {
     u64 v = df_load_granule(g);
     if ((unsigned)(v >> 32) != epoch) {
         const unsigned long long t0 = wall_clock64();
-        for (;;) {
+        for (unsigned it = 0;; it++) {
             __builtin_amdgcn_s_sleep(2);
             v = df_load_granule(g);
             if ((unsigned)(v >> 32) == epoch) break;
+            if ((it & 15u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
             if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
     }

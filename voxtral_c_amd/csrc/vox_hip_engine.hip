@@ -727,50 +727,57 @@ static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float 
 // Streaming-size chunks (n <= 32 rows): the weight-streaming path of vox_skinny.h, 7-8 launches per layer.
 static bool skinny_ok(const vox_hip_engine *e, int n, const RowsCfg &c) {
     return e->use_skinny && e->use_mfma && n >= 1 && n <= 32 && c.kv_heads == c.heads && c.hd == 64 &&
-           c.D % 64 == 0 && c.QD % 64 == 0 && c.H % 64 == 0 && c.D % 32 == 0 && (c.QD + 2 * c.KVD) % 32 == 0;
+           c.D % 64 == 0 && c.QD % 64 == 0 && c.H % 64 == 0 && c.D % 32 == 0 && (c.QD + 2 * c.KVD) % 32 == 0 &&
+           c.D <= 64 * SK_MAXC * SK_WPB;        // the unsplit GEMMs (qkv, w1;w3) have K = D: at most SK_MAXC chunks per wave
 }
-static int skinny_split(int K) { return std::max(1, std::min(16, (K / 64) / SK_WPB)); }
+static int skinny_split(int K) { return std::max(1, std::min(16, (K / 64) / SK_WPB)); }      // one chunk per wave when K allows
 
 static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
     const RowsCfg c = enc_cfg(e);
     const int N3 = c.QD + 2 * c.KVD, L = e->d.enc_layers, pos0 = e->enc_pos;
-    float *xn = (float *)e->sxn.p, *qkv = (float *)e->sqkv.p, *attn = (float *)e->sattn.p, *h = (float *)e->sh.p, *tab = (float *)e->srope.p;
+    float *xn = (float *)e->sxn.p, *qkv = (float *)e->sqkv.p, *attn = (float *)e->sattn.p, *tab = (float *)e->srope.p;
     hipStream_t s = e->stream;
     const int so = skinny_split(c.QD), s2 = skinny_split(c.H);
     if (ensure(e, e->ssplitk, (size_t)std::max(so, s2) * n * c.D * 4)) return -1;
+    // bf16 planes of the normalised rows [3][n][D] and of the gated hidden rows [3][n][H] (sgu is free on this path)
+    if (ensure(e, e->sgu, (size_t)3 * n * (c.D + c.H) * 2)) return -1;
+    uint16_t *xnp = (uint16_t *)e->sgu.p, *hp = xnp + (size_t)3 * n * c.D;
     float *part = (float *)e->ssplitk.p;
     const size_t lds1 = (size_t)SK_WPB * 4096, lds2 = (size_t)SK_WPB * 2 * 4096;
-    if (L > 0)
-        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, s, xn, c.D, x, c.D, e->enc[0].n1, (const float *)nullptr, c.D, c.eps);
+    if (L > 0)      // attention_norm of layer 0 (no partials, no bias: x is left as it is)
+        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)nullptr, 0, n, c.D, (const float *)nullptr,
+                           (const float *)e->enc[0].n1, c.eps, xn, c.D, xnp);
     for (int l = 0; l < L; l++) {
         EncLayer &Ly = e->enc[l];
         {   // attention_norm(x) . [wq; wk; wv]^T + bias, RoPE, K/V into the merged buffer and the rings
             SkinnyArgs a{};
-            a.X = xn; a.ldx = c.D; a.n = n; a.W = Ly.wqkv; a.N = N3; a.K = c.D; a.bias = Ly.bqkv; a.Y = qkv; a.ldy = N3;
+            a.Xp = xnp; a.xp_plane = (size_t)n * c.D; a.n = n; a.W = Ly.wqkv; a.N = N3; a.K = c.D; a.bias = Ly.bqkv; a.Y = qkv; a.ldy = N3;
             a.rope_cols = c.QD + c.KVD; a.head_dim = c.hd; a.rope_tab = tab; a.kring = Ly.kring; a.vring = Ly.vring;
             a.ring_cap = e->enc_ring_cap; a.kv_dim = c.KVD; a.pos0 = pos0; a.q_cols = c.QD;
-            hipLaunchKernelGGL((k_skinny<SK_QKV, 1>), dim3(N3 / 32, 1), dim3(64 * SK_WPB), lds1, s, a);
+            hipLaunchKernelGGL((k_skinny<SK_QKV, 1, true>), dim3(N3 / 32, 1), dim3(64 * SK_WPB), lds1, s, a);
         }
         if (enc_attention(e, c, qkv, attn, n, pos0, Ly.kring, Ly.vring, e->enc_ring_cap)) return -1;
         {   // wo as K-split partials, then x += . + bo and ffn_norm in one launch
             SkinnyArgs a{};
             a.X = attn; a.ldx = c.QD; a.n = n; a.W = Ly.wo; a.N = c.D; a.K = c.QD; a.partial = part;
-            hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1>), dim3(c.D / 32, so), dim3(64 * SK_WPB), lds1, s, a);
+            hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, false>), dim3(c.D / 32, so), dim3(64 * SK_WPB), lds1, s, a);
             hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)part, so, n, c.D, (const float *)Ly.bo,
-                               (const float *)Ly.n2, c.eps, xn, c.D);
+                               (const float *)Ly.n2, c.eps, xn, c.D, xnp);
         }
-        {   // silu(xn w1^T) * (xn w3^T)
+        {   // silu(xn w1^T) * (xn w3^T), written as bf16 planes for the w2 launch
             SkinnyArgs a{};
-            a.X = xn; a.ldx = c.D; a.n = n; a.W = Ly.w13; a.W2 = Ly.w13 + (size_t)c.H * c.D; a.N = c.H; a.K = c.D; a.Y = h; a.ldy = c.H;
-            hipLaunchKernelGGL((k_skinny<SK_SWIGLU, 1>), dim3(c.H / 32, 1), dim3(64 * SK_WPB), lds2, s, a);
+            a.Xp = xnp; a.xp_plane = (size_t)n * c.D; a.n = n; a.W = Ly.w13; a.W2 = Ly.w13 + (size_t)c.H * c.D; a.N = c.H; a.K = c.D;
+            a.Yp = hp; a.yp_plane = (size_t)n * c.H;
+            hipLaunchKernelGGL((k_skinny<SK_SWIGLU, 1, true>), dim3(c.H / 32, 1), dim3(64 * SK_WPB), lds2, s, a);
         }
         {   // w2 partials, then x += . + b2 and the next norm (next layer's attention_norm, or the final norm into `out`)
             SkinnyArgs a{};
-            a.X = h; a.ldx = c.H; a.n = n; a.W = Ly.w2; a.N = c.D; a.K = c.H; a.partial = part;
-            hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1>), dim3(c.D / 32, s2), dim3(64 * SK_WPB), lds1, s, a);
+            a.Xp = hp; a.xp_plane = (size_t)n * c.H; a.n = n; a.W = Ly.w2; a.N = c.D; a.K = c.H; a.partial = part;
+            hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, true>), dim3(c.D / 32, s2), dim3(64 * SK_WPB), lds1, s, a);
             const bool last = l + 1 == L;
             hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)part, s2, n, c.D, (const float *)Ly.b2,
-                               (const float *)(last ? e->enc_final_norm : e->enc[l + 1].n1), c.eps, last ? out : xn, c.D);
+                               (const float *)(last ? e->enc_final_norm : e->enc[l + 1].n1), c.eps, last ? out : xn, c.D,
+                               last ? (uint16_t *)nullptr : xnp);
         }
     }
     if (L == 0)
@@ -1299,7 +1306,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.gq = e->d_gq; a.gp = e->d_gp; a.wo_part = e->d_wo_part;
                 if (++e->fuse_epoch == 0) e->fuse_epoch = 1;
                 a.epoch = e->fuse_epoch; a.split_keys = f_split; a.nsplit = f_ns;
-                a.err = e->d_fuse_err; a.spin_limit = 2000000ull;        // 20 ms at the 100 MHz wall clock
+                a.err = e->d_fuse_err; a.spin_limit = 500000ull;         // 5 ms at the 100 MHz wall clock (a hand-off takes microseconds)
                 a.trace = (l == 13) ? e->d_fuse_trace : nullptr;          // tuning: phase stamps of one mid-stack launch
                 const bool emb = (l == 0 && build_embed);
                 if (e->use_dpp) {
@@ -1440,16 +1447,33 @@ static int set_state(vox_hip_engine *e, int pos, int token, int64_t adapter_phys
     return 0;
 }
 
+// After a synchronisation: did a hand-off of the fused decode kernel time out since the last check?  If so the results of
+// everything enqueued since are void: switch to the launch-per-GEMV chain for good (loudly) and tell the caller to redo.
+static int fused_failed(vox_hip_engine *e) {
+    if (!e->use_fused) return 0;
+    unsigned err = 0;
+    if (hipMemcpy(&err, e->d_fuse_err, sizeof err, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (!err) return 0;
+    fprintf(stderr, "vox_hip: ERROR fused decode kernel timed out in hand-off %u (its 256 workgroups were not co-resident?); "
+                    "switching to the launch-per-GEMV chain and repeating the work\n", err);
+    e->use_fused = false; e->fuse_failures++;
+    (void)hipMemset(e->d_fuse_err, 0, sizeof(unsigned));
+    return 1;
+}
+
 extern "C" int vox_hip_decoder_step(vox_hip_engine_t *e, const float *embed, float *logits) {
     if (!e || !embed) return -1;
     HC(hipSetDevice(e->device));
-    HC(hipMemcpyAsync(e->dx, embed, (size_t)e->d.dec_dim * 4, hipMemcpyHostToDevice, e->stream));
-    if (set_state(e, e->dec_pos, 0, 0)) return -1;
-    if (enqueue_step(e, e->dec_pos, false, e->dlogits, -1, 1)) return -1;
     int tok = -1;
-    HC(hipMemcpyAsync(&tok, e->d_tokens, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    if (logits) HC(hipMemcpyAsync(logits, e->dlogits, (size_t)e->d.vocab * 4, hipMemcpyDeviceToHost, e->stream));
-    HC(hipStreamSynchronize(e->stream));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HC(hipMemcpyAsync(e->dx, embed, (size_t)e->d.dec_dim * 4, hipMemcpyHostToDevice, e->stream));
+        if (set_state(e, e->dec_pos, 0, 0)) return -1;
+        if (enqueue_step(e, e->dec_pos, false, e->dlogits, -1, 1)) return -1;
+        HC(hipMemcpyAsync(&tok, e->d_tokens, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        if (logits) HC(hipMemcpyAsync(logits, e->dlogits, (size_t)e->d.vocab * 4, hipMemcpyDeviceToHost, e->stream));
+        HC(hipStreamSynchronize(e->stream));
+        if (!fused_failed(e)) break;
+    }
     e->dec_pos += 1;
     return tok;
 }
@@ -1466,16 +1490,19 @@ extern "C" int vox_hip_decoder_prefill_stream(vox_hip_engine_t *e, int64_t first
     const float *arow = e->adapter + (size_t)(first_row - e->adapter_row0) * DD;
     hipLaunchKernelGGL(k_embed_prompt, dim3(grid1d((size_t)n_prompt * DD)), dim3(256), 0, s, x, arow,
                        (const uint16_t *)e->tok_emb, n_prompt, DD, bos, pad);
-    // the last prompt row is the first decode step's input (voxtral.c:1005-1012)
-    HC(hipMemcpyAsync(e->dx, x + (size_t)(n_prompt - 1) * DD, (size_t)DD * 4, hipMemcpyDeviceToDevice, s));
     if (n_prompt > 1 && decoder_prefill_dev(e, x, n_prompt - 1)) return -1;
-    if (set_state(e, e->dec_pos, 0, 0)) return -1;
-    if (enqueue_step(e, e->dec_pos, false, e->dlogits, -1, 1)) return -1;
     int tok = -1;
-    HC(hipMemcpyAsync(&tok, e->d_tokens, sizeof(int), hipMemcpyDeviceToHost, s));
-    if (logits) HC(hipMemcpyAsync(logits, e->dlogits, (size_t)e->d.vocab * 4, hipMemcpyDeviceToHost, s));
-    HC(hipEventRecord(e->ev1, s));
-    HC(hipStreamSynchronize(s));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        // the last prompt row is the first decode step's input (voxtral.c:1005-1012)
+        HC(hipMemcpyAsync(e->dx, x + (size_t)(n_prompt - 1) * DD, (size_t)DD * 4, hipMemcpyDeviceToDevice, s));
+        if (set_state(e, e->dec_pos, 0, 0)) return -1;
+        if (enqueue_step(e, e->dec_pos, false, e->dlogits, -1, 1)) return -1;
+        HC(hipMemcpyAsync(&tok, e->d_tokens, sizeof(int), hipMemcpyDeviceToHost, s));
+        if (logits) HC(hipMemcpyAsync(logits, e->dlogits, (size_t)e->d.vocab * 4, hipMemcpyDeviceToHost, s));
+        HC(hipEventRecord(e->ev1, s));
+        HC(hipStreamSynchronize(s));
+        if (!fused_failed(e)) break;
+    }
     float ms = 0.f; hipEventElapsedTime(&ms, e->ev0, e->ev1);
     e->timing.prefill_ms += ms;
     e->dec_pos += 1;
@@ -1503,18 +1530,9 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
         for (int i = 0; i < batch; i++)
             if (enqueue_step(e, e->dec_pos + i, true, logits_out ? lg + (size_t)i * V : lg, eos_token, 1)) return -1;
         DecState st{};
-        unsigned fuse_err = 0;
         HC(hipMemcpyAsync(&st, e->d_st, sizeof st, hipMemcpyDeviceToHost, s));
-        if (e->use_fused) HC(hipMemcpyAsync(&fuse_err, e->d_fuse_err, sizeof fuse_err, hipMemcpyDeviceToHost, s));
         HC(hipStreamSynchronize(s));
-        if (fuse_err) {
-            // a hand-off inside k_dec_attn_fused timed out (its 256 workgroups were not co-resident?): the batch's
-            // results are void.  Loudly switch to the launch-per-GEMV chain for good and run the batch again.
-            fprintf(stderr, "vox_hip: ERROR fused decode kernel timed out in hand-off %u; switching to the launch-per-GEMV chain\n", fuse_err);
-            e->use_fused = false; e->fuse_failures++;
-            HC(hipMemsetAsync(e->d_fuse_err, 0, sizeof(unsigned), s));
-            continue;
-        }
+        if (fused_failed(e)) continue;          // the batch's results are void: run it again (now on the chain)
         const int got = st.n_out;
         if (got > 0) HC(hipMemcpy(tokens_out + done, e->d_tokens, (size_t)got * sizeof(int), hipMemcpyDeviceToHost));
         if (logits_out && got > 0)
@@ -1939,7 +1957,7 @@ static int self_test(vox_hip_engine *e) {
     if (getenv("VOX_HIP_NO_GEMV3")) e->use_gemv3 = false;
     if (getenv("VOX_HIP_NO_SPLITK")) e->use_splitk = false;
     if (getenv("VOX_HIP_NO_SKINNY")) e->use_skinny = false;
-    if (hipFuncSetAttribute((const void *)k_skinny<SK_SWIGLU, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_WPB * 2 * 4096) != hipSuccess) {
+    if (hipFuncSetAttribute((const void *)k_skinny<SK_SWIGLU, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_WPB * 2 * 4096) != hipSuccess) {
         (void)hipGetLastError();
         e->use_skinny = false;
     }

@@ -28,9 +28,12 @@ namespace vox {
 
 enum { SK_PARTIAL = 0, SK_QKV = 1, SK_SWIGLU = 2 };
 constexpr int SK_WPB = 8;                 // waves per workgroup (K splitters of one W tile)
+constexpr int SK_MAXC = 3;                // 64-wide K chunks per wave at most: K <= 64 * SK_MAXC * SK_WPB * gridDim.y
 
 struct SkinnyArgs {
     const float *X; int ldx; int n;       // [n][K] activations, n <= 32 * MT
+    const uint16_t *Xp; size_t xp_plane;  // XS: the activations pre-split by their producer into bf16 planes [3][n][K] (hi, mid, lo)
+    uint16_t *Yp; size_t yp_plane;        // SK_SWIGLU: h is written as bf16 planes [3][n][N] for the w2 launch (and not as f32)
     const uint16_t *W, *W2;               // [N][K] bf16; W2 = up-projection rows (SK_SWIGLU)
     int N, K;
     const float *bias;                    // [N] or null (SK_QKV)
@@ -57,8 +60,18 @@ __device__ __forceinline__ void sk_split_frag(const float4 x0, const float4 x1, 
     fh = ph.v; fm = pm.v; fl = pl.v;
 }
 
+// bf16 planes of one f32 (hi, mid, lo as 16-bit patterns)
+__device__ __forceinline__ void sk_planes1(float x, uint16_t &h, uint16_t &m, uint16_t &l) {
+    uint32_t hh, mm, ll;
+    split3(x, hh, mm, ll);
+    h = (uint16_t)(hh >> 16); m = (uint16_t)(mm >> 16); l = (uint16_t)(ll >> 16);
+}
+
 // grid = (N / 32, S); block = 64 * SK_WPB.  MT = 1 (n <= 32) or 2 (n <= 64) row tiles of the activations.
-template <int EPI, int MT>
+// XS: the activation fragments come pre-split (three 16-byte loads per MFMA step, no VALU work): with f32 activations every
+// one of the N / 32 workgroups repeats the same hi / mid / lo split of x, ~7 VALU operations per element and MFMA step, and
+// that - not HBM - bounded the qkv and w1;w3 launches (measured 15 / 22 us for 15.7 / 26.2 MB).
+template <int EPI, int MT, bool XS>
 __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
     constexpr int NB = (EPI == SK_SWIGLU) ? 2 : 1;              // W tiles per wave
     extern __shared__ __attribute__((aligned(16))) float sk_lds[];   // [SK_WPB][NB][MT][1024] accumulators
@@ -81,36 +94,58 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
     wrow[0] = a.W + (size_t)(row0 + li) * a.K + lg * 8;
     if constexpr (NB == 2) wrow[1] = a.W2 + (size_t)(row0 + li) * a.K + lg * 8;
     const float *xrow[MT];
+    const uint16_t *xprow[MT];
 #pragma unroll
-    for (int t = 0; t < MT; t++) xrow[t] = a.X + (size_t)min(t * 32 + li, a.n - 1) * a.ldx + lg * 8;
+    for (int t = 0; t < MT; t++) {
+        xrow[t] = XS ? nullptr : a.X + (size_t)min(t * 32 + li, a.n - 1) * a.ldx + lg * 8;
+        xprow[t] = XS ? a.Xp + (size_t)min(t * 32 + li, a.n - 1) * a.K + lg * 8 : nullptr;
+    }
 
-    // double-buffered chunk registers; the buffer index is a compile-time constant (runtime-indexed register arrays
-    // would be demoted to scratch memory)
-    uint4 wq0[NB][4], wq1[NB][4];
-    float4 xq0[MT][4][2], xq1[MT][4][2];
-    auto issue = [&](uint4 (&wq)[NB][4], float4 (&xq)[MT][4][2], int c) {
-        const int k0 = c * 64;
+    // A wave owns at most SK_MAXC chunks (the host picks the K split accordingly).  All of its WEIGHT fragments are
+    // requested up front (HBM latency paid once, 16 VGPRs per chunk and tile); the activation fragments (L2 hits, 32 VGPRs
+    // per chunk) are double buffered.  Register arrays are only ever indexed by compile-time constants.
+    uint4 wq[SK_MAXC][NB][4];
+    constexpr int XR = XS ? 3 : 2;            // 16-byte registers per fragment: 3 bf16 planes, or 8 f32
+    float4 xq0[MT][4][XR], xq1[MT][4][XR];
+    auto issue_w = [&](uint4 (&wqc)[NB][4], int c) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
+        for (int s = 0; s < 4; s++)
 #pragma unroll
-            for (int b = 0; b < NB; b++) wq[b][s] = ld_stream(reinterpret_cast<const uint4 *>(wrow[b] + k0 + s * 16));
+            // plain (L1-allocating) loads on purpose: in fragment layout one instruction takes 32 bytes from each of 32 rows,
+            // and the four instructions of a chunk share their 128-byte lines - a non-temporal load would fetch each line 4 x
+            for (int b = 0; b < NB; b++) wqc[b][s] = *reinterpret_cast<const uint4 *>(wrow[b] + c * 64 + s * 16);
+    };
+    auto issue_x = [&](float4 (&xq)[MT][4][XR], int c) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
 #pragma unroll
             for (int t = 0; t < MT; t++) {
-                xq[t][s][0] = *reinterpret_cast<const float4 *>(xrow[t] + k0 + s * 16);
-                xq[t][s][1] = *reinterpret_cast<const float4 *>(xrow[t] + k0 + s * 16 + 4);
+                if constexpr (XS) {
+#pragma unroll
+                    for (int p = 0; p < 3; p++) xq[t][s][p] = *reinterpret_cast<const float4 *>(xprow[t] + p * a.xp_plane + c * 64 + s * 16);
+                } else {
+                    xq[t][s][0] = *reinterpret_cast<const float4 *>(xrow[t] + c * 64 + s * 16);
+                    xq[t][s][1] = *reinterpret_cast<const float4 *>(xrow[t] + c * 64 + s * 16 + 4);
+                }
             }
-        }
     };
-    auto compute = [&](const uint4 (&wq)[NB][4], const float4 (&xq)[MT][4][2]) {
+    auto compute = [&](const uint4 (&wqc)[NB][4], const float4 (&xq)[MT][4][XR]) {
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             bf16x8_t fa[MT][3];
 #pragma unroll
-            for (int t = 0; t < MT; t++) sk_split_frag(xq[t][s][0], xq[t][s][1], fa[t][0], fa[t][1], fa[t][2]);
+            for (int t = 0; t < MT; t++) {
+                if constexpr (XS) {
+#pragma unroll
+                    for (int p = 0; p < 3; p++) { union { float4 f; bf16x8_t v; } cv; cv.f = xq[t][s][p]; fa[t][p] = cv.v; }
+                } else {
+                    sk_split_frag(xq[t][s][0], xq[t][s][1], fa[t][0], fa[t][1], fa[t][2]);
+                }
+            }
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 union { uint4 u; bf16x8_t v; } fb;
-                fb.u = wq[b][s];
+                fb.u = wqc[b][s];
 #pragma unroll
                 for (int p = 2; p >= 0; p--)                   // small terms first
 #pragma unroll
@@ -119,16 +154,19 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
             }
         }
     };
-    int c = kw;
-    if (c < nchunks) issue(wq0, xq0, c);
-    while (c < nchunks) {
-        if (c + kworkers < nchunks) issue(wq1, xq1, c + kworkers);
-        compute(wq0, xq0);
-        c += kworkers;
-        if (c >= nchunks) break;
-        if (c + kworkers < nchunks) issue(wq0, xq0, c + kworkers);
-        compute(wq1, xq1);
-        c += kworkers;
+    static_assert(SK_MAXC == 3, "the chunk schedule below is written out for three chunks");
+    const int c0 = kw, c1 = kw + kworkers, c2 = kw + 2 * kworkers;
+    if (c0 < nchunks) { issue_x(xq0, c0); issue_w(wq[0], c0); }
+    if (c1 < nchunks) issue_w(wq[1], c1);
+    if (c2 < nchunks) issue_w(wq[2], c2);
+    if (c0 < nchunks) {
+        if (c1 < nchunks) issue_x(xq1, c1);
+        compute(wq[0], xq0);
+        if (c1 < nchunks) {
+            if (c2 < nchunks) issue_x(xq0, c2);
+            compute(wq[1], xq1);
+            if (c2 < nchunks) compute(wq[2], xq0);
+        }
     }
 
     // ---- add the K splitters of this workgroup in wave order (element e = r * 64 + lane of each 32 x 32 tile) ------------
@@ -157,7 +195,15 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
         if constexpr (EPI == SK_PARTIAL) {
             a.partial[((size_t)blockIdx.y * a.n + m) * a.N + col] = red[e];
         } else if constexpr (EPI == SK_SWIGLU) {
-            a.Y[(size_t)m * a.ldy + col] = silu(red[e]) * red[MT * 1024 + e];          // tile 0 = gate (w1), tile 1 = up (w3)
+            const float hv = silu(red[e]) * red[MT * 1024 + e];                         // tile 0 = gate (w1), tile 1 = up (w3)
+            if (a.Yp) {
+                uint16_t ph, pm, pl;
+                sk_planes1(hv, ph, pm, pl);
+                uint16_t *dst = a.Yp + (size_t)m * a.N + col;
+                dst[0] = ph; dst[a.yp_plane] = pm; dst[2 * a.yp_plane] = pl;
+            } else {
+                a.Y[(size_t)m * a.ldy + col] = hv;
+            }
         } else {
             float v = red[e] + (a.bias ? a.bias[col] : 0.f);
             if (col < a.rope_cols) {
@@ -178,8 +224,10 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
 
 // x[m] += bias + sum_s partial[s][m]  (split order), then out_norm[m] = rmsnorm(x[m]) * w (+ada) — one block per row.
 // Covers "x += wo(attn) + bo -> ffn_norm" and "x += w2(h) + b2 -> next layer's attention_norm / the final norm".
+// planes (optional): the normalised row also as bf16 planes [3][n][D] for the XS skinny launches that consume it.
 __global__ __launch_bounds__(256) void k_rows_finish(float *x, int ldx, const float *partial, int nsplit, int n, int D,
-                                                     const float *bias, const float *norm_w, float eps, float *out_norm, int ldo) {
+                                                     const float *bias, const float *norm_w, float eps, float *out_norm, int ldo,
+                                                     uint16_t *planes) {
     __shared__ float red[4];
     const int m = blockIdx.x, tid = threadIdx.x;
     float *xr = x + (size_t)m * ldx;
@@ -205,7 +253,17 @@ __global__ __launch_bounds__(256) void k_rows_finish(float *x, int ldx, const fl
     for (int i = tid * 4; i < D; i += 1024) {
         const float4 v = *reinterpret_cast<const float4 *>(xr + i);      // own elements, written above by this thread
         const float4 g = *reinterpret_cast<const float4 *>(norm_w + i);
-        *reinterpret_cast<float4 *>(orow + i) = make_float4(v.x * inv * g.x, v.y * inv * g.y, v.z * inv * g.z, v.w * inv * g.w);
+        const float4 o = make_float4(v.x * inv * g.x, v.y * inv * g.y, v.z * inv * g.z, v.w * inv * g.w);
+        *reinterpret_cast<float4 *>(orow + i) = o;
+        if (planes) {
+            uint32_t h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+            split3(o.x, h0, m0, l0); split3(o.y, h1, m1, l1); split3(o.z, h2, m2, l2); split3(o.w, h3, m3, l3);
+            uint16_t *dst = planes + (size_t)m * D + i;
+            const size_t ps = (size_t)n * D;
+            *reinterpret_cast<uint2 *>(dst) = make_uint2((h0 >> 16) | h1, (h2 >> 16) | h3);
+            *reinterpret_cast<uint2 *>(dst + ps) = make_uint2((m0 >> 16) | m1, (m2 >> 16) | m3);
+            *reinterpret_cast<uint2 *>(dst + 2 * ps) = make_uint2((l0 >> 16) | (l1 & 0xffff0000u), (l2 >> 16) | (l3 & 0xffff0000u));
+        }
     }
 }
 

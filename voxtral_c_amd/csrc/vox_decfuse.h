@@ -68,6 +68,7 @@ struct DecFuseArgs {
     unsigned *err;
     unsigned long long spin_limit;   // wall_clock64 ticks
     unsigned long long *trace;       // optional (tuning): [2 blocks][16] wall-clock stamps of the phases, blocks 0 and 255
+    int spread_groups;               // test switch: group = blockIdx / 32 (members spread over all XCDs) instead of blockIdx % 8
 };
 // stamps stay in registers until the end: a store in the middle would shift the hand-counted s_waitcnt vmcnt values
 #define DF_MARK(k) do { if (a.trace) df_stamp[k] = wall_clock64(); } while (0)
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     float *red = frq + 256;                                                    // [128]: wave sums, the 24 row results
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = blockIdx.x % DF_GROUPS, j = blockIdx.x / DF_GROUPS;
+    const int g = a.spread_groups ? blockIdx.x / DF_BPG : blockIdx.x % DF_GROUPS;
+    const int j = a.spread_groups ? blockIdx.x % DF_BPG : blockIdx.x / DF_GROUPS;
     const unsigned epoch = a.epoch;
     const int pos = a.pos;
     unsigned long long df_stamp[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -413,11 +415,13 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
             }
             __syncthreads();
             {   // PV: out[ho][dd] = out * corr + sum_k p[ho][k] * V[k][dd]
+                // only the tile's valid keys: the rows past s_hi hold whatever the ring slot had (0 x NaN would poison the sum)
                 const float *pr = pt + ho * 64;
                 const float *vcol = reinterpret_cast<const float *>(vt) + dd;
+                const int nv = min(DF_TILE, s_hi - t0 + 1);
                 float accv = 0.f;
-#pragma unroll 16
-                for (int k = 0; k < DF_TILE; k++) accv = fmaf(pr[k], vcol[k * 128], accv);
+#pragma unroll 8
+                for (int k = 0; k < nv; k++) accv = fmaf(pr[k], vcol[k * 128], accv);
                 o_acc = o_acc * cr[ho] + accv;
             }
         }

@@ -124,6 +124,7 @@ struct vox_hip_engine {
     int dec_ring_cap = 0;
     int dec_pos = 0;            // logical positions stored (= kv_pos_offset + kv_cache_len)
     DecState *d_st = nullptr;
+    float *dx2 = nullptr;               // second residual-stream buffer of the fused decode step (see enqueue_step)
     float *dx = nullptr, *dq = nullptr, *dattn = nullptr, *dh = nullptr, *dlogits = nullptr;
     float *blk_val = nullptr; int *blk_idx = nullptr; int logits_grid = 0;
     unsigned skip_kinds = 0;            // timing experiments only: PK_* launches left out of a step
@@ -413,7 +414,7 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
     }
     // decoder step buffers
     rc |= dalloc(e, &e->d_st, 1);
-    rc |= dalloc(e, &e->dx, DD); rc |= dalloc(e, &e->dq, DQ); rc |= dalloc(e, &e->dattn, DQ);
+    rc |= dalloc(e, &e->dx, DD); rc |= dalloc(e, &e->dx2, DD); rc |= dalloc(e, &e->dq, DQ); rc |= dalloc(e, &e->dattn, DQ);
     rc |= dalloc(e, &e->dh, DH); rc |= dalloc(e, &e->dlogits, (size_t)d.vocab);
     e->logits_grid = (d.vocab % (16 * 1024) == 0) ? 1024 : gemv_grid(d.vocab, 16);   // 131072 rows: 8 even trips
     rc |= dalloc(e, &e->blk_val, e->logits_grid); rc |= dalloc(e, &e->blk_idx, e->logits_grid);
@@ -475,7 +476,7 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     }
     F(e->tok_emb8); F(e->stok);
     F(e->hann); F(e->cosT); F(e->sinT); F(e->filtT); F(e->enc_inv_freq); F(e->dec_inv_freq); F(e->dec_rope);
-    F(e->d_st); F(e->dx); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
+    F(e->d_st); F(e->dx); F(e->dx2); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
     F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_gq); F(e->d_gp); F(e->d_wo_part); F(e->d_fuse_err);
     Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
                    &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml, &e->ssplitk};
@@ -1294,20 +1295,26 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
         while ((kv_len + f_split - 1) / f_split > DF_BPG) f_split += 64;
         f_ns = (kv_len + f_split - 1) / f_split;
     }
+    // Fused path: the residual stream ping-pongs between two buffers.  k_gemv_w13x's block 0 writes x' = x + sum(wo partials)
+    // while the other 255 workgroups may not have fetched x yet - in place that is a race that only bites when workgroups
+    // of one launch start far apart (two models sharing the GPU: found by test_two_decoders_sharing_the_gpu_stay_correct).
+    float *xin = e->dx, *xalt = e->dx2;
     for (int l = 0; l < d.dec_layers; l++) {
         DecLayer &L = e->dec[l];
         if (fused) {
             if (!(e->skip_kinds & (1u << PK_QKV))) {
                 // attention_norm -> wq/wk/wv -> RoPE -> KV append -> attention -> wo (K-split partials): one launch
                 DecFuseArgs a{};
-                a.wqkv = L.wqkv; a.wo = L.wo; a.x = e->dx; a.norm_w = L.n1; a.eps = d.dec_eps; a.inv_freq = e->dec_inv_freq;
+                a.wqkv = L.wqkv; a.wo = L.wo; a.x = xin; a.norm_w = L.n1; a.eps = d.dec_eps; a.inv_freq = e->dec_inv_freq;
                 a.kring = L.kring; a.vring = L.vring; a.kv_cap = e->dec_ring_cap; a.pos = kv_pos; a.window = d.dec_window; a.scale = scale;
-                a.adapter = e->adapter; a.tok_emb = e->tok_emb; a.st = e->d_st; a.x_out = e->dx;
+                a.adapter = e->adapter; a.tok_emb = e->tok_emb; a.st = e->d_st; a.x_out = xin;
                 a.gq = e->d_gq; a.gp = e->d_gp; a.wo_part = e->d_wo_part;
                 if (++e->fuse_epoch == 0) e->fuse_epoch = 1;
                 a.epoch = e->fuse_epoch; a.split_keys = f_split; a.nsplit = f_ns;
                 a.err = e->d_fuse_err; a.spin_limit = 500000ull;         // 5 ms at the 100 MHz wall clock (a hand-off takes microseconds)
                 a.trace = (l == 13) ? e->d_fuse_trace : nullptr;          // tuning: phase stamps of one mid-stack launch
+                static const int spread = getenv("VOX_HIP_FUSE_SPREAD") ? 1 : 0;    // test: group members on all XCDs
+                a.spread_groups = spread;
                 const bool emb = (l == 0 && build_embed);
                 if (e->use_dpp) {
                     if (emb) hipLaunchKernelGGL((k_dec_attn_fused<true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
@@ -1321,18 +1328,19 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             if (!(e->skip_kinds & (1u << PK_SWIGLU))) {
                 // x += sum of the wo partials -> ffn_norm * (1 + ada) -> silu(W1 x) * (W3 x)
                 W13xArgs a{};
-                a.w1 = L.w13; a.w3 = L.w13 + (size_t)DH * DD; a.x = e->dx; a.wo_part = e->d_wo_part; a.norm_w = L.n2; a.ada = L.ada;
-                a.eps = d.dec_eps; a.x_out = e->dx; a.h = e->dh;
+                a.w1 = L.w13; a.w3 = L.w13 + (size_t)DH * DD; a.x = xin; a.wo_part = e->d_wo_part; a.norm_w = L.n2; a.ada = L.ada;
+                a.eps = d.dec_eps; a.x_out = xalt; a.h = e->dh;
                 a.trace = (l == 13) ? e->d_fuse_trace : nullptr;
                 hipLaunchKernelGGL(k_gemv_w13x, dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
                 prof_mark(e, PK_SWIGLU);
             }
             if (!(e->skip_kinds & (1u << PK_W2))) {
                 GemvArgs a{};
-                a.W = L.w2; a.x = e->dh; a.y = e->dx; a.N = DD; a.K = DH;
+                a.W = L.w2; a.x = e->dh; a.y = xalt; a.N = DD; a.K = DH;            // x' += h . W2^T, in place (one wave per row)
                 launch_gemv3<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
                 prof_mark(e, PK_W2);
             }
+            std::swap(xin, xalt);
             continue;
         }
         if (!(e->skip_kinds & (1u << PK_QKV)))
@@ -1422,7 +1430,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     }
     {   // final norm -> tied-embedding logits -> per-block argmax (voxtral_decoder.c:694-704)
         GemvArgs a{};
-        a.W = e->tok_emb; a.x = e->dx; a.norm_w = e->dec_final_norm; a.eps = d.dec_eps; a.y = logits_dst;
+        a.W = e->tok_emb; a.x = xin; a.norm_w = e->dec_final_norm; a.eps = d.dec_eps; a.y = logits_dst;
         a.N = d.vocab; a.K = DD; a.blk_val = e->blk_val; a.blk_idx = e->blk_idx;
         if (fast && e->use_fp8) {
             a.W = reinterpret_cast<const uint16_t *>(e->tok_emb8); a.wscale = e->stok;

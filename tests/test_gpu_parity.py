@@ -380,6 +380,16 @@ def test_stream_full_size_matches_reference_golden(vox):
         assert np.array_equal(np.asarray(plain["tokens"]), g["tokens"])
 
 
+def test_stream_full_size_real_speech_matches_reference_golden(vox):
+    """The reference's own sample (samples/jfk.wav, 11 s of speech, stored in the fixture) at the real 4B
+    geometry: 149 steps, 102 distinct ids, smallest reference top-2 margin 2e-3."""
+    g = gold("stream_full_jfk.npz")
+    with vox.Model(model_dir("full")) as m:
+        res = check_stream("full_jfk", g, run_case(m, g))
+    assert res["ok"], res
+    assert res["ref_steps"] >= 140 and res["n_distinct_ref"] > 90, res
+
+
 def test_fp8_decode_weights_track_bf16(vox):
     """BASELINE config 5: fp8 e4m3 copies (one f32 scale per output row) of the decoder matrices for the decode GEMVs.
     Not a parity mode: every weight moves by up to 2^-4 relative, so logits move by ~1e-2 and a greedy id can flip wherever

@@ -62,6 +62,8 @@ CASES = [
 # the headline configuration itself: 32 + 26 layers, vocabulary 131072, the 30 s night1968 input
 FULL_CASES = [
     ("full_batch", "full", 30.0, 0, None, None, False, None, "benchmark/night1968/45s_right_through_the_billboard.wav"),
+    # BASELINE config 1's input at the full geometry, fed as main.c feeds a file: 16000-sample pieces
+    ("full_jfk", "full", 0, 0, "1s", None, False, None, "jfk.wav"),
 ]
 
 

@@ -236,7 +236,9 @@ static int launch_gemm(vox_hip_engine *e, const float *X, int ldx, const uint16_
         int ksplit = 1;
         const int min_slices = x3 ? 2 : 4;            // keep >= 128 k per split
         if (e->use_splitk && tm * tn < 384 && nk >= 2 * min_slices) {
-            ksplit = std::min(std::min((512 + tm * tn - 1) / (tm * tn), nk / min_slices), 16);
+            // 2 workgroups per CU are resident (73.7 KB of LDS each): stay within ONE round of 512.  Rounding up (round 1:
+            // 130 tiles x 4 splits = 520 workgroups) cost a second round for the last 8 - 85 us instead of ~57 for wo / w2.
+            ksplit = std::min(std::min(std::max(1, 512 / (tm * tn)), nk / min_slices), 16);
             if (ksplit < 2) ksplit = 1;
         }
         if (ksplit > 1) {

@@ -120,4 +120,21 @@ __device__ __forceinline__ float dot16_fp8(const uint4 w, const float4 x0, const
     return acc;
 }
 
+
+// Tuning aid (VOX_HIP_FUSE_TL): per-workgroup timeline of one launch, 16 words per workgroup: [0] wall clock at entry,
+// [1] at exit, [2] (XCC_ID << 32) | HW_ID, [3 ..] the kernel's phase stamps - start skew, tails, XCD placement and where
+// every workgroup spends its time.
+constexpr int TL_STRIDE = 16;
+__device__ __forceinline__ unsigned long long tl_begin(const unsigned long long *tl) { return tl ? wall_clock64() : 0ull; }
+__device__ __forceinline__ void tl_end(unsigned long long *tl, unsigned long long t0, const unsigned long long *stamps = nullptr, int n = 0) {
+    if (!tl) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_REG_HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID, bits 3:0
+        unsigned long long *r = tl + (size_t)TL_STRIDE * blockIdx.x;
+        r[0] = t0; r[1] = wall_clock64(); r[2] = ((unsigned long long)xcc << 32) | hw;
+        for (int k = 0; k < n && k < TL_STRIDE - 3; k++) r[3 + k] = stamps[k];
+    }
+}
 }  // namespace vox

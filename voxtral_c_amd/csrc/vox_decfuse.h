@@ -69,9 +69,10 @@ struct DecFuseArgs {
     unsigned long long spin_limit;   // wall_clock64 ticks
     unsigned long long *trace;       // optional (tuning): [2 blocks][16] wall-clock stamps of the phases, blocks 0 and 255
     int spread_groups;               // test switch: group = blockIdx / 32 (members spread over all XCDs) instead of blockIdx % 8
+    unsigned long long *tl;          // optional (tuning): per-workgroup timeline, see tl_begin / tl_end
 };
 // stamps stay in registers until the end: a store in the middle would shift the hand-counted s_waitcnt vmcnt values
-#define DF_MARK(k) do { if (a.trace) df_stamp[k] = wall_clock64(); } while (0)
+#define DF_MARK(k) do { if (a.trace || a.tl) df_stamp[k] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ void df_store_granule(u64 *g, unsigned epoch, float v) {
     __hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     const int j = a.spread_groups ? blockIdx.x % DF_BPG : blockIdx.x / DF_GROUPS;
     const unsigned epoch = a.epoch;
     const int pos = a.pos;
-    unsigned long long df_stamp[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long df_stamp[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tl0 = tl_begin(a.tl);
     DF_MARK(0);
 
     // ---- this workgroup's 24 weight rows: 16 of Wq, 4 of Wk, 4 of Wv; wave w streams rows 3w .. 3w+2 -------------
@@ -214,20 +216,43 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     // The CU issues its waves oldest first: without this barrier wave 0 would put all of its weight loads into the CU's
     // memory FIFO before wave 7 has issued its share of the activation vector (measured: activations landing at 4.7 us
     // instead of ~2, and at 15 us in the 12-wave k_gemv_w13x below).
+    DF_MARK(11);
     __builtin_amdgcn_s_barrier();
-    u32x4 w[3][6];
+    DF_MARK(12);
+    // The weight loads (and the Wo rows later) are ordinary non-temporal loads the compiler counts.  They used to be inline
+    // asm with hand-counted s_waitcnt: a register an asm load is still writing looks "defined" to the compiler, which is then
+    // free to copy it or to reuse it before the data has landed - it did both as soon as the surrounding code changed (seen in
+    // the ISA: v_mov of the last piece's registers in front of the wait; the sweep's temporaries on top of in-flight Wo rows).
+    // What made asm necessary is gone: no LDS-DMA (asm, uncounted) is issued between the weight loads and their use any
+    // more, so the compiler's in-order wait counts are exact here, and where asm DMAs are queued in front they only over-wait.
+    uint4 w[3][6];
 #pragma unroll
     for (int c = 0; c < 6; c++)
 #pragma unroll
-        for (int i = 0; i < 3; i++) df_ld_weight(w[i][c], rp[i] + c * 1024);
+        for (int i = 0; i < 3; i++) w[i][c] = ld_stream(reinterpret_cast<const uint4 *>(rp[i] + c * 1024));
+    __builtin_amdgcn_sched_barrier(0);
     // The first K/V tile (it does not depend on this step's q) and this workgroup's slice of Wo (registers: row i =
     // Wo[96 j + i][512 g .. 512 g + 511] = 1 KiB, 12 rows per wave) follow the projection weights in the queue.  They are
     // issued four at a time behind each weight piece as it lands: a wave that tried to issue them all up front would sit in
     // the issue stage behind the CU's full memory queue instead of doing the RMSNorm and the dot products (measured: +4 us).
     // (Issuing Wo only after the first hand-off sweep was measured too: the sweep is gated by the slowest of the group's 32
     // producers, ~3 us behind the median, and Wo streaming during that wait is worth more than a shorter sweep.)
-    u32x4 wv[12];
-    const unsigned char *wo_src = reinterpret_cast<const unsigned char *>(a.wo) + ((size_t)(DF_WO_ROWS * j + 12 * wave) * DF_DQ + DF_NQ * g) * 2 + lane * 16;
+    // Wo rows (row r = Wo[r][512 g .. 512 g + 511] = 1 KiB).  Up to 8 key slices (KV <= 512: the 30 s clip) the attention members
+    // carry none - they are the critical path, everybody waits for their partials - and the other 32 - ns members share the
+    // group's 3072 rows (13 .. 16 per wave); beyond that every member takes 96 (12 per wave).  A wave always issues 16 loads
+    // (rows past its share re-read its last one) so that the hand-counted waits below hold for every workgroup.
+    uint4 wv[16];        // compiler-visible non-temporal loads (see DF_LATE_WO)
+    const bool wo_light = ns <= 8;
+    int wo_rpw = 12, wo_row0 = DF_WO_ROWS * j + 12 * wave;
+    if (wo_light) {
+        const int nb = DF_BPG - ns, rpb = ((DF_D + nb - 1) / nb + 7) & ~7;
+        wo_rpw = rpb >> 3;
+        wo_row0 = att_block ? DF_D : (j - ns) * rpb + wave * wo_rpw;
+    }
+    const int wo_n = max(0, min(wo_rpw, DF_D - wo_row0));
+    const int wo_rmax = wo_n > 0 ? wo_row0 + wo_n - 1 : DF_D - 1;
+    const unsigned char *wo_base = reinterpret_cast<const unsigned char *>(a.wo) + (size_t)(DF_NQ * g) * 2 + lane * 16;
+#define DF_WO_PTR(i) (wo_base + (size_t)min(wo_row0 + (i), wo_rmax) * (DF_DQ * 2))
     const int tile_last = att_block ? s_hi : 0;
     DF_MARK(1);
 
@@ -248,8 +273,8 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
 #pragma unroll
         for (int k = 0; k < 8; k++) df_tile_op(a, g, s_lo, tile_last, lds_addr(tiles), lds_addr(tiles + DF_TILE_BYTES), wave, lane, k, att_block);
 #pragma unroll
-        for (int i = 0; i < 12; i++) df_ld_weight(wv[i], wo_src + (size_t)i * (DF_DQ * 2));
-        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        for (int i = 0; i < 16; i++) wv[i] = ld_stream(reinterpret_cast<const uint4 *>(DF_WO_PTR(i)));
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(18)" ::: "memory");          // only the 18 weight loads are younger than the activation DMAs
     }
@@ -289,30 +314,32 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
 
     // ---- dot products, piece by piece as the weights land ------------------------------------------------------------
     float acc[3] = {0.f, 0.f, 0.f};
-#define DF_PIECE(C, N)                                                                                   \
+#define DF_PIECE(C)                                                                                      \
     {                                                                                                    \
-        DF_WAIT3(N, w[0][C], w[1][C], w[2][C]);                                                          \
         const float4 x0 = *reinterpret_cast<const float4 *>(xs + (C * 64 + lane) * 8);                   \
         const float4 x1 = *reinterpret_cast<const float4 *>(xs + (C * 64 + lane) * 8 + 4);               \
-        _Pragma("unroll") for (int i = 0; i < 3; i++)                                                    \
-            acc[i] = dot8_bf16(make_uint4(w[i][C].x, w[i][C].y, w[i][C].z, w[i][C].w), x0, x1, acc[i]);  \
+        _Pragma("unroll") for (int i = 0; i < 3; i++) acc[i] = dot8_bf16(w[i][C], x0, x1, acc[i]);       \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
     }
-#define DF_LATE_TILE(K0)                                                                                 \
-    if constexpr (!EMBED) { _Pragma("unroll") for (int k = K0; k < K0 + 4; k++)                          \
-        df_tile_op(a, g, s_lo, tile_last, lds_addr(tiles), lds_addr(tiles + DF_TILE_BYTES), wave, lane, k, att_block); }
 #define DF_LATE_WO(I0)                                                                                   \
-    if constexpr (!EMBED) { _Pragma("unroll") for (int i = I0; i < I0 + 4; i++) df_ld_weight(wv[i], wo_src + (size_t)i * (DF_DQ * 2)); }
-    // wait for piece c = remaining weight loads 3 (5 - c) + late operations issued so far 4 c
-    // (EMBED: everything was issued and has landed already; the waits then only tie the registers to the asm loads)
-    DF_PIECE(0, 15) DF_LATE_TILE(0)
-    DF_PIECE(1, 16) DF_LATE_TILE(4)
-    DF_PIECE(2, 17) DF_LATE_WO(0)
-    DF_PIECE(3, 18) DF_LATE_WO(4)
-    DF_PIECE(4, 19) DF_LATE_WO(8)
-    DF_PIECE(5, 20)
+    if constexpr (!EMBED) { _Pragma("unroll") for (int i = I0; i < I0 + 4; i++) wv[i] = ld_stream(reinterpret_cast<const uint4 *>(DF_WO_PTR(i))); }
+    // The two kinds of workgroup order their memory queue differently (per-workgroup timeline, tools/fuse_timeline.py).
+    // The members that run attention (j < nsplit: 4 of a group's 32 at the 30 s clip's KV length) gate everybody: nobody's
+    // sweep completes before the LAST member has published, and all wait for their partials.  With the K/V tile (64 KB) and
+    // Wo rows (96 KB) interleaved into the weight stream they published 3 us after the others (12.2 vs 9.1 us), and Wo rows
+    // of the early finishers competed with the projection weights of the late ones.  So: everybody takes nothing but the
+    // projection weights first; an attention member queues its K/V tile behind the last piece (it lands under the publish
+    // and the sweep); the others, who have no use for q/k/v and nothing to do until the partials arrive, queue their Wo rows
+    // after their publish.
+    DF_PIECE(0) DF_PIECE(1) DF_PIECE(2) DF_PIECE(3) DF_PIECE(4) DF_PIECE(5)
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]) :: "memory");     // the tile DMAs below stay below the dot products
+    if (att_block) {
+        if constexpr (!EMBED) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) df_tile_op(a, g, s_lo, tile_last, lds_addr(tiles), lds_addr(tiles + DF_TILE_BYTES), wave, lane, k, true);
+        }
+    }
 #undef DF_PIECE
-#undef DF_LATE_TILE
-#undef DF_LATE_WO
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const float sres = df_wave_sum<USE_DPP>(acc[i]);
@@ -344,6 +371,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     }
     __syncthreads();                       // xs / nw are dead from here on: 24 KB of scratch for the attention stage
     DF_MARK(5);
+    if (!att_block) { DF_LATE_WO(0) DF_LATE_WO(4) DF_LATE_WO(8) DF_LATE_WO(12) }
 
     float *qs = xs;                        // [512] the group's q
     float *kvn = xs + 512;                 // [256] this step's k | v of head g
@@ -352,8 +380,8 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     float *pt = xs + 1792;                 // [4 heads][64 keys] softmax numerators of the current tile
     float *cr = xs + 2048;                 // [4] rescale of the running output, [4] running max, [4] running sum
 
-    // ---- hand-off 1: sweep the group's 768 granules ------------------------------------------------------------------
-    {
+    // ---- hand-off 1 (attention members only): sweep the group's 768 granules ------------------------------------------------
+    if (att_block) {
         u64 gv[2];
         gv[0] = df_load_granule(gq + tid);
         if (tid < 256) gv[1] = df_load_granule(gq + 512 + tid);
@@ -382,6 +410,9 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
             if (ti + 1 < n_tiles)                                    // next tile into the other buffer, under this tile's math
                 df_tile_dma(a, g, t0 + DF_TILE, s_hi, lds_addr(tiles + ((ti + 1) & 1) * 2 * DF_TILE_BYTES),
                             lds_addr(tiles + ((ti + 1) & 1) * 2 * DF_TILE_BYTES + DF_TILE_BYTES), wave, lane);
+            // Long contexts: the Wo rows of an attention member stream under its first tile's math (q/k/v and the tile are in,
+            // nothing this workgroup waits for is queued behind them until the partial sweep).
+            if (ti == 0 && !wo_light) { DF_LATE_WO(0) DF_LATE_WO(4) DF_LATE_WO(8) }
             if (t0 + DF_TILE > pos && t0 <= pos) {
                 // this step's own K/V row is not visible in the ring to other CUs yet: patch it in from the hand-off
                 const int key = pos - t0;
@@ -432,34 +463,50 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
             if (dd == 0) { df_store_granule(mine + 4 * DF_HD + 2 * ho, epoch, cr[4 + ho]); df_store_granule(mine + 4 * DF_HD + 2 * ho + 1, epoch, cr[8 + ho]); }
         }
     }
+#undef DF_LATE_WO
+#undef DF_WO_PTR
     DF_MARK(7);
 
     // ---- hand-off 2: sweep the group's partials and merge them in slice order (thread -> head, dim) ---------------------
-    {
+    // (an attention member without Wo rows is done: it only has to let its loads drain)
+    if (!(wo_light && att_block)) {
         const int h = tid >> 7, d = tid & 127;
         float M = -1e30f, L = 0.f, O = 0.f;
-        for (int s0 = 0; s0 < ns; s0 += 4) {           // 4 slices = 12 loads in flight per thread, then check the tags
+        // 28 of a group's 32 workgroups arrive here long before the partials exist.  ONE thread per workgroup polls (one granule
+        // of the last slice); the other 511 sleep at the barrier: with every thread re-reading its granules the pollers took so
+        // much of the fabric that the attention members - whom they are waiting for - finished 2 us later (measured).
+        if (tid == 0) (void)df_wait_granule(gp + (size_t)(ns - 1) * DF_GP + 4 * DF_HD, epoch, a, 2u);
+        __syncthreads();
+        for (int s0 = 0; s0 < ns; s0 += 4) {           // 4 slices = 12 loads in flight per thread, re-issued together until every tag matches
             u64 gv[4][3];
+            const unsigned long long t0 = wall_clock64();
+            for (unsigned it = 0;; it++) {
+                bool ok = true;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const u64 *part = gp + (size_t)min(s0 + u, ns - 1) * DF_GP;
-                gv[u][0] = df_load_granule(part + h * DF_HD + d);
-                gv[u][1] = df_load_granule(part + 4 * DF_HD + 2 * h);
-                gv[u][2] = df_load_granule(part + 4 * DF_HD + 2 * h + 1);
+                for (int u = 0; u < 4; u++) {
+                    const u64 *part = gp + (size_t)min(s0 + u, ns - 1) * DF_GP;
+                    gv[u][0] = df_load_granule(part + h * DF_HD + d);
+                    gv[u][1] = df_load_granule(part + 4 * DF_HD + 2 * h);
+                    gv[u][2] = df_load_granule(part + 4 * DF_HD + 2 * h + 1);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) ok = ok && (unsigned)(gv[u][k] >> 32) == epoch;
+                if (ok) break;
+                // bounded like df_wait_granule: a timeout (or an earlier one of any launch) gives up and flags the batch
+                if ((it & 15u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(4);
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (s0 + u >= ns) break;
-                const u64 *part = gp + (size_t)(s0 + u) * DF_GP;
-                const u64 *src[3] = {part + h * DF_HD + d, part + 4 * DF_HD + 2 * h, part + 4 * DF_HD + 2 * h + 1};
-                float val[3];
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                    val[k] = (unsigned)(gv[u][k] >> 32) == epoch ? __uint_as_float((unsigned)gv[u][k]) : df_wait_granule(src[k], epoch, a, 2u);
-                const float mn = fmaxf(M, val[1]);
-                const float c0 = expf(M - mn), c1 = expf(val[1] - mn);
-                L = L * c0 + val[2] * c1;
-                O = O * c0 + val[0] * c1;
+                const float v0 = __uint_as_float((unsigned)gv[u][0]), vm = __uint_as_float((unsigned)gv[u][1]), vl = __uint_as_float((unsigned)gv[u][2]);
+                const float mn = fmaxf(M, vm);
+                const float c0 = expf(M - mn), c1 = expf(vm - mn);
+                L = L * c0 + vl * c1;
+                O = O * c0 + v0 * c1;
                 M = mn;
             }
         }
@@ -467,27 +514,29 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     }
     DF_MARK(8);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the Wo slice has landed in its registers
-    DF_TIE4(wv[0], wv[1], wv[2], wv[3]); DF_TIE4(wv[4], wv[5], wv[6], wv[7]); DF_TIE4(wv[8], wv[9], wv[10], wv[11]);
     __syncthreads();
     DF_MARK(9);
 
-    // ---- this workgroup's 96 rows of  Wo[:, 512 g .. 512 g + 511] . att  (12 per wave) ---------------------------------------
-    {
+    // ---- this wave's rows of  Wo[:, 512 g .. 512 g + 511] . att ------------------------------------------------------------------
+    if (wo_n > 0) {
         const float4 x0 = *reinterpret_cast<const float4 *>(att + lane * 8);
         const float4 x1 = *reinterpret_cast<const float4 *>(att + lane * 8 + 4);
         float mine = 0.f;
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const float s = df_wave_sum<USE_DPP>(dot8_bf16(make_uint4(wv[i].x, wv[i].y, wv[i].z, wv[i].w), x0, x1, 0.f));
-            if (lane == i) mine = s;
+        for (int i = 0; i < 16; i++) {
+            if (i < wo_n) {
+                const float s = df_wave_sum<USE_DPP>(dot8_bf16(wv[i], x0, x1, 0.f));
+                if (lane == i) mine = s;
+            }
         }
-        if (lane < 12) a.wo_part[(size_t)g * DF_D + DF_WO_ROWS * j + 12 * wave + lane] = mine;
+        if (lane < wo_n) a.wo_part[(size_t)g * DF_D + wo_row0 + lane] = mine;
     }
     DF_MARK(10);
     if (a.trace && tid == 0 && (blockIdx.x == 0 || blockIdx.x == DF_BLOCKS - 1)) {
 #pragma unroll
         for (int k = 0; k < 11; k++) a.trace[(blockIdx.x ? 16 : 0) + k] = df_stamp[k];
     }
+    tl_end(a.tl, tl0, df_stamp, 13);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -507,6 +556,8 @@ struct W13xArgs {
     float *x_out;              // [3072] x' (may alias x)
     float *h;                  // [9216]
     unsigned long long *trace; // optional (tuning): [2 blocks][16] stamps, written at +32
+    unsigned long long *tl;    // optional (tuning): per-workgroup timeline
+    int shift;                 // test switch: workgroup b streams the rows of workgroup (b + shift) % 256
 };
 constexpr int W13X_THREADS = 768;
 constexpr int W13X_LDS_BYTES = (9 + 2 + 1) * DF_D * 4 + 256;
@@ -522,6 +573,7 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned wofs = (unsigned)wave * 1024u;        // 12 waves x 1 KiB = one 12 KB vector per DMA round
     unsigned long long df_stamp[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long tl0 = tl_begin(a.tl);
     DF_MARK(0);
 
     glds16(a.x + tid * 4, lds_addr(stage) + wofs);
@@ -536,7 +588,7 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
     // products ran after the stream instead of under it.  Round 0 (144 KB per CU) is issued before the prologue and covers
     // it; rounds 1 and 2 are issued as the previous round's dot products retire.
     uint4 w[2][3][6];
-    const int pair0 = blockIdx.x * 36 + wave * 3;
+    const int pair0 = ((blockIdx.x + a.shift) & 255) * 36 + wave * 3;
     const uint4 *p1[3], *p3[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -608,6 +660,7 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
 #pragma unroll
         for (int k = 0; k < 5; k++) a.trace[32 + (blockIdx.x ? 16 : 0) + k] = df_stamp[k];
     }
+    tl_end(a.tl, tl0, df_stamp, 5);
 }
 
 }  // namespace vox

@@ -51,6 +51,7 @@ struct GemvArgs {
     int pos_host;              // k_gemv3 EPI_QKV: logical position of this step (RoPE angle, KV slot)
     const float *wscale, *wscale2;   // fp8 weights (W8): per-row dequantisation scale of W / W2
     int row_base;              // EPI_LOGITS: added to the row index reported in blk_idx (vocabulary halves)
+    unsigned long long *tl;    // optional (tuning, k_gemv3): per-workgroup timeline, see tl_begin / tl_end
 };
 
 template <int PRO, int EPI, int RPW, bool W8 = false>
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
     const int N = a.N;
     const int row0 = (blockIdx.x * RG + rg) * RPW;
     const int ns = (PRO == PRO_ATTN) ? a.nsplit : 0;
+    const unsigned long long tl0 = tl_begin(a.tl);
 
     // ---- operand loads, as lambdas so that the two launch modes can order them ----------------
     float yv[RPW];
@@ -797,6 +799,7 @@ __global__ __launch_bounds__(256, MINW) void k_gemv3(const GemvArgs a) {
             }
         }
     }
+    tl_end(a.tl, tl0);
 }
 
 }  // namespace vox

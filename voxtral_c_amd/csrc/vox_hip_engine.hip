@@ -137,6 +137,7 @@ struct vox_hip_engine {
     unsigned *d_fuse_err = nullptr;
     unsigned fuse_epoch = 0;
     unsigned long long *d_fuse_trace = nullptr;
+    unsigned long long *d_fuse_tl = nullptr;      // VOX_HIP_FUSE_TL: [3 kernels][1024 workgroups][3] timeline of the layer-13 launches
     int fuse_failures = 0;
     int *d_tokens = nullptr;
     float *dpart_o = nullptr, *dpart_ml = nullptr;   // decode-step split-K partials (max splits)
@@ -452,6 +453,8 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
             e->use_fused = ok;
             if (ok && getenv("VOX_HIP_FUSE_TRACE") && hipMalloc((void **)&e->d_fuse_trace, 64 * 8) == hipSuccess)
                 hipMemset(e->d_fuse_trace, 0, 64 * 8);
+            if (ok && getenv("VOX_HIP_FUSE_TL") && hipMalloc((void **)&e->d_fuse_tl, 3 * 1024 * TL_STRIDE * 8) == hipSuccess)
+                hipMemset(e->d_fuse_tl, 0, 3 * 1024 * TL_STRIDE * 8);
         }
     }
 
@@ -1301,6 +1304,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     // while the other 255 workgroups may not have fetched x yet - in place that is a race that only bites when workgroups
     // of one launch start far apart (two models sharing the GPU: found by test_two_decoders_sharing_the_gpu_stay_correct).
     float *xin = e->dx, *xalt = e->dx2;
+    static const int tl_layer = getenv("VOX_HIP_FUSE_TL_LAYER") ? atoi(getenv("VOX_HIP_FUSE_TL_LAYER")) : 13;
     for (int l = 0; l < d.dec_layers; l++) {
         DecLayer &L = e->dec[l];
         if (fused) {
@@ -1315,6 +1319,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.epoch = e->fuse_epoch; a.split_keys = f_split; a.nsplit = f_ns;
                 a.err = e->d_fuse_err; a.spin_limit = 500000ull;         // 5 ms at the 100 MHz wall clock (a hand-off takes microseconds)
                 a.trace = (l == 13) ? e->d_fuse_trace : nullptr;          // tuning: phase stamps of one mid-stack launch
+                a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl : nullptr;
                 static const int spread = getenv("VOX_HIP_FUSE_SPREAD") ? 1 : 0;    // test: group members on all XCDs
                 a.spread_groups = spread;
                 const bool emb = (l == 0 && build_embed);
@@ -1333,12 +1338,16 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.w1 = L.w13; a.w3 = L.w13 + (size_t)DH * DD; a.x = xin; a.wo_part = e->d_wo_part; a.norm_w = L.n2; a.ada = L.ada;
                 a.eps = d.dec_eps; a.x_out = xalt; a.h = e->dh;
                 a.trace = (l == 13) ? e->d_fuse_trace : nullptr;
+                a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + TL_STRIDE * 1024 : nullptr;
+                static const int w13_shift = getenv("VOX_HIP_W13_SHIFT") ? atoi(getenv("VOX_HIP_W13_SHIFT")) : 0;   // test switch
+                a.shift = w13_shift;
                 hipLaunchKernelGGL(k_gemv_w13x, dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
                 prof_mark(e, PK_SWIGLU);
             }
             if (!(e->skip_kinds & (1u << PK_W2))) {
                 GemvArgs a{};
                 a.W = L.w2; a.x = e->dh; a.y = xalt; a.N = DD; a.K = DH;            // x' += h . W2^T, in place (one wave per row)
+                a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + 2 * TL_STRIDE * 1024 : nullptr;
                 launch_gemv3<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
                 prof_mark(e, PK_W2);
             }
@@ -1721,6 +1730,25 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
                 for (int k = 1; k <= 4; k++) fprintf(stderr, " %d:%.2f", k, (double)(h[32 + b * 16 + k] - h[32 + b * 16]) / 100.0);
                 fprintf(stderr, "\n");
             }
+    }
+    if (e->d_fuse_tl && getenv("VOX_HIP_FUSE_TL")) {      // per-workgroup timeline of the last step's layer-13 launches -> text file
+        std::vector<unsigned long long> h((size_t)3 * 1024 * TL_STRIDE);
+        FILE *f = fopen(getenv("VOX_HIP_FUSE_TL"), "w");
+        if (f && hipMemcpy(h.data(), e->d_fuse_tl, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long t0 = ~0ull;
+            for (int b = 0; b < 256; b++) if (h[(size_t)TL_STRIDE * b] && h[(size_t)TL_STRIDE * b] < t0) t0 = h[(size_t)TL_STRIDE * b];
+            fprintf(f, "# kernel block start_us end_us xcc hw_id stamps...   (kernel 0 = k_dec_attn_fused, 1 = k_gemv_w13x, 2 = k_gemv3 W2; 100 MHz clock)\n");
+            for (int k = 0; k < 3; k++)
+                for (int b = 0; b < 1024; b++) {
+                    const unsigned long long *r = &h[(size_t)(k * 1024 + b) * TL_STRIDE];
+                    if (!r[0]) continue;
+                    fprintf(f, "%d %d %.2f %.2f %u %u", k, b, (double)(r[0] - t0) / 100.0, (double)(r[1] - t0) / 100.0,
+                            (unsigned)(r[2] >> 32), (unsigned)r[2]);
+                    for (int q = 3; q < TL_STRIDE; q++) fprintf(f, " %.2f", r[q] ? (double)(r[q] - t0) / 100.0 : -1.0);
+                    fprintf(f, "\n");
+                }
+        }
+        if (f) fclose(f);
     }
     return (double)ms * 1e-3 / iters;
 }

@@ -663,4 +663,61 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
     tl_end(a.tl, tl0, df_stamp, 5);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// k_gemv_w2x - the FFN down-projection of a decoder step, same shape as k_gemv_w13x:
+//     x'' = x' + W2 h        (voxtral_decoder.c:688-690)
+// ONE 768-thread workgroup per CU, wave w streams row 12 b + w of W2 (18 KB = 18 x 16 B per lane) in three staged rounds,
+// h (36 KB) is staged once per CU by LDS-DMA.  (k_gemv3 ran this as 512 four-wave workgroups, two per CU, each staging
+// its own copy of h and splitting every row between two waves: 5.5 TB/s against this layout's 6.3 in k_gemv_w13x.)
+// ---------------------------------------------------------------------------------------------------------
+struct W2xArgs {
+    const uint16_t *w2;        // [3072][9216]
+    const float *h;            // [9216]
+    float *x;                  // [3072] residual stream, updated in place (every row is read and written by its one wave)
+    unsigned long long *tl;    // optional (tuning): per-workgroup timeline
+};
+constexpr int W2X_THREADS = 768, W2X_K = 9216;
+constexpr int W2X_LDS_BYTES = W2X_K * 4 + 64;
+
+__global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *hs = smem;                    // [9216]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wofs = (unsigned)wave * 1024u;
+    const unsigned long long tl0 = tl_begin(a.tl);
+    const int row = blockIdx.x * 12 + wave;
+    const float resid = a.x[row];
+#pragma unroll
+    for (int p = 0; p < 3; p++) glds16(a.h + p * 3072 + tid * 4, lds_addr(hs + p * 3072) + wofs);
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 w[18];
+    const uint4 *wp = reinterpret_cast<const uint4 *>(a.w2 + (size_t)row * W2X_K) + lane;
+#define W2_ISSUE(R) { _Pragma("unroll") for (int c = 6 * (R); c < 6 * (R) + 6; c++) w[c] = ld_stream(wp + c * 64); }
+#define W2_DOT(R)                                                                                  \
+    { _Pragma("unroll") for (int c = 6 * (R); c < 6 * (R) + 6; c++) {                               \
+        const float4 x0 = *reinterpret_cast<const float4 *>(hs + (c * 64 + lane) * 8);              \
+        const float4 x1 = *reinterpret_cast<const float4 *>(hs + (c * 64 + lane) * 8 + 4);          \
+        acc = dot8_bf16(w[c], x0, x1, acc); } }
+    W2_ISSUE(0)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the residual load and the 3 DMAs are in; round 0 still streams
+    __syncthreads();
+    float acc = 0.f;
+    W2_ISSUE(1)
+    __builtin_amdgcn_sched_barrier(0);
+    W2_DOT(0)
+    __builtin_amdgcn_sched_barrier(0);
+    W2_ISSUE(2)
+    __builtin_amdgcn_sched_barrier(0);
+    W2_DOT(1)
+    __builtin_amdgcn_sched_barrier(0);
+    W2_DOT(2)
+#undef W2_ISSUE
+#undef W2_DOT
+    acc = wave_sum(acc);
+    if (lane == 0) a.x[row] = resid + acc;
+    tl_end(a.tl, tl0);
+}
 }  // namespace vox

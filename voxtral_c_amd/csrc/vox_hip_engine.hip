@@ -448,7 +448,8 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  hipFuncSetAttribute((const void *)k_dec_attn_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_dec_attn_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_dec_attn_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_gemv_w13x, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess;
+                 hipFuncSetAttribute((const void *)k_gemv_w13x, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_gemv_w2x, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess;
             if (!ok) { (void)hipGetLastError(); fprintf(stderr, "vox_hip: fused decode kernels unavailable; launch-per-GEMV chain\n"); }
             e->use_fused = ok;
             if (ok && getenv("VOX_HIP_FUSE_TRACE") && hipMalloc((void **)&e->d_fuse_trace, 64 * 8) == hipSuccess)
@@ -1345,10 +1346,18 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 prof_mark(e, PK_SWIGLU);
             }
             if (!(e->skip_kinds & (1u << PK_W2))) {
-                GemvArgs a{};
-                a.W = L.w2; a.x = e->dh; a.y = xalt; a.N = DD; a.K = DH;            // x' += h . W2^T, in place (one wave per row)
-                a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + 2 * TL_STRIDE * 1024 : nullptr;
-                launch_gemv3<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
+                static const int old_w2 = getenv("VOX_HIP_OLD_W2") ? 1 : 0;         // A/B switch: the k_gemv3 launch this replaced
+                if (old_w2) {
+                    GemvArgs a{};
+                    a.W = L.w2; a.x = e->dh; a.y = xalt; a.N = DD; a.K = DH;        // x' += h . W2^T, in place
+                    a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + 2 * TL_STRIDE * 1024 : nullptr;
+                    launch_gemv3<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
+                } else {
+                    W2xArgs a{};
+                    a.w2 = L.w2; a.h = e->dh; a.x = xalt;                            // x' += h . W2^T, in place (one wave per row)
+                    a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + 2 * TL_STRIDE * 1024 : nullptr;
+                    hipLaunchKernelGGL(k_gemv_w2x, dim3(256), dim3(W2X_THREADS), W2X_LDS_BYTES, s, a);
+                }
                 prof_mark(e, PK_W2);
             }
             std::swap(xin, xalt);

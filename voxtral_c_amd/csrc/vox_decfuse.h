@@ -20,15 +20,14 @@
 // no flag, no fence, the data is the flag.  The epoch is the engine's launch counter, so buffers are
 // reused launch after launch without clearing.
 //
-// Memory queue of a workgroup (a CU returns loads in issue order, so order = schedule):
-//   t0  inv_freq, x, norm weights                by LDS-DMA   (needed first)
-//       6 weight rows per wave (36 x 16 B/lane)  registers, non-temporal, piece-major
-//       first half of this workgroup's Wo slice  by LDS-DMA   (96 rows x 512 columns = 96 KB in LDS)
-//   t1  (weights consumed piece by piece as they land: explicit s_waitcnt vmcnt(N); the weight loads
-//        are inline asm so that the compiler's own wait counting cannot over-wait on the younger DMA)
-//       second half of the Wo slice, publish q/k/v, sweep the group's q/k/v  (lands behind the Wo
-//        stream: by then every producer has long published), attention over this workgroup's key
-//        slice, publish the partial, sweep the partials, merge, Wo partial product from LDS.
+// Memory queue of a workgroup (a CU returns loads in issue order, so order = schedule; DESIGN.md 8.1 has the timeline):
+//   t0  inv_freq, x, norm weights                    by LDS-DMA   (needed first)
+//       3 weight rows per wave (18 x 16 B per lane)  registers, non-temporal, ordinary loads (compiler-counted waits)
+//   t1  RMSNorm, then the dot products piece by piece as the weights land; RoPE; publish q/k/v
+//   attention members (j < nsplit):  K/V tile (LDS-DMA) behind the last weight piece -> sweep q/k/v -> attention over their
+//       key slice -> publish the partial.  Up to 8 slices they carry no Wo rows and are done here.
+//   the others:  13-16 Wo rows per wave queued after their publish -> ONE thread polls for the partials -> batch sweep, merge
+//       -> Wo partial product from registers.
 // Output: wo_part[g][3072], the 8 K-split partial sums of the projection; the next launch
 // (k_gemv_w13x, below) adds them to the residual stream in a fixed order in its prologue.
 //

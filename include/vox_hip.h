@@ -240,9 +240,11 @@ enum vox_hip_path {
     VOX_PATH_FP8_DECODE       = 1u << 6,   /* fp8 decode weights in use (config 5 only)                    */
     VOX_PATH_SKINNY_ENC       = 1u << 7,   /* streaming encoder chunks (<= 32 rows) on the weight-streaming kernels */
     VOX_PATH_DEC_FUSED        = 1u << 8,   /* decode step: qkv + attention + wo as one launch (k_dec_attn_fused), 3 launches per layer */
+    VOX_PATH_GEMM_PLANES      = 1u << 9,   /* large-M GEMMs on producer-split bf16 planes, LDS-DMA pipeline (k_gemm_planes) */
 };
 #define VOX_PATH_ALL_BF16 (VOX_PATH_GEMM_MFMA_BF16X3 | VOX_PATH_GEMM_MFMA_F32 | VOX_PATH_GEMM_SPLITK | \
-                           VOX_PATH_ATTN_ENC_MFMA | VOX_PATH_ATTN_DEC_DPP | VOX_PATH_GEMV3 | VOX_PATH_DEC_FUSED | VOX_PATH_SKINNY_ENC)
+                           VOX_PATH_ATTN_ENC_MFMA | VOX_PATH_ATTN_DEC_DPP | VOX_PATH_GEMV3 | VOX_PATH_DEC_FUSED | VOX_PATH_SKINNY_ENC | \
+                           VOX_PATH_GEMM_PLANES)
 unsigned vox_hip_active_paths(const vox_hip_engine_t *e);
 
 /* Experiment: seconds per pass over ONE decoder layer's five kernels run back to back (weights

@@ -44,6 +44,8 @@ struct GemmArgs {
     // (deterministic — no atomics).
     int ksplit, kper;
     float *partial;
+    // k_gemm_planes (vox_gemm_planes.h): the activations pre-split into bf16 planes [3][M][K] (hi, mid, lo), row stride ldxp
+    const uint16_t *Xp; size_t xp_plane; int ldxp;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -54,7 +56,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // Fused epilogue shared by the MFMA kernels (C/D layout of every 32x32 MFMA: col = lane&31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[2][2], int bm0, int bn0, int wm, int wn,
+template <int TN = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[2][TN], int bm0, int bn0, int wm, int wn,
                                               int li, int lg) {
     const int M = a.M, N = a.N;
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
@@ -63,8 +66,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[2
 #pragma unroll
         for (int tm = 0; tm < 2; tm++)
 #pragma unroll
-            for (int tn = 0; tn < 2; tn++) {
-                const int col = bn0 + wn * 64 + tn * 32 + li;
+            for (int tn = 0; tn < TN; tn++) {
+                const int col = bn0 + wn * (32 * TN) + tn * 32 + li;
                 if (col >= N) continue;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
@@ -77,8 +80,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[2
 #pragma unroll
     for (int tm = 0; tm < 2; tm++)
 #pragma unroll
-        for (int tn = 0; tn < 2; tn++) {
-            const int col = bn0 + wn * 64 + tn * 32 + li;
+        for (int tn = 0; tn < TN; tn++) {
+            const int col = bn0 + wn * (32 * TN) + tn * 32 + li;
             if (col >= N) continue;
             const float b = a.bias ? a.bias[col] : 0.f;
 #pragma unroll

@@ -23,6 +23,7 @@
 #include "vox_common.h"
 #include "vox_gemv.h"
 #include "vox_gemm.h"
+#include "vox_gemm_planes.h"
 #include "vox_misc.h"
 #include "vox_attn.h"
 #include "vox_kernel_api.h"
@@ -137,6 +138,9 @@ struct vox_hip_engine {
     unsigned *d_fuse_err = nullptr;
     unsigned fuse_epoch = 0;
     unsigned long long *d_fuse_trace = nullptr;
+    bool use_planes = true;       // large-M GEMMs on pre-split bf16 planes (k_gemm_planes)
+    int gp_tn = 2;                // MFMA tiles per wave along N in k_gemm_planes (2: 128 x 128 workgroup tile, 4: 128 x 256)
+    Buf splanes;                  // [3][n][max(D, QD, H)] bf16
     unsigned long long *d_fuse_tl = nullptr;      // VOX_HIP_FUSE_TL: [3 kernels][1024 workgroups][3] timeline of the layer-13 launches
     int fuse_failures = 0;
     int *d_tokens = nullptr;
@@ -257,6 +261,36 @@ static int launch_gemm(vox_hip_engine *e, const float *X, int ldx, const uint16_
     } else {
         dim3 grid((N + 63) / 64, (M + 3) / 4);
         hipLaunchKernelGGL(k_gemm_scalar, grid, dim3(256), 0, e->stream, a);
+    }
+    return 0;
+}
+
+// y = sum_p Xp[p] . W^T on pre-split activations (vox_gemm_planes.h); same epilogue / split-K contract as launch_gemm.
+static int launch_gemm_planes(vox_hip_engine *e, const uint16_t *Xp, size_t plane, int ldxp, const uint16_t *W, float *Y, int ldy,
+                              int M, int N, int K, const float *bias, const float *resid, int ldr, int act) {
+    GemmArgs a{nullptr, 0, W, Y, ldy, M, N, K, bias, resid, ldr, act, 1, 0, nullptr};
+    a.Xp = Xp; a.xp_plane = plane; a.ldxp = ldxp;
+    if (M <= 0 || N <= 0) return 0;
+    const int TN = e->gp_tn, st = 2;
+    const int BN = 64 * TN;
+    const int tn = (N + BN - 1) / BN, tm = (M + GB_M - 1) / GB_M, nk = K / GP_K;
+    const int resident = 512;                      // 2 workgroups per CU (64 / 80 KB of LDS each)
+    int ksplit = 1;
+    if (e->use_splitk && tm * tn < (resident * 3) / 4 && nk >= 8) {
+        ksplit = std::min(std::min(std::max(1, resident / (tm * tn)), nk / 4), 16);
+        if (ksplit < 2) ksplit = 1;
+    }
+    auto kern = TN == 2 ? k_gemm_planes<2, 2> : k_gemm_planes<2, 4>;
+    const size_t lds = (size_t)st * gp_stage_bytes(TN);
+    if (ksplit > 1) {
+        if (ensure(e, e->ssplitk, (size_t)ksplit * M * N * 4)) return -1;
+        a.ksplit = ksplit; a.kper = (nk + ksplit - 1) / ksplit; a.partial = (float *)e->ssplitk.p;
+        a.ksplit = (nk + a.kper - 1) / a.kper;
+        dim3 grid(tn, tm, a.ksplit);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, e->stream, a);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((size_t)M * N)), dim3(256), 0, e->stream, a);
+    } else {
+        hipLaunchKernelGGL(kern, dim3(tn, tm), dim3(256), lds, e->stream, a);
     }
     return 0;
 }
@@ -619,10 +653,22 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
     float *gu = (float *)e->sgu.p, *h = (float *)e->sh.p, *tab = (float *)e->srope.p;
     const int N3 = c.QD + 2 * c.KVD;
     hipStream_t s = e->stream;
-    // 1. attention_norm
-    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, s, xn, c.D, x, c.D, n1, (const float *)nullptr, c.D, c.eps);
-    // 2. merged QKV projection (+ q/v bias on the encoder, voxtral_encoder.c:542-544)
-    if (launch_gemm(e, xn, c.D, wqkv, qkv, N3, n, N3, c.D, bqkv, nullptr, 0, ACT_NONE)) return -1;
+    // Large chunks: the activations of every GEMM are written by their producer as bf16 planes (exact 3-term split, once)
+    // and the GEMMs run on k_gemm_planes; small ones keep the f32-activation kernels.
+    const bool planes = e->use_planes && e->use_mfma && e->use_bf16x3 && n >= 64 && c.D % GP_K == 0 && c.QD % GP_K == 0 && c.H % GP_K == 0;
+    uint16_t *P = nullptr;
+    if (planes) {
+        if (ensure(e, e->splanes, (size_t)3 * n * std::max(std::max(c.D, c.QD), c.H) * 2)) return -1;
+        P = (uint16_t *)e->splanes.p;
+    }
+    // 1. attention_norm   2. merged QKV projection (+ q/v bias on the encoder, voxtral_encoder.c:542-544)
+    if (planes) {
+        hipLaunchKernelGGL(k_rmsnorm_planes, dim3(n), dim3(256), 0, s, P, (size_t)n * c.D, (const float *)x, c.D, n1, (const float *)nullptr, c.D, c.eps);
+        if (launch_gemm_planes(e, P, (size_t)n * c.D, c.D, wqkv, qkv, N3, n, N3, c.D, bqkv, nullptr, 0, ACT_NONE)) return -1;
+    } else {
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, s, xn, c.D, x, c.D, n1, (const float *)nullptr, c.D, c.eps);
+        if (launch_gemm(e, xn, c.D, wqkv, qkv, N3, n, N3, c.D, bqkv, nullptr, 0, ACT_NONE)) return -1;
+    }
     // 3. RoPE on q and k columns (table built once per chunk by the caller)
     hipLaunchKernelGGL(k_rope_apply, dim3(grid1d((size_t)n * (c.QD + c.KVD) / 2)), dim3(256), 0, s,
                        qkv, N3, n, c.QD + c.KVD, c.hd, tab);
@@ -679,6 +725,16 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
         if (nsplit > 1)
             hipLaunchKernelGGL((k_attn_combine<128>), dim3(c.heads, n), dim3(128), 0, s, attn, c.QD,
                                (const float *)a.part_o, (const float *)a.part_ml, c.heads, nsplit);
+    }
+    if (planes) {
+        // 5. x += attn.Wo^T (+bo)   6. ffn_norm (+ ada)   7. SwiGLU: merged W1;W3 GEMM, gate, W2 (+b2) + residual
+        hipLaunchKernelGGL(k_split_planes, dim3(grid1d((size_t)n * c.QD / 4)), dim3(256), 0, s, P, (size_t)n * c.QD, (const float *)attn, c.QD, n, c.QD);
+        if (launch_gemm_planes(e, P, (size_t)n * c.QD, c.QD, wo, x, c.D, n, c.D, c.QD, bo, x, c.D, ACT_NONE)) return -1;
+        hipLaunchKernelGGL(k_rmsnorm_planes, dim3(n), dim3(256), 0, s, P, (size_t)n * c.D, (const float *)x, c.D, n2, ada, c.D, c.eps);
+        if (launch_gemm_planes(e, P, (size_t)n * c.D, c.D, w13, gu, 2 * c.H, n, 2 * c.H, c.D, nullptr, nullptr, 0, ACT_NONE)) return -1;
+        hipLaunchKernelGGL(k_silu_mul_planes, dim3(grid1d((size_t)n * c.H / 4)), dim3(256), 0, s, P, (size_t)n * c.H, (const float *)gu, n, c.H);
+        if (launch_gemm_planes(e, P, (size_t)n * c.H, c.H, w2, x, c.D, n, c.D, c.H, b2, x, c.D, ACT_NONE)) return -1;
+        return 0;
     }
     // 5. x += attn.Wo^T (+bo)
     if (launch_gemm(e, attn, c.QD, wo, x, c.D, n, c.D, c.QD, bo, x, c.D, ACT_NONE)) return -1;
@@ -1963,6 +2019,31 @@ static int self_test(vox_hip_engine *e) {
         e->use_mfma = false; failed++;
     }
     if (getenv("VOX_HIP_NO_BF16X3")) e->use_bf16x3 = false;
+    {   // (2b) the planes GEMM (pre-split activations, LDS-DMA pipeline) on the same problem, with and without split-K
+        if (getenv("VOX_HIP_GP_TN")) e->gp_tn = atoi(getenv("VOX_HIP_GP_TN")) == 4 ? 4 : 2;
+        bool okp = hipFuncSetAttribute((const void *)k_gemm_planes<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(2)) == hipSuccess &&
+                   hipFuncSetAttribute((const void *)k_gemm_planes<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(4)) == hipSuccess;
+        uint16_t *dp = nullptr;
+        okp = okp && hipMalloc((void **)&dp, (size_t)3 * M * K * 2) == hipSuccess;
+        if (okp) {
+            hipLaunchKernelGGL(k_split_planes, dim3(grid1d((size_t)M * K / 4)), dim3(256), 0, e->stream, dp, (size_t)M * K, (const float *)dx, K, M, K);
+            double worst = 0;
+            for (int pass = 0; pass < 2 && okp; pass++) {
+                const bool sk = e->use_splitk;
+                if (pass == 1) e->use_splitk = false;
+                okp = launch_gemm_planes(e, dp, (size_t)M * K, K, dw, dy0, N, M, N, K, dbias, nullptr, 0, ACT_NONE) == 0;
+                e->use_splitk = sk;
+                okp = okp && hipStreamSynchronize(e->stream) == hipSuccess &&
+                      hipMemcpy(hy0.data(), dy0, hy0.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+                for (size_t i = 0; okp && i < hy0.size(); i++) worst = std::max(worst, (double)fabsf(hy0[i] - hy2[i]));
+            }
+            if (!(worst < 2e-5)) okp = false;
+            if (!okp) fprintf(stderr, "vox_hip: planes GEMM self-test FAILED (max diff %g)\n", worst);
+        }
+        if (dp) hipFree(dp);
+        if (!okp) { (void)hipGetLastError(); e->use_planes = false; failed++; }
+        if (getenv("VOX_HIP_NO_PLANES")) e->use_planes = false;
+    }
 
     // (3) MFMA encoder attention vs the thread-per-query kernel: 200 queries, 2 heads, window 90
     {
@@ -2039,6 +2120,7 @@ extern "C" unsigned vox_hip_active_paths(const vox_hip_engine_t *e) {
     if (e->use_fp8) m |= VOX_PATH_FP8_DECODE;
     if (fast_geom && e->use_fused && !e->use_fp8) m |= VOX_PATH_DEC_FUSED;
     if (e->use_skinny && e->use_mfma) m |= VOX_PATH_SKINNY_ENC;
+    if (e->use_planes && e->use_mfma && e->use_bf16x3) m |= VOX_PATH_GEMM_PLANES;
     return m;
 }
 

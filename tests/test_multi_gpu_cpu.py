@@ -76,6 +76,9 @@ class OracleShardEngine:
         u = vo.linear_bf16(xn, w.bf(w.enc(l, "feed_forward.w3.weight")))
         self.x = x + vo.linear_bf16(g * u, w.bf(w.enc(l, "feed_forward.w2.weight")), w.f32(w.enc(l, "feed_forward.w2.bias")))
 
+    def sync(self):
+        pass
+
     def kv_export(self, l, pos_first, n, buf):
         kk, vv = self.own_k[l], self.own_v[l]
         if self.tail_k[l] is not None:

@@ -202,10 +202,16 @@ def encode_sharded(eng, comm, padded, n_frames, staging, dst=0):
     assert n == pos1 - pos0, (n, pos0, pos1)
     tail = min(eng.window - 1, pos0)                       # positions we need from the left
     send_tail = min(eng.window - 1, pos1) if rank + 1 < world else 0
-    s_in = staging((2, max(tail, 1), eng.kv_dim))
+    # Two receive buffers, alternating by layer: kv_import only ENQUEUES its copies on the engine stream, so the buffer of
+    # layer l - 1 may still be read while layer l's tail arrives.  A buffer is reused two layers later; by then the engine
+    # stream has been synchronised by kv_export - except on a rank that never exports (the last one), which syncs itself.
+    s_ins = [staging((2, max(tail, 1), eng.kv_dim)) for _ in range(2)]
     s_out = staging((2, max(send_tail, 1), eng.kv_dim))
     for l in range(eng.n_layers):
         if rank > 0 and tail > 0:
+            s_in = s_ins[l & 1]
+            if send_tail == 0 and l >= 2:
+                eng.sync()
             comm.recv(s_in.tensor, rank - 1)
             comm.sync()
             s_in.before_engine_read()

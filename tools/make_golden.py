@@ -64,6 +64,8 @@ FULL_CASES = [
     ("full_batch", "full", 30.0, 0, None, None, False, None, "benchmark/night1968/45s_right_through_the_billboard.wav"),
     # BASELINE config 1's input at the full geometry, fed as main.c feeds a file: 16000-sample pieces
     ("full_jfk", "full", 0, 0, "1s", None, False, None, "jfk.wav"),
+    # BASELINE config 3's feed pattern at the full geometry: 0.5 s feeds, -I 0.5, continuous mode (20 s of the night1968 clip)
+    ("full_stream", "full", 20.0, 0, 8000, 0.5, True, None, "benchmark/night1968/45s_right_through_the_billboard.wav"),
 ]
 
 

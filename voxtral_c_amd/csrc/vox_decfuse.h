@@ -547,7 +547,8 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
 // x' back (the W2 launch reads it as its residual).
 // ---------------------------------------------------------------------------------------------------------
 struct W13xArgs {
-    const uint16_t *w1, *w3;   // [9216][3072] each
+    const uint16_t *w1, *w3;   // [9216][3072] each (W8: fp8 e4m3 bytes, one f32 scale per row in s1 / s3)
+    const float *s1, *s3;
     const float *x;            // [3072]
     const float *wo_part;      // [8][3072]
     const float *norm_w, *ada; // [3072]
@@ -561,6 +562,7 @@ struct W13xArgs {
 constexpr int W13X_THREADS = 768;
 constexpr int W13X_LDS_BYTES = (9 + 2 + 1) * DF_D * 4 + 256;
 
+template <bool W8>
 __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *stage = smem;                 // [9][3072]: x, wo_part[0..7]
@@ -586,17 +588,20 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
     // slowest of the 12 waves reached the prologue barrier only after ~15 us (measured), so the sum / RMSNorm and all dot
     // products ran after the stream instead of under it.  Round 0 (144 KB per CU) is issued before the prologue and covers
     // it; rounds 1 and 2 are issued as the previous round's dot products retire.
-    uint4 w[2][3][6];
-    const int pair0 = ((blockIdx.x + a.shift) & 255) * 36 + wave * 3;
+    // bf16: 6 pieces of 1 KiB per row (8 weights per lane and piece); fp8: 3 pieces (16 weights per lane and piece)
+    constexpr int NP = W8 ? 3 : 6, EPP = W8 ? 16 : 8;
+    uint4 w[2][3][NP];
+    const int pair0 = blockIdx.x * 36 + wave * 3;
     const uint4 *p1[3], *p3[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        p1[r] = reinterpret_cast<const uint4 *>(a.w1 + (size_t)(pair0 + r) * DF_D) + lane;
-        p3[r] = reinterpret_cast<const uint4 *>(a.w3 + (size_t)(pair0 + r) * DF_D) + lane;
+        constexpr size_t ROWB = W8 ? DF_D : 2 * DF_D;
+        p1[r] = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.w1) + (size_t)(pair0 + r) * ROWB) + lane;
+        p3[r] = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.w3) + (size_t)(pair0 + r) * ROWB) + lane;
     }
 #define W13_ISSUE(C)                                                                    \
-    { _Pragma("unroll") for (int r = 0; r < 3; r++) w[0][r][C] = ld_stream(p1[r] + (C) * 64); \
-      _Pragma("unroll") for (int r = 0; r < 3; r++) w[1][r][C] = ld_stream(p3[r] + (C) * 64); }
+    if constexpr ((C) < NP) { _Pragma("unroll") for (int r = 0; r < 3; r++) w[0][r][(C) < NP ? (C) : 0] = ld_stream(p1[r] + (C) * 64); \
+      _Pragma("unroll") for (int r = 0; r < 3; r++) w[1][r][(C) < NP ? (C) : 0] = ld_stream(p3[r] + (C) * 64); }
     W13_ISSUE(0) W13_ISSUE(1)
     __builtin_amdgcn_sched_barrier(0);
     DF_MARK(1);
@@ -629,11 +634,20 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
     DF_MARK(3);
     float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 #define W13_DOT(C)                                                                      \
-    {                                                                                   \
-        const float4 x0 = *reinterpret_cast<const float4 *>(xs + ((C) * 64 + lane) * 8);     \
-        const float4 x1 = *reinterpret_cast<const float4 *>(xs + ((C) * 64 + lane) * 8 + 4); \
-        _Pragma("unroll") for (int m = 0; m < 2; m++)                                   \
-            _Pragma("unroll") for (int r = 0; r < 3; r++) acc[m][r] = dot8_bf16(w[m][r][C], x0, x1, acc[m][r]); \
+    if constexpr ((C) < NP) {                                                           \
+        constexpr int CC = (C) < NP ? (C) : 0;                                          \
+        const float *xp = xs + (CC * 64 + lane) * EPP;                                  \
+        const float4 x0 = *reinterpret_cast<const float4 *>(xp);                        \
+        const float4 x1 = *reinterpret_cast<const float4 *>(xp + 4);                    \
+        if constexpr (W8) {                                                             \
+            const float4 x2 = *reinterpret_cast<const float4 *>(xp + 8);                \
+            const float4 x3 = *reinterpret_cast<const float4 *>(xp + 12);               \
+            _Pragma("unroll") for (int m = 0; m < 2; m++)                               \
+                _Pragma("unroll") for (int r = 0; r < 3; r++) acc[m][r] = dot16_fp8(w[m][r][CC], x0, x1, x2, x3, acc[m][r]); \
+        } else {                                                                        \
+            _Pragma("unroll") for (int m = 0; m < 2; m++)                               \
+                _Pragma("unroll") for (int r = 0; r < 3; r++) acc[m][r] = dot8_bf16(w[m][r][CC], x0, x1, acc[m][r]); \
+        }                                                                               \
     }
     W13_ISSUE(2) W13_ISSUE(3)
     __builtin_amdgcn_sched_barrier(0);
@@ -652,7 +666,11 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
         for (int r = 0; r < 3; r++) acc[m][r] = wave_sum(acc[m][r]);
     if (lane == 0) {
 #pragma unroll
-        for (int r = 0; r < 3; r++) a.h[pair0 + r] = silu(acc[0][r]) * acc[1][r];      // voxtral_decoder.c:684-687
+        for (int r = 0; r < 3; r++) {
+            float g = acc[0][r], u = acc[1][r];
+            if constexpr (W8) { g *= a.s1[pair0 + r]; u *= a.s3[pair0 + r]; }          // per-row dequantisation scale
+            a.h[pair0 + r] = silu(g) * u;                                               // voxtral_decoder.c:684-687
+        }
     }
     DF_MARK(4);
     if (a.trace && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 255)) {
@@ -671,7 +689,8 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
 // its own copy of h and splitting every row between two waves: 5.5 TB/s against this layout's 6.3 in k_gemv_w13x.)
 // ---------------------------------------------------------------------------------------------------------
 struct W2xArgs {
-    const uint16_t *w2;        // [3072][9216]
+    const uint16_t *w2;        // [3072][9216] (W8: fp8 e4m3 bytes, one f32 scale per row in s2)
+    const float *s2;
     const float *h;            // [9216]
     float *x;                  // [3072] residual stream, updated in place (every row is read and written by its one wave)
     unsigned long long *tl;    // optional (tuning): per-workgroup timeline
@@ -679,6 +698,7 @@ struct W2xArgs {
 constexpr int W2X_THREADS = 768, W2X_K = 9216;
 constexpr int W2X_LDS_BYTES = W2X_K * 4 + 64;
 
+template <bool W8>
 __global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *hs = smem;                    // [9216]
@@ -691,17 +711,26 @@ __global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
 #pragma unroll
     for (int p = 0; p < 3; p++) glds16(a.h + p * 3072 + tid * 4, lds_addr(hs + p * 3072) + wofs);
     __builtin_amdgcn_sched_barrier(0);
-    uint4 w[18];
-    const uint4 *wp = reinterpret_cast<const uint4 *>(a.w2 + (size_t)row * W2X_K) + lane;
-#define W2_ISSUE(R) { _Pragma("unroll") for (int c = 6 * (R); c < 6 * (R) + 6; c++) w[c] = ld_stream(wp + c * 64); }
+    // bf16: 18 pieces of 1 KiB per row in rounds of 6; fp8: 9 pieces in rounds of 3
+    constexpr int NP = W8 ? 9 : 18, RND = NP / 3, EPP = W8 ? 16 : 8;
+    uint4 w[NP];
+    const uint4 *wp = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.w2) + (size_t)row * (W8 ? W2X_K : 2 * W2X_K)) + lane;
+#define W2_ISSUE(R) { _Pragma("unroll") for (int c = RND * (R); c < RND * (R) + RND; c++) w[c] = ld_stream(wp + c * 64); }
 #define W2_DOT(R)                                                                                  \
-    { _Pragma("unroll") for (int c = 6 * (R); c < 6 * (R) + 6; c++) {                               \
-        const float4 x0 = *reinterpret_cast<const float4 *>(hs + (c * 64 + lane) * 8);              \
-        const float4 x1 = *reinterpret_cast<const float4 *>(hs + (c * 64 + lane) * 8 + 4);          \
-        acc = dot8_bf16(w[c], x0, x1, acc); } }
+    { _Pragma("unroll") for (int c = RND * (R); c < RND * (R) + RND; c++) {                         \
+        const float *xp = hs + (c * 64 + lane) * EPP;                                               \
+        const float4 x0 = *reinterpret_cast<const float4 *>(xp);                                    \
+        const float4 x1 = *reinterpret_cast<const float4 *>(xp + 4);                                \
+        if constexpr (W8) {                                                                         \
+            const float4 x2 = *reinterpret_cast<const float4 *>(xp + 8);                            \
+            const float4 x3 = *reinterpret_cast<const float4 *>(xp + 12);                           \
+            acc = dot16_fp8(w[c], x0, x1, x2, x3, acc);                                             \
+        } else {                                                                                    \
+            acc = dot8_bf16(w[c], x0, x1, acc);                                                     \
+        } } }
     W2_ISSUE(0)
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the residual load and the 3 DMAs are in; round 0 still streams
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RND) : "memory");      // the residual load and the 3 DMAs are in; round 0 still streams
     __syncthreads();
     float acc = 0.f;
     W2_ISSUE(1)
@@ -716,6 +745,7 @@ __global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
 #undef W2_ISSUE
 #undef W2_DOT
     acc = wave_sum(acc);
+    if constexpr (W8) acc *= a.s2[row];
     if (lane == 0) a.x[row] = resid + acc;
     tl_end(a.tl, tl0);
 }

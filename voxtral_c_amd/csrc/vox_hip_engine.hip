@@ -482,8 +482,10 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  hipFuncSetAttribute((const void *)k_dec_attn_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_dec_attn_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_dec_attn_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_gemv_w13x, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_gemv_w2x, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess;
+                 hipFuncSetAttribute((const void *)k_gemv_w13x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_gemv_w13x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_gemv_w2x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_gemv_w2x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess;
             if (!ok) { (void)hipGetLastError(); fprintf(stderr, "vox_hip: fused decode kernels unavailable; launch-per-GEMV chain\n"); }
             e->use_fused = ok;
             if (ok && getenv("VOX_HIP_FUSE_TRACE") && hipMalloc((void **)&e->d_fuse_trace, 64 * 8) == hipSuccess)
@@ -1350,7 +1352,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     const int nsplit = (kv_len + split_keys - 1) / split_keys;
     const bool fuse_combine = fast && nsplit <= 8;
     const float scale = 1.0f / sqrtf((float)HD);
-    const bool fused = fast && e->use_fused && !e->use_fp8;
+    const bool fused = fast && e->use_fused;          // fp8 mode: qkv / wo stay on the bf16 matrices (k_dec_attn_fused), w1;w3 and w2 stream the fp8 copies
     // fused path: key slices of the attention stage (<= 32 per KV head, multiples of 64 keys)
     int f_split = 64, f_ns = 1;
     if (fused) {
@@ -1398,7 +1400,13 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + TL_STRIDE * 1024 : nullptr;
                 static const int w13_shift = getenv("VOX_HIP_W13_SHIFT") ? atoi(getenv("VOX_HIP_W13_SHIFT")) : 0;   // test switch
                 a.shift = w13_shift;
-                hipLaunchKernelGGL(k_gemv_w13x, dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
+                if (e->use_fp8) {
+                    a.w1 = reinterpret_cast<const uint16_t *>(L.w138); a.w3 = reinterpret_cast<const uint16_t *>(L.w138 + (size_t)DH * DD);
+                    a.s1 = L.s13; a.s3 = L.s13 + DH;
+                    hipLaunchKernelGGL(k_gemv_w13x<true>, dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
+                } else {
+                    hipLaunchKernelGGL(k_gemv_w13x<false>, dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
+                }
                 prof_mark(e, PK_SWIGLU);
             }
             if (!(e->skip_kinds & (1u << PK_W2))) {
@@ -1412,7 +1420,12 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                     W2xArgs a{};
                     a.w2 = L.w2; a.h = e->dh; a.x = xalt;                            // x' += h . W2^T, in place (one wave per row)
                     a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + 2 * TL_STRIDE * 1024 : nullptr;
-                    hipLaunchKernelGGL(k_gemv_w2x, dim3(256), dim3(W2X_THREADS), W2X_LDS_BYTES, s, a);
+                    if (e->use_fp8) {
+                        a.w2 = reinterpret_cast<const uint16_t *>(L.w28); a.s2 = L.s2;
+                        hipLaunchKernelGGL(k_gemv_w2x<true>, dim3(256), dim3(W2X_THREADS), W2X_LDS_BYTES, s, a);
+                    } else {
+                        hipLaunchKernelGGL(k_gemv_w2x<false>, dim3(256), dim3(W2X_THREADS), W2X_LDS_BYTES, s, a);
+                    }
                 }
                 prof_mark(e, PK_W2);
             }
@@ -2118,7 +2131,7 @@ extern "C" unsigned vox_hip_active_paths(const vox_hip_engine_t *e) {
     if (e->use_splitk) m |= VOX_PATH_GEMM_SPLITK;
     if (fast_geom && e->use_gemv2 && e->use_gemv3) m |= VOX_PATH_GEMV3;
     if (e->use_fp8) m |= VOX_PATH_FP8_DECODE;
-    if (fast_geom && e->use_fused && !e->use_fp8) m |= VOX_PATH_DEC_FUSED;
+    if (fast_geom && e->use_fused) m |= VOX_PATH_DEC_FUSED;
     if (e->use_skinny && e->use_mfma) m |= VOX_PATH_SKINNY_ENC;
     if (e->use_planes && e->use_mfma && e->use_bf16x3) m |= VOX_PATH_GEMM_PLANES;
     return m;

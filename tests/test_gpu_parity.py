@@ -503,6 +503,31 @@ def test_fused_decode_step_matches_the_launch_per_gemv_chain(vox):
     assert same == n, (same, n)
 
 
+def test_fused_decode_step_matches_the_chain_at_long_context(vox):
+    """The same comparison where the fused kernel works differently: 200 s of audio = 2500 decoder steps, KV to ~2540 -
+    every member of a KV-head group runs attention (up to 32 key slices, two K/V tiles each beyond 2048 keys), Wo rows ride under
+    the first tile, and the partials are merged by the two-round-trip scheme (weights from the (max, sum) pairs first, then one
+    batch of up to 32 granules per thread).  The chain's ids are teacher-forced into the fused run so that every step sees the
+    same inputs; the two argmax sequences may then differ only at numerical near-ties (different summation order)."""
+    audio = synth_speech(200.0, 77)
+    os.environ["VOX_HIP_NO_FUSED"] = "1"
+    try:
+        with vox.Model(model_dir("full")) as m2:
+            c = m2.transcribe(audio, record_logits=64)
+    finally:
+        del os.environ["VOX_HIP_NO_FUSED"]
+    with vox.Model(model_dir("full")) as m:
+        a = m.transcribe(audio, record_logits=64, force_tokens=c["tokens"])
+        assert "dec_fused" in m.active_paths()[1], "a hand-off timed out: the engine fell back to the chain"
+    n = len(c["tokens"])
+    assert n > 2400 and len(a["tokens"]) == n
+    diff = int((a["tokens"] != c["tokens"]).sum())
+    err = float(np.abs(a["logits"] - c["logits"]).max())
+    diag("fused_vs_chain_long", steps=n, differing_argmax=diff, max_logit_diff_first_64=err)
+    assert err < 2e-4, err
+    assert diff <= n // 500, (diff, n)          # near-ties only: a wrong merge changes most steps
+
+
 def test_two_decoders_sharing_the_gpu_stay_correct(vox):
     """The fused decode kernel needs its 256 workgroups co-resident (one per CU).  Two models decoding at the same time on
     one GPU (two host threads, two HIP streams) can split the CUs between their launches; a hand-off that then cannot

@@ -476,6 +476,51 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
         // much of the fabric that the attention members - whom they are waiting for - finished 2 us later (measured).
         if (tid == 0) (void)df_wait_granule(gp + (size_t)(ns - 1) * DF_GP + 4 * DF_HD, epoch, a, 2u);
         __syncthreads();
+        if (ns > 8) {
+            // Many slices (long contexts): three round trips instead of one per 4 slices (the 30 slices of a 1900-key window took
+            // 8 of them, 6.5 - 8.7 us per layer, timeline).  First the (max, sum) pairs - 8 per slice, one thread each - into
+            // LDS and from them every slice's weight exp(m_s - M) / L per head; then every thread fetches its (head, dim) of
+            // all slices, 16 in flight, and adds them up in slice order.
+            float *mlv = xs + 2080;                    // [32 slices][4 heads][2]
+            float *scl = xs + 2080 + 256;              // [4 heads][32 slices]
+            if (tid < ns * 8) {
+                const u64 *src = gp + (size_t)(tid >> 3) * DF_GP + 4 * DF_HD + (tid & 7);
+                mlv[tid] = df_wait_granule(src, epoch, a, 2u);
+            }
+            __syncthreads();
+            if (tid < 128) {       // thread -> (head = tid >> 5, slice = tid & 31): max and sum over the 32-lane segment
+                const int hh = tid >> 5, s1 = tid & 31;
+                const float ms = s1 < ns ? mlv[(s1 * 4 + hh) * 2] : -1e30f, lsum = s1 < ns ? mlv[(s1 * 4 + hh) * 2 + 1] : 0.f;
+                float Mx = ms;
+#pragma unroll
+                for (int o = 16; o >= 1; o >>= 1) Mx = fmaxf(Mx, __shfl_xor(Mx, o, 32));
+                const float e = expf(ms - Mx);
+                float Ls = lsum * e;
+#pragma unroll
+                for (int o = 16; o >= 1; o >>= 1) Ls += __shfl_xor(Ls, o, 32);
+                scl[hh * 32 + s1] = Ls > 0.f ? e / Ls : 0.f;
+            }
+            __syncthreads();
+            {
+                u64 gv[32];
+                const unsigned long long t0 = wall_clock64();
+                for (unsigned it = 0;; it++) {
+                    bool ok = true;
+#pragma unroll
+                    for (int u = 0; u < 32; u++) gv[u] = df_load_granule(gp + (size_t)min(u, ns - 1) * DF_GP + h * DF_HD + d);
+#pragma unroll
+                    for (int u = 0; u < 32; u++) ok = ok && (unsigned)(gv[u] >> 32) == epoch;
+                    if (ok) break;
+                    if ((it & 15u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                    if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+#pragma unroll
+                for (int u = 0; u < 32; u++)
+                    if (u < ns) O = fmaf(scl[h * 32 + u], __uint_as_float((unsigned)gv[u]), O);
+            }
+            L = 1.0f;
+        } else
         for (int s0 = 0; s0 < ns; s0 += 4) {           // 4 slices = 12 loads in flight per thread, re-issued together until every tag matches
             u64 gv[4][3];
             const unsigned long long t0 = wall_clock64();

@@ -385,9 +385,20 @@ def test_stream_full_size_real_speech_matches_reference_golden(vox):
     geometry: 149 steps, 102 distinct ids, smallest reference top-2 margin 2e-3."""
     g = gold("stream_full_jfk.npz")
     with vox.Model(model_dir("full")) as m:
-        res = check_stream("full_jfk", g, run_case(m, g))
+        res = check_stream("full_jfk", g, run_case(m, g, 16000))
     assert res["ok"], res
     assert res["ref_steps"] >= 140 and res["n_distinct_ref"] > 90, res
+
+
+def test_stream_full_size_streaming_feeds_match_reference_golden(vox):
+    """BASELINE config 3's feed pattern at the real 4B geometry: the first 20 s of the night1968 clip in 0.5 s feeds with
+    -I 0.5 in continuous mode (the encoder runs on 25-row chunks: the k_skinny path; the decoder in bursts of 6-7 steps):
+    261 steps, 103 distinct ids, against the reference's own run of the same feeds."""
+    g = gold("stream_full_stream.npz")
+    with vox.Model(model_dir("full")) as m:
+        res = check_stream("full_stream", g, run_case(m, g, 8000, 0.5, True))
+    assert res["ok"], res
+    assert res["ref_steps"] >= 250 and res["n_distinct_ref"] > 90, res
 
 
 def test_fp8_decode_weights_track_bf16(vox):

@@ -56,6 +56,9 @@ CASES = [
     # synthetic audio through it: 3761 decoder steps, KV to 3799
     ("deep_batch", "deep", 30.0, 0, None, None, False, None, "benchmark/night1968/45s_right_through_the_billboard.wav"),
     ("deep_long", "deep", 300.0, 11, None, None, False),
+    # 700 s through the full depth: 8750 decoder steps, past the real decoder window of 8192 (KV compaction in the reference,
+    # ring wrap-around on the device)
+    ("deep_wrap", "deep", 700.0, 13, None, None, False),
     # 300 s at the real per-layer shapes: decode attention with KV to 3799 (many key slices)
     ("small_xlong", "small", 300.0, 12, None, None, False),
 ]

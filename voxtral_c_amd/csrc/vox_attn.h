@@ -506,6 +506,108 @@ __global__ __launch_bounds__(256) void k_attn_dec(const AttnArgs a, const int ns
     }
 }
 
+// Encoder attention for streaming-size chunks (n_q <= 32 queries, head_dim 64, no GQA): grid = (heads, 64-key slices of the
+// window), 256 threads; partials (o, m, l) in the layout k_attn_combine<64> merges.  k_attn_enc_mfma tiles 128 queries per
+// workgroup and spent 17.5 us per layer on a 25-row chunk, most of it on padding; this is plain f32 FMA (vox_causal_attention,
+// voxtral_kernels.c:412-482, up to summation order): lane = key for the scores (K row in registers, q broadcast from LDS),
+// lane = dim for P.V.
+__device__ __forceinline__ float as_dpp_sum(float v) {          // wave-wide sum: 4 DPP row steps + the 4 row sums via readlane
+    v = row16_sum<true>(v);
+    const int iv = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16)) +
+           __int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+}
+__device__ __forceinline__ float as_dpp_max(float v) {
+    int x;
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);  v = fmaxf(v, __int_as_float(x));
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);  v = fmaxf(v, __int_as_float(x));
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true); v = fmaxf(v, __int_as_float(x));
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true); v = fmaxf(v, __int_as_float(x));
+    const int iv = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48))));
+}
+
+template <bool USE_DPP>
+__global__ __launch_bounds__(256) void k_attn_small(const AttnArgs a, int key_lo) {
+    __shared__ __attribute__((aligned(16))) float qs[32][64];
+    __shared__ float ks[64][65];
+    __shared__ __attribute__((aligned(16))) float vs[64][64];
+    __shared__ __attribute__((aligned(16))) float ps[32][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, z = blockIdx.y, nz = gridDim.y;
+    const int n = a.n_q, t0 = key_lo + z * 64;
+    for (int i = tid; i < 512; i += 256) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n) v = *reinterpret_cast<const float4 *>(a.q + (size_t)r * a.ldq + h * 64 + c);
+        *reinterpret_cast<float4 *>(&qs[r][c]) = v;
+    }
+    for (int i = tid; i < 1024; i += 256) {
+        const int key = i >> 4, c = (i & 15) * 4;
+        const int pos = t0 + key;
+        float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+        if (pos <= a.last_key) {
+            if (pos >= a.posB0) {
+                const size_t off = (size_t)(pos - a.posB0) * a.ldB + h * 64 + c;
+                kk = *reinterpret_cast<const float4 *>(a.kB + off); vv = *reinterpret_cast<const float4 *>(a.vB + off);
+            } else {
+                const size_t off = (size_t)(pos % a.capA) * a.ldA + h * 64 + c;
+                kk = *reinterpret_cast<const float4 *>(a.kA + off); vv = *reinterpret_cast<const float4 *>(a.vA + off);
+            }
+        }
+        ks[key][c] = kk.x; ks[key][c + 1] = kk.y; ks[key][c + 2] = kk.z; ks[key][c + 3] = kk.w;
+        *reinterpret_cast<float4 *>(&vs[key][c]) = vv;
+    }
+    __syncthreads();
+    {   // scores and the slice's softmax statistics: wave = 8 query rows, lane = key
+        float kr[64];
+#pragma unroll
+        for (int d = 0; d < 64; d++) kr[d] = ks[lane][d];
+        const int t = t0 + lane;
+        // one row at a time (unrolling the 8 rows makes the compiler hoist all 512 q values into registers: 256 VGPRs + spills,
+        // 23 us); the reductions are DPP row steps + readlane, not ds_bpermute butterflies
+#pragma unroll 1
+        for (int r = 0; r < 8; r++) {
+            const int row = wave * 8 + r, P = a.qpos0 + row;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; d += 4) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(&qs[row][d]);
+                s = fmaf(q4.x, kr[d], s); s = fmaf(q4.y, kr[d + 1], s); s = fmaf(q4.z, kr[d + 2], s); s = fmaf(q4.w, kr[d + 3], s);
+            }
+            const bool ok = row < n && t <= a.last_key && t <= P && t >= P - a.window + 1;
+            s = ok ? s * a.scale : -1e30f;
+            const float m = USE_DPP ? as_dpp_max(s) : wave_max(s);
+            const float pe = (ok && m > -1e29f) ? expf(s - m) : 0.f;
+            const float l = USE_DPP ? as_dpp_sum(pe) : wave_sum(pe);
+            ps[row][lane] = pe;
+            if (lane == 0 && row < n) {
+                float *ml = a.part_ml + (((size_t)row * a.n_heads + h) * nz + z) * 2;
+                ml[0] = m > -1e29f ? m : -1e30f; ml[1] = l;
+            }
+        }
+    }
+    __syncthreads();
+    {   // P.V: wave = 8 query rows, lane = dim
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k4 = 0; k4 < 64; k4 += 4) {
+            const float v0 = vs[k4][lane], v1 = vs[k4 + 1][lane], v2 = vs[k4 + 2][lane], v3 = vs[k4 + 3][lane];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const float4 p4 = *reinterpret_cast<const float4 *>(&ps[wave * 8 + r][k4]);
+                acc[r] = fmaf(p4.x, v0, acc[r]); acc[r] = fmaf(p4.y, v1, acc[r]); acc[r] = fmaf(p4.z, v2, acc[r]); acc[r] = fmaf(p4.w, v3, acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int row = wave * 8 + r;
+            if (row < n) a.part_o[(((size_t)row * a.n_heads + h) * nz + z) * 64 + lane] = acc[r];
+        }
+    }
+}
+
 // Merge split-K partials.  grid = (n_heads, n_q), block = HD threads.
 template <int HD>
 __global__ __launch_bounds__(HD) void k_attn_combine(float *out, int ldo, const float *part_o,

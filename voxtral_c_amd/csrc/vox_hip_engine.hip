@@ -770,6 +770,19 @@ static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float 
     a.kB = qkv + c.QD; a.vB = qkv + c.QD + c.KVD; a.ldB = N3; a.posB0 = pos0; a.last_key = pos0 + n - 1;
     a.kA = kring; a.vA = vring; a.capA = ring_cap; a.ldA = c.KVD;
     a.n_heads = c.heads; a.n_kv_heads = c.kv_heads; a.scale = 1.0f / sqrtf((float)c.hd); a.window = c.window; a.st = nullptr;
+    static const int no_small = getenv("VOX_HIP_NO_ATTN_SMALL") ? 1 : 0;
+    if (n <= 32 && c.hd == 64 && c.heads == c.kv_heads && !no_small) {
+        // streaming-size chunk: (head, 64-key slice) workgroups on plain FMAs + the usual combine
+        const int lo = std::max(0, pos0 - c.window + 1), ks = (pos0 + n - 1 - lo) / 64 + 1;
+        if (ensure(e, e->spart_o, (size_t)n * c.heads * ks * c.hd * 4)) return -1;
+        if (ensure(e, e->spart_ml, (size_t)n * c.heads * ks * 2 * 4)) return -1;
+        a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
+        if (e->use_dpp) hipLaunchKernelGGL(k_attn_small<true>, dim3(c.heads, ks), dim3(256), 0, s, a, lo);
+        else hipLaunchKernelGGL(k_attn_small<false>, dim3(c.heads, ks), dim3(256), 0, s, a, lo);
+        hipLaunchKernelGGL((k_attn_combine<64>), dim3(c.heads, n), dim3(64), 0, s, attn, c.QD,
+                           (const float *)a.part_o, (const float *)a.part_ml, c.heads, ks);
+        return 0;
+    }
     const int qt = (n + 127) / 128, blocks = qt * c.heads;
     const int span = std::min(pos0 + n, c.window + std::min(n, 128));
     int ks = 1;

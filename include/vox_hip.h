@@ -86,6 +86,10 @@ int vox_hip_upload_bf16(vox_hip_engine_t *e, int tensor, int layer,
                         const uint16_t *host_bf16, size_t n_elems);
 int vox_hip_upload_f32(vox_hip_engine_t *e, int tensor, int layer,
                        const float *host_f32, size_t n_elems);
+/* Weights >= 4 MB go through a staged, multi-threaded pinned pipeline (page cache -> pinned slots -> hipMemcpyAsync); the engine's
+ * compute stream is ordered behind them.  vox_hip_upload_done waits for the last copy and releases the staging threads and buffers
+ * (reference side: the mmap loader voxtral_safetensors.c:204-429 + the per-tensor warm-up voxtral.c:163-251). */
+int vox_hip_upload_done(vox_hip_engine_t *e);
 /* Mel tables built by the host exactly as voxtral_audio.c:248-285,531-542 does:
  * filters [mel_bins,201], hann[400], dft_cos/sin [201,400]. */
 int vox_hip_upload_mel_tables(vox_hip_engine_t *e, const float *filters, const float *hann,

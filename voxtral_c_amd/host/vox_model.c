@@ -258,6 +258,7 @@ vox_ctx_t *vox_load_ex(const char *model_dir, const vox_load_opts_t *opts) {
         rc |= vox_hip_upload_mel_tables((vox_hip_engine_t *)ctx->engine, mt->filters, mt->hann, mt->dft_cos, mt->dft_sin);
     }
     if (!rc) rc |= update_time_conditioning(ctx);
+    if (!rc) rc |= vox_hip_upload_done((vox_hip_engine_t *)ctx->engine);      /* the staged weight copies have reached HBM */
     if (rc) { fprintf(stderr, "vox_load: failed to load weights\n"); vox_free(ctx); return NULL; }
 
     ctx->shard_engines[0] = ctx->engine;

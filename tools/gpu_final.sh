@@ -8,6 +8,8 @@ if [ -z "$SKIP_TESTS" ]; then
 echo "== pytest -m gpu"
 timeout 1500 python -m pytest tests -m gpu -q -rf --tb=short -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.log
 fi
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 echo "== headline bench (with the live PMC sub-run and the live CPU sample)"
 timeout 900 python bench.py --steps 10 --warmup 3 --cold-load > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 echo "== rocprofv3 kernel stats of the headline command"

@@ -46,6 +46,10 @@ struct GemmArgs {
     float *partial;
     // k_gemm_planes (vox_gemm_planes.h): the activations pre-split into bf16 planes [3][M][K] (hi, mid, lo), row stride ldxp
     const uint16_t *Xp; size_t xp_plane; int ldxp;
+    // k_gemm_planes epilogues: GP_EPI_SWIGLU writes silu(gate) * up as bf16 planes [3][M][N] (W = [w1; w3], w3 at row N);
+    // GP_EPI_ROPE applies the interleaved-pair RoPE (table [M][head_dim / 2][cos, sin]) to the first rope_cols columns
+    uint16_t *Yp; size_t yp_plane;
+    const float *rope_tab; int rope_cols, head_dim;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {

@@ -39,7 +39,9 @@ constexpr int gp_stage_bytes(int TN) { return 3 * GP_PLANE_BYTES + 64 * TN * GP_
 // reads 6 A fragments (2 row tiles x 3 planes) and TN B fragments for 6 TN MFMAs: with TN = 2 the LDS (fragment reads + the
 // DMA writes) is as busy as the matrix pipe (measured: 31 % MFMA utilisation, barely better than the kernel this replaces);
 // TN = 4 shares every A fragment between four B tiles (10 reads per 24 MFMAs).
-template <int NSTAGE, int TN>
+enum { GP_EPI_STD = 0, GP_EPI_SWIGLU = 1, GP_EPI_ROPE = 2 };
+
+template <int NSTAGE, int TN, int EPI = GP_EPI_STD>
 __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gp_smem[];
     constexpr int STAGE = gp_stage_bytes(TN);
@@ -72,7 +74,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
             src[i] = reinterpret_cast<const unsigned char *>(a.Xp + (size_t)(q >> 3) * a.xp_plane + (size_t)min(bm0 + row, M - 1) * a.ldxp) + dchunk * 16;
         } else {
             const int row = 16 * (q - 24) + drow;
-            src[i] = reinterpret_cast<const unsigned char *>(a.W + (size_t)min(bn0 + row, N - 1) * K) + dchunk * 16;
+            int wrow = min(bn0 + row, N - 1);
+            if constexpr (EPI == GP_EPI_SWIGLU) {
+                // a workgroup covers 64 hidden columns; tile row r = 64 wn + 32 tn + li holds gate (tn = 0: w1) or up (tn = 1: w3)
+                // of column 64 blockIdx.x + 32 wn + li, so that a lane's two accumulator tiles are the pair the gate needs
+                static_assert(EPI != GP_EPI_SWIGLU || TN == 2, "the SwiGLU epilogue pairs the two N tiles of a wave");
+                wrow = ((row >> 5) & 1) * N + min((int)blockIdx.x * 64 + (row >> 6) * 32 + (row & 31), N - 1);
+            }
+            src[i] = reinterpret_cast<const unsigned char *>(a.W + (size_t)wrow * K) + dchunk * 16;
         }
     }
     const unsigned lds_wave = lds_addr(gp_smem) + (unsigned)(wave * IPW) * 1024u;
@@ -134,7 +143,51 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
             compute(gp_smem + (size_t)(t % NSTAGE) * STAGE);
         }
     }
-    gemm_epilogue<TN>(a, acc, bm0, bn0, wm, wn, li, lg);
+    if constexpr (EPI == GP_EPI_SWIGLU) {
+        // h = silu(gate) * up (voxtral_encoder.c:598-606), written as the bf16 planes the W2 launch consumes
+        const int col = (int)blockIdx.x * 64 + wn * 32 + li;
+        if (col < N) {
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = bm0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                    if (row < M) {
+                        const float hv = silu(acc[tm][0][r]) * acc[tm][1][r];
+                        uint32_t ph, pm, pl;
+                        split3(hv, ph, pm, pl);
+                        uint16_t *dst = a.Yp + (size_t)row * N + col;
+                        dst[0] = (uint16_t)(ph >> 16); dst[a.yp_plane] = (uint16_t)(pm >> 16); dst[2 * a.yp_plane] = (uint16_t)(pl >> 16);
+                    }
+                }
+        }
+    } else if constexpr (EPI == GP_EPI_ROPE) {
+        // + bias, then the interleaved-pair RoPE (voxtral_kernels.c:502-526) on columns < rope_cols: the partner of column c is
+        // c ^ 1 = the neighbouring lane (C layout: column = lane & 31), fetched with one DPP quad permute
+        const int half = a.head_dim >> 1;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) {
+                const int col = bn0 + wn * (32 * TN) + tn * 32 + li;
+                const float b = (a.bias && col < N) ? a.bias[col] : 0.f;
+                const bool rot = col < a.rope_cols;
+                const int pd = (col % a.head_dim) >> 1;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = bm0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                    float v = acc[tm][tn][r] + b;
+                    const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+                    if (rot && row < M) {
+                        const float2 cs = *reinterpret_cast<const float2 *>(a.rope_tab + ((size_t)row * half + pd) * 2);
+                        v = (col & 1) ? other * cs.y + v * cs.x : v * cs.x - other * cs.y;
+                    }
+                    if (row < M && col < N) a.Y[(size_t)row * a.ldy + col] = v;
+                }
+            }
+    } else {
+        gemm_epilogue<TN>(a, acc, bm0, bn0, wm, wn, li, lg);
+    }
 }
 
 // ---- producers of the planes --------------------------------------------------------------------------------------

@@ -364,9 +364,20 @@ static int launch_gemm(vox_hip_engine *e, const float *X, int ldx, const uint16_
 
 // y = sum_p Xp[p] . W^T on pre-split activations (vox_gemm_planes.h); same epilogue / split-K contract as launch_gemm.
 static int launch_gemm_planes(vox_hip_engine *e, const uint16_t *Xp, size_t plane, int ldxp, const uint16_t *W, float *Y, int ldy,
-                              int M, int N, int K, const float *bias, const float *resid, int ldr, int act) {
+                              int M, int N, int K, const float *bias, const float *resid, int ldr, int act,
+                              int epi = GP_EPI_STD, const GemmArgs *extra = nullptr) {
     GemmArgs a{nullptr, 0, W, Y, ldy, M, N, K, bias, resid, ldr, act, 1, 0, nullptr};
     a.Xp = Xp; a.xp_plane = plane; a.ldxp = ldxp;
+    if (epi == GP_EPI_SWIGLU) {       // N = hidden columns, W = [w1; w3]; output = bf16 planes of the gated hidden rows
+        a.Yp = extra->Yp; a.yp_plane = extra->yp_plane;
+        hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_SWIGLU>), dim3((N + 63) / 64, (M + GB_M - 1) / GB_M), dim3(256), (size_t)2 * gp_stage_bytes(2), e->stream, a);
+        return 0;
+    }
+    if (epi == GP_EPI_ROPE) {
+        a.rope_tab = extra->rope_tab; a.rope_cols = extra->rope_cols; a.head_dim = extra->head_dim;
+        hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_ROPE>), dim3((N + 127) / 128, (M + GB_M - 1) / GB_M), dim3(256), (size_t)2 * gp_stage_bytes(2), e->stream, a);
+        return 0;
+    }
     if (M <= 0 || N <= 0) return 0;
     const int TN = e->gp_tn, st = 2;
     const int BN = 64 * TN;
@@ -778,19 +789,27 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
     const bool planes = e->use_planes && e->use_mfma && e->use_bf16x3 && n >= 64 && c.D % GP_K == 0 && c.QD % GP_K == 0 && c.H % GP_K == 0;
     uint16_t *P = nullptr;
     if (planes) {
-        if (ensure(e, e->splanes, (size_t)3 * n * std::max(std::max(c.D, c.QD), c.H) * 2)) return -1;
+        const size_t pmax = (size_t)3 * n * std::max(std::max(c.D, c.QD), c.H);
+        if (ensure(e, e->splanes, 2 * pmax * 2)) return -1;          // two plane sets: the W1;W3 launch reads one and writes the other
         P = (uint16_t *)e->splanes.p;
     }
+    static const int gp_fuse = getenv("VOX_HIP_GP_NO_EPI") ? 0 : 1;   // A/B: separate RoPE / SiLU launches
+    // (only for chunks that fill the chip with tiles: the epilogue variants have no split-K, and a 68-row pass ran its QKV launch
+    // as 96 workgroups x 40 sequential K slices: 56 us against ~26 for split-K + reduce + RoPE)
+    const bool fuse_epi = planes && gp_fuse && n >= 512 && (c.QD + c.KVD) % 2 == 0 && c.H % 64 == 0;
     // 1. attention_norm   2. merged QKV projection (+ q/v bias on the encoder, voxtral_encoder.c:542-544)
     if (planes) {
         hipLaunchKernelGGL(k_rmsnorm_planes, dim3(n), dim3(256), 0, s, P, (size_t)n * c.D, (const float *)x, c.D, n1, (const float *)nullptr, c.D, c.eps);
-        if (launch_gemm_planes(e, P, (size_t)n * c.D, c.D, wqkv, qkv, N3, n, N3, c.D, bqkv, nullptr, 0, ACT_NONE)) return -1;
+        if (fuse_epi) {
+            GemmArgs x{}; x.rope_tab = tab; x.rope_cols = c.QD + c.KVD; x.head_dim = c.hd;
+            if (launch_gemm_planes(e, P, (size_t)n * c.D, c.D, wqkv, qkv, N3, n, N3, c.D, bqkv, nullptr, 0, ACT_NONE, GP_EPI_ROPE, &x)) return -1;
+        } else if (launch_gemm_planes(e, P, (size_t)n * c.D, c.D, wqkv, qkv, N3, n, N3, c.D, bqkv, nullptr, 0, ACT_NONE)) return -1;
     } else {
         hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, s, xn, c.D, x, c.D, n1, (const float *)nullptr, c.D, c.eps);
         if (launch_gemm(e, xn, c.D, wqkv, qkv, N3, n, N3, c.D, bqkv, nullptr, 0, ACT_NONE)) return -1;
     }
-    // 3. RoPE on q and k columns (table built once per chunk by the caller)
-    hipLaunchKernelGGL(k_rope_apply, dim3(grid1d((size_t)n * (c.QD + c.KVD) / 2)), dim3(256), 0, s,
+    // 3. RoPE on q and k columns (table built once per chunk by the caller) - unless the QKV launch did it in its epilogue
+    if (!fuse_epi) hipLaunchKernelGGL(k_rope_apply, dim3(grid1d((size_t)n * (c.QD + c.KVD) / 2)), dim3(256), 0, s,
                        qkv, N3, n, c.QD + c.KVD, c.hd, tab);
     // 4. attention over [window tail in the ring] + [this chunk]
     const float scale = 1.0f / sqrtf((float)c.hd);
@@ -851,6 +870,13 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
         hipLaunchKernelGGL(k_split_planes, dim3(grid1d((size_t)n * c.QD / 4)), dim3(256), 0, s, P, (size_t)n * c.QD, (const float *)attn, c.QD, n, c.QD);
         if (launch_gemm_planes(e, P, (size_t)n * c.QD, c.QD, wo, x, c.D, n, c.D, c.QD, bo, x, c.D, ACT_NONE)) return -1;
         hipLaunchKernelGGL(k_rmsnorm_planes, dim3(n), dim3(256), 0, s, P, (size_t)n * c.D, (const float *)x, c.D, n2, ada, c.D, c.eps);
+        if (fuse_epi) {
+            uint16_t *P2 = P + (size_t)3 * n * std::max(std::max(c.D, c.QD), c.H);
+            GemmArgs xa{}; xa.Yp = P2; xa.yp_plane = (size_t)n * c.H;
+            if (launch_gemm_planes(e, P, (size_t)n * c.D, c.D, w13, nullptr, 0, n, c.H, c.D, nullptr, nullptr, 0, ACT_NONE, GP_EPI_SWIGLU, &xa)) return -1;
+            if (launch_gemm_planes(e, P2, (size_t)n * c.H, c.H, w2, x, c.D, n, c.D, c.H, b2, x, c.D, ACT_NONE)) return -1;
+            return 0;
+        }
         if (launch_gemm_planes(e, P, (size_t)n * c.D, c.D, w13, gu, 2 * c.H, n, 2 * c.H, c.D, nullptr, nullptr, 0, ACT_NONE)) return -1;
         hipLaunchKernelGGL(k_silu_mul_planes, dim3(grid1d((size_t)n * c.H / 4)), dim3(256), 0, s, P, (size_t)n * c.H, (const float *)gu, n, c.H);
         if (launch_gemm_planes(e, P, (size_t)n * c.H, c.H, w2, x, c.D, n, c.D, c.H, b2, x, c.D, ACT_NONE)) return -1;
@@ -2167,7 +2193,9 @@ static int self_test(vox_hip_engine *e) {
     {   // (2b) the planes GEMM (pre-split activations, LDS-DMA pipeline) on the same problem, with and without split-K
         if (getenv("VOX_HIP_GP_TN")) e->gp_tn = atoi(getenv("VOX_HIP_GP_TN")) == 4 ? 4 : 2;
         bool okp = hipFuncSetAttribute((const void *)k_gemm_planes<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(2)) == hipSuccess &&
-                   hipFuncSetAttribute((const void *)k_gemm_planes<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(4)) == hipSuccess;
+                   hipFuncSetAttribute((const void *)k_gemm_planes<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(4)) == hipSuccess &&
+                   hipFuncSetAttribute((const void *)k_gemm_planes<2, 2, GP_EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(2)) == hipSuccess &&
+                   hipFuncSetAttribute((const void *)k_gemm_planes<2, 2, GP_EPI_ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(2)) == hipSuccess;
         uint16_t *dp = nullptr;
         okp = okp && hipMalloc((void **)&dp, (size_t)3 * M * K * 2) == hipSuccess;
         if (okp) {

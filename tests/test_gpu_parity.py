@@ -355,7 +355,7 @@ def deep(vox):
     m.close()
 
 
-@pytest.mark.parametrize("name", ["deep_batch", "deep_long"])
+@pytest.mark.parametrize("name", ["deep_batch", "deep_long", "deep_wrap"])
 def test_stream_deep_matches_reference_golden(deep, name):
     """The full depth (32 + 26 layers) and the real windows at the tiny widths: 30 s of the headline
     input, and 300 s (3761 steps, KV to 3799) - depth x context in one case."""

@@ -70,7 +70,7 @@ struct DecFuseArgs {
     int spread_groups;               // test switch: group = blockIdx / 32 (members spread over all XCDs) instead of blockIdx % 8
     unsigned long long *tl;          // optional (tuning): per-workgroup timeline, see tl_begin / tl_end
 };
-// stamps stay in registers until the end: a store in the middle would shift the hand-counted s_waitcnt vmcnt values
+// stamps stay in registers until the end (no stores in the middle of the memory schedule)
 #define DF_MARK(k) do { if (a.trace || a.tl) df_stamp[k] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ void df_store_granule(u64 *g, unsigned epoch, float v) {
@@ -96,11 +96,6 @@ __device__ __forceinline__ float df_wait_granule(const u64 *g, unsigned epoch, c
         }
     }
     return __uint_as_float((unsigned)v);
-}
-
-// 16-byte non-temporal weight load the compiler does not count (see the header comment).
-__device__ __forceinline__ void df_ld_weight(u32x4 &dst, const void *p) {
-    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
 }
 
 // Wave-wide sum: four DPP row steps, then the four row sums through readlane (no LDS traffic, unlike ds_bpermute
@@ -138,8 +133,6 @@ constexpr int DF_TILE = 64;                       // keys per K/V tile in LDS
 constexpr int DF_TILE_BYTES = DF_TILE * 512;      // one of K or V: 64 keys x 128 f32
 // LDS: [xs | nw] 24 KB (scratch after the projections) | K/V tiles, double buffered 2 x (32 + 32) KB | inv_freq | red
 constexpr int DF_LDS_BYTES = 2 * DF_D * 4 + 4 * DF_TILE_BYTES + 1024 + 512;
-#define DF_WAIT3(N, A, B, C) asm volatile("s_waitcnt vmcnt(%[cnt])" : "+v"(A), "+v"(B), "+v"(C) : [cnt] "n"(N) : "memory")
-#define DF_TIE4(A, B, C, D) asm volatile("" : "+v"(A), "+v"(B), "+v"(C), "+v"(D))
 
 // One K/V tile (keys t0 .. t0+63 of KV head g, clamped to last) from the ring into LDS by LDS-DMA: 8 instructions per
 // wave (4 for K, 4 for V), each moving two 512-byte head rows.  K is stored with its 16-byte chunks XOR-swizzled by the
@@ -602,7 +595,6 @@ struct W13xArgs {
     float *h;                  // [9216]
     unsigned long long *trace; // optional (tuning): [2 blocks][16] stamps, written at +32
     unsigned long long *tl;    // optional (tuning): per-workgroup timeline
-    int shift;                 // test switch: workgroup b streams the rows of workgroup (b + shift) % 256
 };
 constexpr int W13X_THREADS = 768;
 constexpr int W13X_LDS_BYTES = (9 + 2 + 1) * DF_D * 4 + 256;

@@ -1555,8 +1555,6 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.eps = d.dec_eps; a.x_out = xalt; a.h = e->dh;
                 a.trace = (l == 13) ? e->d_fuse_trace : nullptr;
                 a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + TL_STRIDE * 1024 : nullptr;
-                static const int w13_shift = getenv("VOX_HIP_W13_SHIFT") ? atoi(getenv("VOX_HIP_W13_SHIFT")) : 0;   // test switch
-                a.shift = w13_shift;
                 if (e->use_fp8) {
                     a.w1 = reinterpret_cast<const uint16_t *>(L.w138); a.w3 = reinterpret_cast<const uint16_t *>(L.w138 + (size_t)DH * DD);
                     a.s1 = L.s13; a.s3 = L.s13 + DH;

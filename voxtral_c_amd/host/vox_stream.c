@@ -397,9 +397,8 @@ int vox_stream_feed(vox_stream_t *s, const float *samples, int n_samples) {
     return 0;
 }
 
-int vox_stream_flush(vox_stream_t *s) {
-    if (!s || s->finished) return -1;
-    /* right padding: align to a token, then (delay+1) + 10 tokens of silence (voxtral.c:1593-1606) */
+/* right padding: align to a token, then (delay+1) + 10 tokens of silence (voxtral.c:1593-1606) */
+static void feed_right_padding(vox_stream_t *s) {
     const int align = (int)((SAMPLES_PER_TOKEN - (s->samples_fed % SAMPLES_PER_TOKEN)) % SAMPLES_PER_TOKEN);
     int remaining = align + ((s->ctx->delay_tokens + 1) + RIGHT_PAD_BUFFER_TOKENS) * SAMPLES_PER_TOKEN;
     static const float zeros[4096] = {0};
@@ -408,6 +407,11 @@ int vox_stream_flush(vox_stream_t *s) {
         vox_mel_feed(s->mel, zeros, n);
         remaining -= n;
     }
+}
+
+int vox_stream_flush(vox_stream_t *s) {
+    if (!s || s->finished) return -1;
+    feed_right_padding(s);
     const int saved = s->min_new_mel;
     s->min_new_mel = 1;
     run_encoder(s);
@@ -418,7 +422,12 @@ int vox_stream_flush(vox_stream_t *s) {
 
 int vox_stream_finish(vox_stream_t *s) {
     if (!s || s->finished) return -1;
-    vox_stream_flush(s);
+    /* The reference flushes (padding -> encoder -> decoder) and then finishes the mel (-> encoder on the last frame -> decoder)
+     * (voxtral.c:1608-1625).  Encoder and decoder outputs do not depend on how the frames are cut into chunks, so outside
+     * continuous mode - whose watchdogs look at the state after every decoder run - the padding and the mel tail go through
+     * ONE encoder pass and one decoder run: the separate 1-row encoder pass was 273 launches = 2.4 ms of pure launch latency. */
+    if (s->continuous) vox_stream_flush(s);
+    else feed_right_padding(s);
     s->finished = 1;
     vox_mel_finish(s->mel, 0);
     if (vox_verbose >= 2)

@@ -576,6 +576,24 @@ def test_production_kernels_are_the_ones_running(vox, small):
     assert not (mk & vox.PATHS["gemv3"])          # tiny geometry: the generic GEMV, reported as such
 
 
+@pytest.mark.parametrize("switch", ["VOX_HIP_NO_STAGED_UPLOAD", "VOX_HIP_NO_PLANES", "VOX_HIP_GP_NO_EPI", "VOX_HIP_NO_ATTN_SMALL"])
+def test_ab_switches_give_the_same_ids(vox, small, switch):
+    """Each A/B switch selects the older HIP path of one component (plain hipMemcpy ingest, f32-activation GEMM, separate RoPE /
+    SiLU launches, MFMA attention for small chunks); ids must not depend on it, logits only up to summation order."""
+    audio = synth_speech(22.0, 99)
+    feeds = [8000] * (len(audio) // 8000 + 1)          # 0.5 s feeds after a large first chunk: both encoder paths run
+    feeds[0] = 16000 * 12
+    a = small.transcribe(audio, feed_sizes=feeds, interval=0.5, record_logits=32)
+    os.environ[switch] = "1"
+    try:
+        with vox.Model(model_dir("small")) as m2:
+            b = m2.transcribe(audio, feed_sizes=feeds, interval=0.5, record_logits=32)
+    finally:
+        del os.environ[switch]
+    assert np.array_equal(a["tokens"], b["tokens"]), switch
+    assert float(np.abs(a["logits"] - b["logits"]).max()) < 2e-4
+
+
 def test_batch_and_streaming_feeds_agree(tiny):
     """Reference property: one feed == 1 s feeds == 4096-sample feeds at -I 0.1."""
     audio = synth_speech(9.0, 21)

@@ -235,6 +235,7 @@ struct vox_hip_engine {
     unsigned fuse_epoch = 0;
     unsigned long long *d_fuse_trace = nullptr;
     bool use_planes = true;       // large-M GEMMs on pre-split bf16 planes (k_gemm_planes)
+    bool use_epi = true, use_attn_small = true, use_staged_upload = true;     // A/B switches, read once per engine (self_test)
     int gp_tn = 2;                // MFMA tiles per wave along N in k_gemm_planes (2: 128 x 128 workgroup tile, 4: 128 x 256)
     Buf splanes;                  // [3][n][max(D, QD, H)] bf16
     Uploader *up = nullptr;       // staged weight ingest (lives until the first compute call or the engine's end)
@@ -678,8 +679,7 @@ extern "C" int vox_hip_upload_bf16(vox_hip_engine_t *e, int tensor, int layer, c
         g_err = b; fprintf(stderr, "%s\n", b);
         return -1;
     }
-    static const int no_stage = getenv("VOX_HIP_NO_STAGED_UPLOAD") ? 1 : 0;
-    if (!no_stage && n * 2 >= ((size_t)4 << 20)) {
+    if (e->use_staged_upload && n * 2 >= ((size_t)4 << 20)) {
         if (!e->up) e->up = new Uploader();
         if (e->up->start() && e->up->copy(dst, src, n * 2) == 0 && e->up->fence(e->stream) == 0) return 0;
         (void)hipGetLastError();
@@ -793,10 +793,9 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
         if (ensure(e, e->splanes, 2 * pmax * 2)) return -1;          // two plane sets: the W1;W3 launch reads one and writes the other
         P = (uint16_t *)e->splanes.p;
     }
-    static const int gp_fuse = getenv("VOX_HIP_GP_NO_EPI") ? 0 : 1;   // A/B: separate RoPE / SiLU launches
     // (only for chunks that fill the chip with tiles: the epilogue variants have no split-K, and a 68-row pass ran its QKV launch
     // as 96 workgroups x 40 sequential K slices: 56 us against ~26 for split-K + reduce + RoPE)
-    const bool fuse_epi = planes && gp_fuse && n >= 512 && (c.QD + c.KVD) % 2 == 0 && c.H % 64 == 0;
+    const bool fuse_epi = planes && e->use_epi && n >= 512 && (c.QD + c.KVD) % 2 == 0 && c.H % 64 == 0;
     // 1. attention_norm   2. merged QKV projection (+ q/v bias on the encoder, voxtral_encoder.c:542-544)
     if (planes) {
         hipLaunchKernelGGL(k_rmsnorm_planes, dim3(n), dim3(256), 0, s, P, (size_t)n * c.D, (const float *)x, c.D, n1, (const float *)nullptr, c.D, c.eps);
@@ -914,8 +913,7 @@ static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float 
     a.kB = qkv + c.QD; a.vB = qkv + c.QD + c.KVD; a.ldB = N3; a.posB0 = pos0; a.last_key = pos0 + n - 1;
     a.kA = kring; a.vA = vring; a.capA = ring_cap; a.ldA = c.KVD;
     a.n_heads = c.heads; a.n_kv_heads = c.kv_heads; a.scale = 1.0f / sqrtf((float)c.hd); a.window = c.window; a.st = nullptr;
-    static const int no_small = getenv("VOX_HIP_NO_ATTN_SMALL") ? 1 : 0;
-    if (n <= 32 && c.hd == 64 && c.heads == c.kv_heads && !no_small) {
+    if (n <= 32 && c.hd == 64 && c.heads == c.kv_heads && e->use_attn_small) {
         // streaming-size chunk: (head, 64-key slice) workgroups on plain FMAs + the usual combine
         const int lo = std::max(0, pos0 - c.window + 1), ks = (pos0 + n - 1 - lo) / 64 + 1;
         if (ensure(e, e->spart_o, (size_t)n * c.heads * ks * c.hd * 4)) return -1;
@@ -2214,6 +2212,9 @@ static int self_test(vox_hip_engine *e) {
         if (dp) hipFree(dp);
         if (!okp) { (void)hipGetLastError(); e->use_planes = false; failed++; }
         if (getenv("VOX_HIP_NO_PLANES")) e->use_planes = false;
+        if (getenv("VOX_HIP_GP_NO_EPI")) e->use_epi = false;                 // A/B: separate RoPE / SiLU launches
+        if (getenv("VOX_HIP_NO_ATTN_SMALL")) e->use_attn_small = false;
+        if (getenv("VOX_HIP_NO_STAGED_UPLOAD")) e->use_staged_upload = false;
     }
 
     // (3) MFMA encoder attention vs the thread-per-query kernel: 200 queries, 2 heads, window 90

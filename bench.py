@@ -12,7 +12,9 @@ the golden fixture tests/golden/stream_full_batch.npz - and after the timed regi
 token ids are compared with that fixture, i.e. with the reference CPU path's own run on the
 same checkpoint and audio ("parity" in the JSON line).  Other lengths tile that clip.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W        (N>1: one rank per GPU over RCCL - launched by
+                                                         torch.distributed.run, or by this script itself when it is
+                                                         called without WORLD_SIZE in the environment)
 
 Prints ONE JSON line (rank 0): value = RTF (wall seconds per audio second, lower is better),
 plus decode_tok_s, the roofline of the dominant kernel (decode GEMV, HBM-bound) measured live
@@ -166,10 +168,10 @@ def cpu_baseline(model_dir_full, preset_dims):
 
 
 def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True):
-    fused = "dec_fused" in model.active_paths()[1]
-    DOM_KERNEL_SUBSTR = DOM_KERNEL_FUSED if fused else DOM_KERNEL_CHAIN
     """roofline object of the JSON line: dominant decode kernel (w1;w3 GEMV) measured live with HIP
     events on the engine stream, plus the per-kernel table and the whole-step figure."""
+    fused = "dec_fused" in model.active_paths()[1]
+    DOM_KERNEL_SUBSTR = DOM_KERNEL_FUSED if fused else DOM_KERNEL_CHAIN
     # ---- roofline of the dominant kernel, measured live with HIP events --------------------
     import ctypes as C
     v.hip.vox_hip_profile_decode.restype = C.c_double
@@ -332,9 +334,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Called directly (`python bench.py --gpus N`): become the launcher.  One rank per GPU under torch.distributed.run
+        # on 127.0.0.1, same arguments; this process is replaced, the ranks' output (rank 0 prints the JSON line) is ours.
+        import socket
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execv(sys.executable, cmd)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1 and os.environ.get("VOX_FORCE_DIST") != "1":
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus}, or call "
+                         "`python bench.py --gpus N` directly and let it launch the ranks itself)")
 
     if world > 1 or os.environ.get("VOX_FORCE_DIST") == "1":
         # torch ships its own HIP runtime: bring it up before the engine's (loaded RTLD_LOCAL) so that the process

@@ -90,6 +90,9 @@ int vox_hip_upload_f32(vox_hip_engine_t *e, int tensor, int layer,
  * compute stream is ordered behind them.  vox_hip_upload_done waits for the last copy and releases the staging threads and buffers
  * (reference side: the mmap loader voxtral_safetensors.c:204-429 + the per-tensor warm-up voxtral.c:163-251). */
 int vox_hip_upload_done(vox_hip_engine_t *e);
+/* (mandatory after the last upload for direct users of this header: the staging threads and 32 MB of pinned memory live
+ * until this call or vox_hip_engine_destroy.  If staging cannot be set up the engine says so once on stderr and uses
+ * plain copies for the rest of its life.) */
 /* Mel tables built by the host exactly as voxtral_audio.c:248-285,531-542 does:
  * filters [mel_bins,201], hann[400], dft_cos/sin [201,400]. */
 int vox_hip_upload_mel_tables(vox_hip_engine_t *e, const float *filters, const float *hann,
@@ -167,6 +170,16 @@ int vox_hip_shard_layer(vox_hip_engine_t *e, int layer);
 int vox_hip_shard_kv_export(vox_hip_engine_t *e, int layer, int pos_first, int n, void *dst_dev);       /* [2][n][kv] */
 int vox_hip_shard_kv_import(vox_hip_engine_t *e, int layer, int pos_first, int n, const void *src_dev);
 int vox_hip_shard_end(vox_hip_engine_t *e, void *adapter_rows_dev);                  /* returns adapter rows written */
+/* Stream-ordered variants: nothing below waits on the host.  A transport that is ordered behind the engine stream (RCCL
+ * issued on vox_hip_stream_handle through torch.cuda.ExternalStream, or an event) needs no host round trip per layer;
+ * vox_hip_host_syncs counts the host-side waits on the engine stream so that tests can assert there were none between
+ * vox_hip_shard_begin and vox_hip_shard_end_async.  The plain names above = the async call + one synchronisation. */
+int vox_hip_shard_kv_export_async(vox_hip_engine_t *e, int layer, int pos_first, int n, void *dst_dev);
+int vox_hip_shard_end_async(vox_hip_engine_t *e, void *adapter_rows_dev);
+int vox_hip_adapter_append_dev_async(vox_hip_engine_t *e, const void *rows_dev, int n_rows);
+void vox_hip_reset_encoder_async(vox_hip_engine_t *e);
+void *vox_hip_stream_handle(vox_hip_engine_t *e);                   /* the engine's hipStream_t */
+unsigned long long vox_hip_host_syncs(const vox_hip_engine_t *e);
 int vox_hip_adapter_append_dev(vox_hip_engine_t *e, const void *rows_dev, int n_rows);
 void *vox_hip_device_alloc(vox_hip_engine_t *e, size_t bytes);
 void vox_hip_device_free(vox_hip_engine_t *e, void *p);
@@ -251,6 +264,15 @@ enum vox_hip_path {
                            VOX_PATH_GEMM_PLANES)
 unsigned vox_hip_active_paths(const vox_hip_engine_t *e);
 
+/* The fused decode kernel (VOX_PATH_DEC_FUSED) needs its 256 workgroups co-resident; a hand-off that times out (another
+ * process or stream held CUs) makes the engine repeat the batch on the launch-per-GEMV chain and SUSPEND the fused kernel
+ * for 256 clean decode steps (doubling with every further time-out, capped at 16384), after which it is re-armed.
+ * failures = time-outs so far, armed = 1 if the fused kernel is live now, rearm_in = steps left of a suspension.
+ * Returns 0 if the engine has the fused kernel at all, 1 if not, -1 on error. */
+int vox_hip_fuse_stats(const vox_hip_engine_t *e, int *failures, int *armed, long *rearm_in);
+/* Test hook: the next check after a synchronisation behaves as if a hand-off had timed out. */
+int vox_hip_debug_inject_fuse_timeout(vox_hip_engine_t *e);
+
 /* Experiment: seconds per pass over ONE decoder layer's five kernels run back to back (weights
  * stay in the 256 MB Infinity Cache), for comparison with the streamed per-layer time. */
 double vox_hip_time_layer_repeat(vox_hip_engine_t *e, int iters, int kv_len, double *avg_us, int *launches);
@@ -262,6 +284,7 @@ typedef struct vox_hip_timing {
 } vox_hip_timing_t;
 void vox_hip_get_timing(const vox_hip_engine_t *e, vox_hip_timing_t *t);
 void vox_hip_reset_timing(vox_hip_engine_t *e);
+void vox_hip_add_encode_ms(vox_hip_engine_t *e, double ms);   /* encoder time measured by the host (multi-engine chunk) */
 
 #ifdef __cplusplus
 }

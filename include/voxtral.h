@@ -10,9 +10,9 @@
  * (include/vox_hip.h is the device boundary).  There is no CPU compute path:
  * vox_load() fails if no gfx950 device is available.
  *
- * vox_ctx_t is an engine-owned struct.  Clients only hold pointers to it (main.c
- * never dereferences it); the handful of counters the reference exposes in its
- * own struct (voxtral.h:163-190) are mirrored with the same names.
+ * vox_ctx_t starts with the reference's own fields (same names, types, order: voxtral.h:154-204) and the
+ * weight-view types it is built from (vox_enc_layer_t ... vox_adapter_t, voxtral.h:56-148) are declared and
+ * filled, so code that names those types or reads those fields compiles and runs; the engine's own state is appended.
  */
 #ifndef VOXTRAL_H
 #define VOXTRAL_H
@@ -56,6 +56,66 @@ extern "C" {
 #define VOX_ROPE_THETA       1000000.0f
 #define VOX_MAX_ALT          4
 
+/* ---- weight views (reference voxtral.h:56-148: vox_enc_layer_t, vox_encoder_t, vox_dec_layer_t, vox_decoder_t,
+ * vox_adapter_t) -----------------------------------------------------------------------------------------------------
+ * Same type names, field names, field types and field order as the reference, so that code written against its
+ * header - naming the types, walking ctx->decoder.layers[i], reading a bias - compiles and finds what it expects.
+ * Here they are HOST VIEWS of the checkpoint, filled by vox_load: the *_bf16 pointers point into the mmap'd
+ * consolidated.safetensors exactly as the reference's load_bf16_direct leaves them (voxtral_encoder.c:42-48,
+ * voxtral_decoder.c:41-47), the f32 pointers are the load_f32 conversions (conv weights, biases, norms, ada MLP);
+ * the f32 variants of the big matrices are NULL ("NULL if bf16").  The engine computes from its own copy in HBM:
+ * writing through these pointers does not change what the GPU runs.  The arrays are sized by the 4B constants above;
+ * a reduced test checkpoint fills the first dims.enc_layers / dims.dec_layers entries. */
+typedef struct {
+    float *wq_weight;        uint16_t *wq_weight_bf16;   /* [heads*64, enc_dim] */
+    float *wq_bias;
+    float *wk_weight;        uint16_t *wk_weight_bf16;   /* no bias */
+    float *wv_weight;        uint16_t *wv_weight_bf16;
+    float *wv_bias;
+    float *wo_weight;        uint16_t *wo_weight_bf16;   /* [enc_dim, heads*64] */
+    float *wo_bias;
+    float *attention_norm;
+    float *w1_weight;        uint16_t *w1_weight_bf16;   /* [enc_hidden, enc_dim] gate */
+    float *w2_weight;        uint16_t *w2_weight_bf16;   /* [enc_dim, enc_hidden] down */
+    float *w2_bias;
+    float *w3_weight;        uint16_t *w3_weight_bf16;   /* [enc_hidden, enc_dim] up */
+    float *ffn_norm;
+} vox_enc_layer_t;
+
+typedef struct {
+    float *conv0_weight;     /* [enc_dim, mel_bins, 3] */
+    float *conv0_bias;
+    float *conv1_weight;     /* [enc_dim, enc_dim, 3] */
+    float *conv1_bias;
+    vox_enc_layer_t layers[VOX_ENC_LAYERS];
+    float *norm;
+} vox_encoder_t;
+
+typedef struct {
+    float *ada_norm_down;    /* [ada_dim, dec_dim] */
+    float *ada_norm_up;      /* [dec_dim, ada_dim] */
+    float *wq_weight;        uint16_t *wq_weight_bf16;
+    float *wk_weight;        uint16_t *wk_weight_bf16;
+    float *wv_weight;        uint16_t *wv_weight_bf16;
+    float *wo_weight;        uint16_t *wo_weight_bf16;
+    float *attention_norm;
+    float *w1_weight;        uint16_t *w1_weight_bf16;
+    float *w2_weight;        uint16_t *w2_weight_bf16;
+    float *w3_weight;        uint16_t *w3_weight_bf16;
+    float *ffn_norm;
+} vox_dec_layer_t;
+
+typedef struct {
+    float *tok_embeddings;   uint16_t *tok_embeddings_bf16;   /* [vocab, dec_dim], tied LM head */
+    vox_dec_layer_t layers[VOX_DEC_LAYERS];
+    float *norm;
+} vox_decoder_t;
+
+typedef struct {
+    float *linear0_weight;   uint16_t *linear0_weight_bf16;   /* [dec_dim, 4*enc_dim] */
+    float *linear1_weight;   uint16_t *linear1_weight_bf16;   /* [dec_dim, dec_dim] */
+} vox_adapter_t;
+
 /* Geometry discovered from consolidated.safetensors at load time. */
 #define VOX_MAX_DEVICES 8
 
@@ -66,30 +126,55 @@ typedef struct vox_model_dims {
     int vocab, ada_dim;
 } vox_model_dims_t;
 
+/* vox_ctx_t (reference voxtral.h:154-204).  The reference's fields come first, same names, types and order, so the
+ * struct is layout-compatible with code compiled against the reference header; what the MI355X engine adds is
+ * APPENDED.  Fields of the reference that describe host buffers this engine does not have - both KV caches and the
+ * per-call scratch live in HBM - are present and NULL / 0; the cache COUNTERS are live mirrors of the reference's
+ * physical-length arithmetic (its restart watchdogs key on them, voxtral.c:1147). */
 typedef struct vox_ctx {
-    char model_dir[512];
-    vox_model_dims_t dims;
-    int device;                 /* HIP device ordinal */
+    vox_encoder_t encoder;      /* host views, see above */
+    vox_adapter_t adapter;
+    vox_decoder_t decoder;
+
     void *safetensors;          /* mmap'd checkpoint (kept open for the ctx lifetime) */
-    void *engine;               /* vox_hip_engine_t*  (include/vox_hip.h) */
+    char model_dir[512];
+
+    float *kv_cache_k, *kv_cache_v;             /* NULL: the decoder KV window is a ring in HBM */
+    uint16_t *kv_cache_k_f16, *kv_cache_v_f16;  /* NULL */
+    int kv_cache_fp16;                          /* 0 */
+    int kv_cache_len, kv_cache_max, kv_pos_offset;   /* mirrors (voxtral_decoder.c:171-347,615-623) */
 
     int delay_tokens;           /* transcription delay in 80 ms tokens, default 6 */
-    float *t_cond;              /* [dec_dim] time embedding of delay_tokens */
+    float t_cond[VOX_DEC_DIM];  /* time embedding of delay_tokens (first dims.dec_dim entries) */
     float *ada_scale;           /* [dec_layers * dec_dim], also resident on the device */
-    float **ada_down, **ada_up; /* per-layer f32 copies of the ada MLP weights */
-
-    /* Mirrors of the reference's cache counters (same names, voxtral.h:169-171,186-189).
-     * The device keeps both KV windows as position-indexed rings; these reproduce the
-     * reference's physical-length arithmetic, which its restart watchdogs key on. */
-    int kv_cache_len, kv_cache_max, kv_pos_offset;
-    int enc_kv_cache_len, enc_kv_pos_offset;
     int use_bf16;               /* always 1: weights stay bf16 in HBM */
+
+    float *enc_kv_cache_k, *enc_kv_cache_v;     /* NULL: the encoder KV window is a ring in HBM */
+    int enc_kv_cache_len, enc_kv_cache_max, enc_kv_cache_is_shared, enc_kv_pos_offset;   /* len / offset: mirrors */
+
+    int enc_inc_cap;            /* 0; the scratch pointers below are NULL (device scratch) */
+    float *enc_inc_x_norm, *enc_inc_q, *enc_inc_k, *enc_inc_v;
+    float *enc_inc_attn_out, *enc_inc_proj_out;
+    float *enc_inc_gate, *enc_inc_up, *enc_inc_ffn_out;
+    int *enc_inc_positions;
+    float *enc_inc_rope_freqs;
+    float *dec_x, *dec_x_norm, *dec_q, *dec_k, *dec_v;
+    float *dec_attn_out, *dec_proj_out;
+    float *dec_gate, *dec_up, *dec_ffn_out;
+    float *dec_rope_freqs;
+
+    /* ---- appended by this engine ------------------------------------------------------------------------------ */
+    vox_model_dims_t dims;
+    int device;                 /* HIP device ordinal */
+    void *engine;               /* vox_hip_engine_t*  (include/vox_hip.h) */
+    float **ada_down, **ada_up; /* per-layer f32 copies of the ada MLP weights (= decoder.layers[i].ada_norm_*) */
     void *tokenizer;            /* vox_tokenizer_t shared by the streams of this model (parsed once) */
     /* Extra GPUs of a multi-device model (vox_load_opts_t.devices / VOX_DEVICES=0,1,...): encoder-only engines that take
      * contiguous position ranges of a large first chunk (exact context parallelism, host/vox_multi.c).  engine above is
      * shard_engines[0]'s peer on devices[0] and runs everything else (streaming chunks, prefill, decode). */
     void *shard_engines[VOX_MAX_DEVICES];
     int n_shard_engines;        /* engines taking part in a sharded chunk, including `engine` (1 = single GPU) */
+    float **owned_f32; int n_owned_f32, cap_owned_f32;   /* the f32 views this ctx allocated (freed by vox_free) */
 } vox_ctx_t;
 
 /* Optional load parameters (vox_load uses the defaults; the environment variables

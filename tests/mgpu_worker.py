@@ -23,9 +23,12 @@ def main():
     dev = 0 if os.environ.get("VOX_SHARE_GPU") == "1" else local_rank
     torch.cuda.set_device(dev)
     dist.init_process_group(backend=os.environ.get("VOX_DIST_BACKEND", "nccl"))
-    comm = TorchComm(device=f"cuda:{dev}")
     win = {} if preset != "tiny" else dict(enc_window=48, dec_window=64)
     model = v.Model(model_dir(preset), device=dev, **win)
+    import ctypes as C
+    v.hip.vox_hip_stream_handle.restype = C.c_void_p
+    v.hip.vox_hip_stream_handle.argtypes = [C.c_void_p]
+    comm = TorchComm(device=f"cuda:{dev}", engine_stream=v.hip.vox_hip_stream_handle(model.engine))
     sess = DistributedSession(model, comm)
     if len(sys.argv) > 5 and sys.argv[5] == "many":     # one clip per rank, every encoder sharded over all ranks
         toks = sess.transcribe_many([synth_speech(seconds, seed + r) for r in range(comm.world)])

@@ -91,18 +91,44 @@ def test_in_library_multi_device_encoder_matches_single_gpu(preset, seconds, dev
     assert np.array_equal(got2, want2) and np.array_equal(want2, want)
 
 
-def test_rccl_backend_single_rank_bench_path(tmp_path):
-    """The RCCL ("nccl") code path of bench.py --gpus N (GPU-resident staging tensors handed to
-    the engine by data_ptr, device-side adapter append, all_reduce of the timing) with the only
-    world size a 1-GPU box allows."""
+def _bench_json(cmd, env, timeout=1500):
     import json
-    env = dict(os.environ, VOX_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--preset", "small", "--seconds", "20"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    out = json.loads(line)
+    return json.loads(line)
+
+
+def test_rccl_backend_single_rank_bench_path(tmp_path):
+    """The RCCL ("nccl") code path of bench.py --gpus N with the only world size a 1-GPU box allows: GPU-resident staging
+    tensors handed to the engine by data_ptr, the engine's stream as torch's current stream (ExternalStream), a grouped RCCL
+    send + recv to self per layer (VOX_DIST_SELF_LOOP: export -> RCCL -> import, all stream-ordered), device-side adapter
+    append, all_reduce of the timing - and NO host wait on the engine stream between shard_begin and shard_end."""
+    env = dict(os.environ, VOX_FORCE_DIST="1", VOX_DIST_SELF_LOOP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--preset", "small", "--seconds", "20"]
+    out = _bench_json(cmd, env)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["decoder_steps_per_pass"] > 100
-    assert out["config"]["backend"] == "nccl"
+    assert out["config"]["backend"] == "nccl" and out["rccl_ranks"] == 1
+    assert out["host_syncs_in_wavefront"] == 0, out
+    assert out["replica"]["value"] > 0 and set(out["phases_ms"]) >= {"encode", "gather", "prefill", "decode"}
+
+
+def test_bench_self_launches_two_ranks_and_matches_the_reference_golden():
+    """`python bench.py --gpus 2` exactly as the driver calls it (no torch.distributed.run around it): the script launches
+    its own ranks.  Two ranks share this box's one GPU (VOX_SHARE_GPU: gloo, host-staged halo), FULL geometry, the golden
+    30 s night1968 clip on every rank: the 2-way sharded encoder at the 4B width must reproduce the reference's 386 ids on
+    both ranks, and so must the replica pass."""
+    import voxtral_c_amd as v
+    if v.device_count() < 1:
+        pytest.fail("no HIP device")
+    env = dict(os.environ, VOX_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    out = _bench_json(cmd, env)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"] == "gloo"
+    assert out["parity"]["checked"] and out["parity"]["checked_ranks"] == 2 and out["parity"]["mismatches_all_ranks"] == 0, out["parity"]
+    assert out["decoder_steps_per_pass"] == 2 * 386
+    assert out["replica"]["parity_checked_ranks"] == 2 and out["replica"]["parity_mismatches_all_ranks"] == 0
+    assert out["replica"]["value"] > 0 and out["value"] > 0

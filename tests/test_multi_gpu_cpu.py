@@ -76,9 +76,6 @@ class OracleShardEngine:
         u = vo.linear_bf16(xn, w.bf(w.enc(l, "feed_forward.w3.weight")))
         self.x = x + vo.linear_bf16(g * u, w.bf(w.enc(l, "feed_forward.w2.weight")), w.f32(w.enc(l, "feed_forward.w2.bias")))
 
-    def sync(self):
-        pass
-
     def kv_export(self, l, pos_first, n, buf):
         kk, vv = self.own_k[l], self.own_v[l]
         if self.tail_k[l] is not None:
@@ -98,7 +95,8 @@ class OracleShardEngine:
         return ad.shape[0]
 
     def sync(self):
-        pass
+        raise AssertionError("encode_sharded must not wait on the engine: the wavefront is enqueue-only "
+                             "(host-staged transports block inside their own recv / wait / Staging hooks)")
 
 
 def _worker(rank, world, port, mdir, out_path, dst=0):
@@ -122,8 +120,14 @@ def _worker(rank, world, port, mdir, out_path, dst=0):
     def staging(shape):
         return Staging(comm.empty(shape))
 
+    comm.sync = eng.sync          # any host synchronisation requested by the orchestration itself is an error
     rows, counts = encode_sharded(eng, comm, padded, n_frames, staging, dst=dst)
     assert (rows is not None) == (rank == dst)
+    # gloo blocks per message by construction; what is counted here is that the orchestration waited only where a
+    # buffer is about to be reused (one wait per receive, one per send of two layers earlier + the final two)
+    L = eng.n_layers
+    expect = (L if rank > 0 else 0) + (L if rank + 1 < world else 0)
+    assert comm.host_waits == expect, (comm.host_waits, expect)
     if rank == dst:
         np.save(out_path, rows.numpy())
     dist.barrier()

@@ -70,13 +70,21 @@ FULL_CASES = [
     # BASELINE config 3's feed pattern at the full geometry: 0.5 s feeds, -I 0.5, continuous mode (20 s of the night1968 clip)
     ("full_stream", "full", 20.0, 0, 8000, 0.5, True, None, "benchmark/night1968/45s_right_through_the_billboard.wav"),
 ]
+# BASELINE config 3 through a continuous-mode restart at the full geometry (voxtral.c:378,1137-1187: full stream
+# reset once kv_cache_len > 2000, i.e. after ~160 s): the 30 s night1968 clip tiled to 176 s, 0.5 s feeds, -I 0.5.
+# ~30 min of reference CPU time on 8 cores; run with --only full_continuous.  The fixture stores the 30 s base clip
+# once (audio_i16) and the tiled length (audio_total_samples).
+LONG_CASES = [
+    ("full_continuous", "full", 30.0, 0, 8000, 0.5, True, None, "benchmark/night1968/45s_right_through_the_billboard.wav",
+     dict(tile_to=176 * 16000, max_logit_rows=2400, stride=160)),
+]
 
 
 MARGIN_EDGES = np.array([0, 1e-4, 3e-4, 1e-3, 3e-3, 1e-2, 3e-2, 1e-1, 3e-1, 1, 1e9], np.float64)
 STRIDE = 16
 
 
-def summarise(r, vocab):
+def summarise(r, vocab, stride_override=None):
     lg = r["logits"]
     out = dict(tokens=r["tokens"].astype(np.int32), pieces=np.array(r["pieces"], dtype=object))
     out["n_distinct"] = np.int32(len(set(r["tokens"].tolist())))
@@ -89,6 +97,8 @@ def summarise(r, vocab):
         out["top_vals"] = np.take_along_axis(lg, order, axis=1).astype(np.float32)
         out["logits_head"] = lg[:(1 if vocab > 65536 else 4)].astype(np.float32)
         stride = 32 if vocab > 65536 else max(STRIDE, -(-len(lg) // 64))     # keeps the fixture at a few MB
+        if stride_override:
+            stride = stride_override
         steps = np.arange(0, len(lg), stride)
         out["stride_steps"] = steps.astype(np.int32)
         out["logits_stride"] = lg[steps].astype(np.float32)
@@ -133,10 +143,13 @@ def main():
     cases = list(CASES)
     if args.full:
         cases += FULL_CASES
+    if args.only in [c[0] for c in LONG_CASES]:
+        cases += LONG_CASES
     for case in cases:
         name, preset, secs, aseed, feed, interval, cont = case[:7]
         delay_ms = case[7] if len(case) > 7 else None
         wav = case[8] if len(case) > 8 else None
+        extra = case[9] if len(case) > 9 else {}
         if args.only and args.only != name:
             continue
         if preset not in libs:
@@ -144,12 +157,17 @@ def main():
         R = libs[preset]
         d = vo.PRESETS[preset]
         audio, audio_i16 = case_audio(R, wav, secs, aseed)
+        if extra.get("tile_to"):
+            audio = np.tile(audio, -(-extra["tile_to"] // len(audio)))[:extra["tile_to"]].copy()
         ctx = R.load(model_dir(preset))
         r = R.transcribe_stream(ctx, audio, feed_sizes=feeds_for(feed, len(audio)), interval=interval,
-                                continuous=cont, vocab=d.vocab, max_logit_rows=4096 if preset != "full" else 512,
+                                continuous=cont, vocab=d.vocab,
+                                max_logit_rows=extra.get("max_logit_rows", 4096 if preset != "full" else 512),
                                 delay_ms=delay_ms)
         R.free(ctx)
-        out = summarise(r, d.vocab)
+        out = summarise(r, d.vocab, extra.get("stride"))
+        if extra.get("tile_to"):
+            out["audio_total_samples"] = np.int64(extra["tile_to"])
         out["meta"] = np.array([preset, str(secs), str(aseed), str(feed), str(interval), str(int(cont)),
                                 str(delay_ms if delay_ms is not None else 480), str(wav)], dtype=object)
         if audio_i16 is not None:

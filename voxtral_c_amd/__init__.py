@@ -32,13 +32,52 @@ class _Dims(C.Structure):
         "vocab", "ada_dim")]
 
 
+def _ptrs(*names):
+    return [(n, C.c_void_p) for n in names]
+
+
+# the reference's weight-view types (include/voxtral.h, reference voxtral.h:56-148): pointer fields only
+class _EncLayer(C.Structure):
+    _fields_ = _ptrs("wq_weight", "wq_weight_bf16", "wq_bias", "wk_weight", "wk_weight_bf16", "wv_weight", "wv_weight_bf16",
+                     "wv_bias", "wo_weight", "wo_weight_bf16", "wo_bias", "attention_norm", "w1_weight", "w1_weight_bf16",
+                     "w2_weight", "w2_weight_bf16", "w2_bias", "w3_weight", "w3_weight_bf16", "ffn_norm")
+
+
+class _Encoder(C.Structure):
+    _fields_ = _ptrs("conv0_weight", "conv0_bias", "conv1_weight", "conv1_bias") + [("layers", _EncLayer * 32)] + _ptrs("norm")
+
+
+class _DecLayer(C.Structure):
+    _fields_ = _ptrs("ada_norm_down", "ada_norm_up", "wq_weight", "wq_weight_bf16", "wk_weight", "wk_weight_bf16", "wv_weight",
+                     "wv_weight_bf16", "wo_weight", "wo_weight_bf16", "attention_norm", "w1_weight", "w1_weight_bf16",
+                     "w2_weight", "w2_weight_bf16", "w3_weight", "w3_weight_bf16", "ffn_norm")
+
+
+class _Decoder(C.Structure):
+    _fields_ = _ptrs("tok_embeddings", "tok_embeddings_bf16") + [("layers", _DecLayer * 26)] + _ptrs("norm")
+
+
+class _Adapter(C.Structure):
+    _fields_ = _ptrs("linear0_weight", "linear0_weight_bf16", "linear1_weight", "linear1_weight_bf16")
+
+
 class _Ctx(C.Structure):
-    _fields_ = [("model_dir", C.c_char * 512), ("dims", _Dims), ("device", C.c_int),
-                ("safetensors", C.c_void_p), ("engine", C.c_void_p), ("delay_tokens", C.c_int),
-                ("t_cond", f32p), ("ada_scale", f32p), ("ada_down", C.c_void_p), ("ada_up", C.c_void_p),
-                ("kv_cache_len", C.c_int), ("kv_cache_max", C.c_int), ("kv_pos_offset", C.c_int),
-                ("enc_kv_cache_len", C.c_int), ("enc_kv_pos_offset", C.c_int), ("use_bf16", C.c_int),
-                ("tokenizer", C.c_void_p), ("shard_engines", C.c_void_p * 8), ("n_shard_engines", C.c_int)]
+    """vox_ctx_t: the reference's fields first (same order), the engine's appended (include/voxtral.h)."""
+    _fields_ = ([("encoder", _Encoder), ("adapter", _Adapter), ("decoder", _Decoder),
+                 ("safetensors", C.c_void_p), ("model_dir", C.c_char * 512)] +
+                _ptrs("kv_cache_k", "kv_cache_v", "kv_cache_k_f16", "kv_cache_v_f16") +
+                [("kv_cache_fp16", C.c_int), ("kv_cache_len", C.c_int), ("kv_cache_max", C.c_int), ("kv_pos_offset", C.c_int),
+                 ("delay_tokens", C.c_int), ("t_cond", C.c_float * 3072), ("ada_scale", f32p), ("use_bf16", C.c_int)] +
+                _ptrs("enc_kv_cache_k", "enc_kv_cache_v") +
+                [("enc_kv_cache_len", C.c_int), ("enc_kv_cache_max", C.c_int), ("enc_kv_cache_is_shared", C.c_int),
+                 ("enc_kv_pos_offset", C.c_int), ("enc_inc_cap", C.c_int)] +
+                _ptrs("enc_inc_x_norm", "enc_inc_q", "enc_inc_k", "enc_inc_v", "enc_inc_attn_out", "enc_inc_proj_out",
+                      "enc_inc_gate", "enc_inc_up", "enc_inc_ffn_out", "enc_inc_positions", "enc_inc_rope_freqs",
+                      "dec_x", "dec_x_norm", "dec_q", "dec_k", "dec_v", "dec_attn_out", "dec_proj_out", "dec_gate", "dec_up",
+                      "dec_ffn_out", "dec_rope_freqs") +
+                [("dims", _Dims), ("device", C.c_int), ("engine", C.c_void_p), ("ada_down", C.c_void_p), ("ada_up", C.c_void_p),
+                 ("tokenizer", C.c_void_p), ("shard_engines", C.c_void_p * 8), ("n_shard_engines", C.c_int),
+                 ("owned_f32", C.c_void_p), ("n_owned_f32", C.c_int), ("cap_owned_f32", C.c_int)])
 
 
 class _LoadOpts(C.Structure):

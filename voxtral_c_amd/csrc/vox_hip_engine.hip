@@ -229,6 +229,8 @@ struct vox_hip_engine {
     uint8_t *tok_emb8 = nullptr; float *stok = nullptr;
     // fused attention half of the decode step (vox_decfuse.h)
     bool use_fused = false;
+    bool fused_ok = false;        // the fused kernels exist for this geometry / device (use_fused may be suspended after a time-out)
+    long fuse_rearm = 0;          // clean decode steps on the chain before the fused kernel is tried again (0 = not suspended)
     u64 *d_gq = nullptr, *d_gp = nullptr;
     float *d_wo_part = nullptr;
     unsigned *d_fuse_err = nullptr;
@@ -238,7 +240,7 @@ struct vox_hip_engine {
     bool use_epi = true, use_attn_small = true, use_staged_upload = true;     // A/B switches, read once per engine (self_test)
     int gp_tn = 2;                // MFMA tiles per wave along N in k_gemm_planes (2: 128 x 128 workgroup tile, 4: 128 x 256)
     Buf splanes;                  // [3][n][max(D, QD, H)] bf16
-    Uploader *up = nullptr;       // staged weight ingest (lives until the first compute call or the engine's end)
+    Uploader *up = nullptr;       // staged weight ingest: lives until vox_hip_upload_done (vox_load calls it) or the engine's end
     unsigned long long *d_fuse_tl = nullptr;      // VOX_HIP_FUSE_TL: [3 kernels][1024 workgroups][3] timeline of the layer-13 launches
     int fuse_failures = 0;
     int *d_tokens = nullptr;
@@ -255,7 +257,15 @@ struct vox_hip_engine {
     std::vector<hipEvent_t> prof_ev;
     std::vector<int> prof_kind;
     size_t prof_used = 0;
+    unsigned long long n_host_syncs = 0;      // esync() calls (tests: no host wait inside a sharded wavefront)
 };
+
+// Every host-side wait on the engine stream goes through here and is counted (vox_hip_host_syncs): the multi-GPU
+// wavefront must not synchronise between shard_begin and shard_end, and the tests check that with this counter.
+static hipError_t esync(vox_hip_engine *e) {
+    e->n_host_syncs++;
+    return hipStreamSynchronize(e->stream);
+}
 
 enum { PK_BEGIN = 0, PK_QKV, PK_ATTN, PK_COMBINE, PK_WO, PK_SWIGLU, PK_W2, PK_LOGITS, PK_ARGMAX, PK_COUNT };
 
@@ -287,7 +297,7 @@ static int ensure(vox_hip_engine *e, Buf &b, size_t bytes) {
     if (b.bytes >= bytes) return 0;
     size_t nb = std::max(bytes, b.bytes * 3 / 2);
     void *np = nullptr;
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMalloc(&np, nb));
     if (b.p) { HC(hipFree(b.p)); e->mem_used -= b.bytes; }
     b.p = np; b.bytes = nb; e->mem_used += nb;
@@ -298,7 +308,7 @@ static int ensure_keep(vox_hip_engine *e, Buf &b, size_t bytes, size_t keep) {
     if (b.bytes >= bytes) return 0;
     size_t nb = std::max(bytes, b.bytes * 3 / 2);
     void *np = nullptr;
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMalloc(&np, nb));
     HC(hipMemset(np, 0, nb));
     if (b.p) {
@@ -596,7 +606,7 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  hipFuncSetAttribute((const void *)k_gemv_w2x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w2x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess;
             if (!ok) { (void)hipGetLastError(); fprintf(stderr, "vox_hip: fused decode kernels unavailable; launch-per-GEMV chain\n"); }
-            e->use_fused = ok;
+            e->use_fused = ok; e->fused_ok = ok;
             if (ok && getenv("VOX_HIP_FUSE_TRACE") && hipMalloc((void **)&e->d_fuse_trace, 64 * 8) == hipSuccess)
                 hipMemset(e->d_fuse_trace, 0, 64 * 8);
             if (ok && getenv("VOX_HIP_FUSE_TL") && hipMalloc((void **)&e->d_fuse_tl, 3 * 1024 * TL_STRIDE * 8) == hipSuccess)
@@ -608,7 +618,7 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
     if (ensure_keep(e, e->conv_in0, (size_t)(2 + 1024) * d.mel_bins * 4, 0)) return fail();
     if (ensure_keep(e, e->conv_in1, (size_t)(2 + 1024) * ED * 4, 0)) return fail();
     if (ensure_keep(e, e->enc_out, (size_t)(3 + 512) * ED * 4, 0)) return fail();
-    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail();
+    if (esync(e) != hipSuccess) return fail();
     if (self_test(e) != 0) return fail();
     return e;
 }
@@ -617,7 +627,7 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     if (!e) return;
     hipSetDevice(e->device);
     if (e->up) { e->up->stop(); delete e->up; e->up = nullptr; }
-    if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->stream) esync(e);
     auto F = [](void *p) { if (p) hipFree(p); };
     F(e->splanes.p);
     F(e->tok_emb); F(e->conv0_w); F(e->conv1_w); F(e->adapter0); F(e->adapter1);
@@ -682,8 +692,13 @@ extern "C" int vox_hip_upload_bf16(vox_hip_engine_t *e, int tensor, int layer, c
     if (e->use_staged_upload && n * 2 >= ((size_t)4 << 20)) {
         if (!e->up) e->up = new Uploader();
         if (e->up->start() && e->up->copy(dst, src, n * 2) == 0 && e->up->fence(e->stream) == 0) return 0;
+        // staging unavailable (stream / event / pinned allocation refused, or a copy failed): release whatever start() got
+        // hold of - a retry per tensor would leak it again and again - and use plain copies for the rest of this engine's life
         (void)hipGetLastError();
-        HC(hipStreamSynchronize(e->up->st ? e->up->st : e->stream));      // staging unavailable: plain copy below
+        e->up->stop(); delete e->up; e->up = nullptr;
+        e->use_staged_upload = false;
+        fprintf(stderr, "vox_hip: staged weight upload unavailable; plain hipMemcpy from here on\n");
+        HC(esync(e));
     }
     HC(hipMemcpy(dst, src, n * 2, hipMemcpyHostToDevice));
     return 0;
@@ -729,7 +744,7 @@ extern "C" int vox_hip_upload_f32(vox_hip_engine_t *e, int tensor, int layer, co
         g_err = b; fprintf(stderr, "%s\n", b);
         return -1;
     }
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMemcpy(dst, src, n * 4, hipMemcpyHostToDevice));
     return 0;
 }
@@ -948,7 +963,8 @@ static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float 
 static bool skinny_ok(const vox_hip_engine *e, int n, const RowsCfg &c) {
     return e->use_skinny && e->use_mfma && n >= 1 && n <= 32 && c.kv_heads == c.heads && c.hd == 64 &&
            c.D % 64 == 0 && c.QD % 64 == 0 && c.H % 64 == 0 && c.D % 32 == 0 && (c.QD + 2 * c.KVD) % 32 == 0 &&
-           c.D <= 64 * SK_MAXC * SK_WPB;        // the unsplit GEMMs (qkv, w1;w3) have K = D: at most SK_MAXC chunks per wave
+           c.D <= 64 * SK_MAXC * SK_WPB &&      // the unsplit GEMMs (qkv, w1;w3) have K = D: at most SK_MAXC chunks per wave
+           c.QD <= 64 * SK_MAXC * SK_WPB * 16 && c.H <= 64 * SK_MAXC * SK_WPB * 16;   // wo / w2: skinny_split() stops at 16 K splits
 }
 static int skinny_split(int K) { return std::max(1, std::min(16, (K / 64) / SK_WPB)); }      // one chunk per wave when K allows
 
@@ -1066,7 +1082,7 @@ extern "C" int vox_hip_mel_frames(vox_hip_engine_t *e, const float *samples, int
     hipLaunchKernelGGL(k_mel_frames, dim3(n_frames), dim3(256), 0, e->stream, dst, MB, (const float *)e->ssamples.p,
                        e->hann, e->cosT, e->sinT, e->filtT);
     if (out_mel) HC(hipMemcpyAsync(out_mel, dst, (size_t)n_frames * MB * 4, hipMemcpyDeviceToHost, e->stream));
-    HC(hipStreamSynchronize(e->stream));   // the host sample buffer may be reused by the caller
+    HC(esync(e));   // the host sample buffer may be reused by the caller
     if (to_queue) e->mel_q += n_frames;
     return 0;
 }
@@ -1144,7 +1160,7 @@ extern "C" int vox_hip_conv_stem(vox_hip_engine_t *e, const float *mel_new, int 
         if (rows > out_cap_rows) { g_err = "vox_hip_conv_stem: output buffer too small"; return -1; }
         HC(hipMemcpyAsync(out, x, (size_t)rows * ED * 4, hipMemcpyDeviceToHost, e->stream));
     }
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     return rows;
 }
 
@@ -1170,7 +1186,7 @@ extern "C" int vox_hip_conv_stem_pad_odd(vox_hip_engine_t *e, float *out_row) {
     HC(hipMemcpyAsync(in1, in1 + (size_t)2 * ED, (size_t)ED * 4, hipMemcpyDeviceToDevice, s));   // history <- the zero frame
     e->c0_carry = 0;
     if (out_row) HC(hipMemcpyAsync(out_row, x, (size_t)ED * 4, hipMemcpyDeviceToHost, s));
-    HC(hipStreamSynchronize(s));
+    HC(esync(e));
     return 1;
 }
 
@@ -1186,7 +1202,7 @@ extern "C" int vox_hip_encoder_chunk(vox_hip_engine_t *e, const float *x_new, in
     HC(hipMemcpyAsync(e->stmp_in.p, x_new, (size_t)new_len * ED * 4, hipMemcpyHostToDevice, e->stream));
     if (encoder_rows_dev(e, (float *)e->stmp_in.p, new_len, (float *)e->stmp_out.p)) return -1;
     HC(hipMemcpyAsync(out, e->stmp_out.p, (size_t)new_len * ED * 4, hipMemcpyDeviceToHost, e->stream));
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     return 0;
 }
 
@@ -1201,7 +1217,7 @@ extern "C" int vox_hip_adapter(vox_hip_engine_t *e, const float *enc_out, int en
     HC(hipMemcpyAsync(e->stmp_in.p, enc_out, (size_t)m * 4 * ED * 4, hipMemcpyHostToDevice, e->stream));
     if (adapter_dev(e, (const float *)e->stmp_in.p, m, (float *)e->stmp_out.p)) return -1;
     HC(hipMemcpyAsync(out, e->stmp_out.p, (size_t)m * DD * 4, hipMemcpyDeviceToHost, e->stream));
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     return m;
 }
 
@@ -1216,7 +1232,7 @@ static int adapter_reserve(vox_hip_engine *e, int64_t extra_rows) {
     const int64_t dead = std::min(e->adapter_consumed - e->adapter_row0, phys);
     if (dead > 0) {
         const int64_t live = phys - dead;
-        HC(hipStreamSynchronize(e->stream));
+        HC(esync(e));
         if (live > 0) {
             if (ensure(e, e->stmp_in, (size_t)live * DD * 4)) return -1;
             HC(hipMemcpy(e->stmp_in.p, e->adapter + (size_t)dead * DD, (size_t)live * DD * 4, hipMemcpyDeviceToDevice));
@@ -1229,7 +1245,7 @@ static int adapter_reserve(vox_hip_engine *e, int64_t extra_rows) {
     int64_t ncap = e->adapter_cap;
     while (ncap < phys + extra_rows) ncap *= 2;
     float *np = nullptr;
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMalloc((void **)&np, (size_t)ncap * DD * 4));
     if (phys > 0) HC(hipMemcpy(np, e->adapter, (size_t)phys * DD * 4, hipMemcpyDeviceToDevice));
     HC(hipFree(e->adapter));
@@ -1248,7 +1264,7 @@ extern "C" int vox_hip_adapter_read(vox_hip_engine_t *e, int64_t first_row, int 
     if (!e || n_rows <= 0) return -1;
     HC(hipSetDevice(e->device));
     if (first_row < e->adapter_row0 || first_row + n_rows > e->adapter_total) { g_err = "vox_hip_adapter_read: rows not resident"; return -1; }
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMemcpy(out, e->adapter + (size_t)(first_row - e->adapter_row0) * e->d.dec_dim,
                  (size_t)n_rows * e->d.dec_dim * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -1305,7 +1321,7 @@ extern "C" int vox_hip_stream_encode(vox_hip_engine_t *e, int n_mel, int *conv_r
     }
     if (enc_residual) *enc_residual = e->enc_res;
     HC(hipEventRecord(e->ev1, s));
-    HC(hipStreamSynchronize(s));
+    HC(esync(e));
     float ms = 0.f;
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
     e->timing.encode_ms += ms;
@@ -1349,8 +1365,10 @@ extern "C" int vox_hip_shard_layer(vox_hip_engine_t *e, int layer) {
                           L.n1, L.n2, nullptr, L.kring, L.vring, e->enc_ring_cap);
 }
 
-// K then V rows of positions [pos_first, pos_first+n) of `layer`: dst [2][n][kv_dim] (device).
-extern "C" int vox_hip_shard_kv_export(vox_hip_engine_t *e, int layer, int pos_first, int n, void *dst_dev) {
+// K then V rows of positions [pos_first, pos_first+n) of `layer`: dst [2][n][kv_dim] (device).  The copies are only
+// ENQUEUED on the engine stream (a consumer ordered behind that stream - RCCL on the same stream, an event - needs no
+// host wait); vox_hip_shard_kv_export is the same followed by a host synchronisation (host-staged transports: gloo).
+extern "C" int vox_hip_shard_kv_export_async(vox_hip_engine_t *e, int layer, int pos_first, int n, void *dst_dev) {
     if (!e || layer < 0 || layer >= e->d.enc_layers || n <= 0) return -1;
     HC(hipSetDevice(e->device));
     const int kvd = e->enc_qd, cap = e->enc_ring_cap;
@@ -1362,7 +1380,11 @@ extern "C" int vox_hip_shard_kv_export(vox_hip_engine_t *e, int layer, int pos_f
         HC(hipMemcpyAsync(dst + (size_t)(n + i) * kvd, e->enc[layer].vring + (size_t)slot * kvd, (size_t)run * kvd * 4, hipMemcpyDeviceToDevice, e->stream));
         i += run;
     }
-    HC(hipStreamSynchronize(e->stream));
+    return 0;
+}
+extern "C" int vox_hip_shard_kv_export(vox_hip_engine_t *e, int layer, int pos_first, int n, void *dst_dev) {
+    if (vox_hip_shard_kv_export_async(e, layer, pos_first, n, dst_dev)) return -1;
+    HC(esync(e));
     return 0;
 }
 
@@ -1384,7 +1406,7 @@ extern "C" int vox_hip_shard_kv_import(vox_hip_engine_t *e, int layer, int pos_f
 
 // Final norm + adapter over the shard rows (shard_n must be a multiple of 4). Writes
 // [shard_n/4, dec_dim] rows to dst_dev (device) and returns the row count.
-extern "C" int vox_hip_shard_end(vox_hip_engine_t *e, void *dst_dev) {
+extern "C" int vox_hip_shard_end_async(vox_hip_engine_t *e, void *dst_dev) {
     if (!e || !e->shard_x || !dst_dev) return -1;
     HC(hipSetDevice(e->device));
     const int n = e->shard_n, ED = e->d.enc_dim;
@@ -1393,20 +1415,29 @@ extern "C" int vox_hip_shard_end(vox_hip_engine_t *e, void *dst_dev) {
     hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, e->stream, (float *)e->stmp_out.p, ED, e->shard_x, ED,
                        e->enc_final_norm, (const float *)nullptr, ED, e->d.enc_eps);
     if (adapter_dev(e, (const float *)e->stmp_out.p, n / 4, (float *)dst_dev)) return -1;
-    HC(hipStreamSynchronize(e->stream));
     e->shard_x = nullptr; e->shard_n = 0;
     return n / 4;
 }
+extern "C" int vox_hip_shard_end(vox_hip_engine_t *e, void *dst_dev) {
+    const int m = vox_hip_shard_end_async(e, dst_dev);
+    if (m < 0) return -1;
+    HC(esync(e));
+    return m;
+}
 
 // Append adapter rows that already live in device memory (gathered over xGMI).
-extern "C" int vox_hip_adapter_append_dev(vox_hip_engine_t *e, const void *rows_dev, int n_rows) {
+extern "C" int vox_hip_adapter_append_dev_async(vox_hip_engine_t *e, const void *rows_dev, int n_rows) {
     if (!e || n_rows <= 0) return -1;
     HC(hipSetDevice(e->device));
-    if (adapter_reserve(e, n_rows)) return -1;
+    if (adapter_reserve(e, n_rows)) return -1;           // (waits only when the buffer has to grow or compact)
     HC(hipMemcpyAsync(e->adapter + (size_t)(e->adapter_total - e->adapter_row0) * e->d.dec_dim, rows_dev,
                       (size_t)n_rows * e->d.dec_dim * 4, hipMemcpyDeviceToDevice, e->stream));
-    HC(hipStreamSynchronize(e->stream));
     e->adapter_total += n_rows;
+    return 0;
+}
+extern "C" int vox_hip_adapter_append_dev(vox_hip_engine_t *e, const void *rows_dev, int n_rows) {
+    if (vox_hip_adapter_append_dev_async(e, rows_dev, n_rows)) return -1;
+    HC(esync(e));
     return 0;
 }
 
@@ -1421,7 +1452,7 @@ extern "C" void vox_hip_device_free(vox_hip_engine_t *e, void *p) { if (e && p) 
 extern "C" int vox_hip_memcpy(vox_hip_engine_t *e, void *dst, const void *src, size_t bytes, int kind) {
     if (!e) return -1;
     HC(hipSetDevice(e->device));
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMemcpy(dst, src, bytes, kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice));
     return 0;
 }
@@ -1455,7 +1486,7 @@ extern "C" int vox_hip_decoder_prefill(vox_hip_engine_t *e, const float *embeds,
     if (ensure(e, e->sx, (size_t)seq_len * DD * 4)) return -1;
     HC(hipMemcpyAsync(e->sx.p, embeds, (size_t)seq_len * DD * 4, hipMemcpyHostToDevice, e->stream));
     if (decoder_prefill_dev(e, (float *)e->sx.p, seq_len)) return -1;
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     return 0;
 }
 
@@ -1693,22 +1724,57 @@ static int set_state(vox_hip_engine *e, int pos, int token, int64_t adapter_phys
     DecState st{};
     st.pos = pos; st.token = token; st.n_out = 0; st.stop = 0; st.adapter_row = adapter_phys_row;
     HC(hipMemcpyAsync(e->d_st, &st, sizeof st, hipMemcpyHostToDevice, e->stream));
-    HC(hipStreamSynchronize(e->stream));   // st lives on the host stack
+    HC(esync(e));   // st lives on the host stack
     return 0;
 }
 
 // After a synchronisation: did a hand-off of the fused decode kernel time out since the last check?  If so the results of
-// everything enqueued since are void: switch to the launch-per-GEMV chain for good (loudly) and tell the caller to redo.
+// everything enqueued since are void: switch to the launch-per-GEMV chain (loudly) and tell the caller to redo.  The switch
+// is a suspension, not a verdict: a time-out means the 256 workgroups were not co-resident for a moment (another process or
+// stream held CUs), so after FUSE_REARM_STEPS clean steps on the chain (doubling with every further failure, capped) the
+// fused kernel is tried again - one transient contention event used to cost 0.2 ms per token for the engine's lifetime.
+// VOX_HIP_FUSE_NO_REARM=1 keeps the old sticky behaviour (A/B).
+constexpr long FUSE_REARM_STEPS = 256;
 static int fused_failed(vox_hip_engine *e) {
     if (!e->use_fused) return 0;
     unsigned err = 0;
     if (hipMemcpy(&err, e->d_fuse_err, sizeof err, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
     if (!err) return 0;
-    fprintf(stderr, "vox_hip: ERROR fused decode kernel timed out in hand-off %u (its 256 workgroups were not co-resident?); "
-                    "switching to the launch-per-GEMV chain and repeating the work\n", err);
     e->use_fused = false; e->fuse_failures++;
+    static const bool no_rearm = getenv("VOX_HIP_FUSE_NO_REARM") != nullptr;
+    e->fuse_rearm = no_rearm ? 0 : FUSE_REARM_STEPS << std::min(e->fuse_failures - 1, 6);
+    fprintf(stderr, "vox_hip: ERROR fused decode kernel timed out in hand-off %u (its 256 workgroups were not co-resident?); "
+                    "repeating the work on the launch-per-GEMV chain%s\n", err,
+            e->fuse_rearm ? " and staying there for a while before the fused kernel is tried again" : " and staying there");
     (void)hipMemset(e->d_fuse_err, 0, sizeof(unsigned));
     return 1;
+}
+// `steps` decode steps completed cleanly: count down a suspension of the fused kernel.
+static void fused_rearm_tick(vox_hip_engine *e, int steps) {
+    if (!e->fused_ok || e->use_fused || e->fuse_rearm <= 0 || steps <= 0) return;
+    e->fuse_rearm -= steps;
+    if (e->fuse_rearm <= 0) {
+        e->fuse_rearm = 0; e->use_fused = true;
+        fprintf(stderr, "vox_hip: fused decode kernel re-armed after %d time-out(s)\n", e->fuse_failures);
+    }
+}
+// fuse_failures so far / is the fused kernel live right now / steps left of a suspension (tests, bench)
+extern "C" int vox_hip_fuse_stats(const vox_hip_engine_t *e, int *failures, int *armed, long *rearm_in) {
+    if (!e) return -1;
+    if (failures) *failures = e->fuse_failures;
+    if (armed) *armed = e->use_fused ? 1 : 0;
+    if (rearm_in) *rearm_in = e->fuse_rearm;
+    return e->fused_ok ? 0 : 1;
+}
+// Test hook: make the next check after a synchronisation behave as if a hand-off had timed out (the batch is repeated on
+// the chain, the suspension / re-arm logic runs).  No effect on engines without the fused kernel.
+extern "C" int vox_hip_debug_inject_fuse_timeout(vox_hip_engine_t *e) {
+    if (!e || !e->use_fused) return -1;
+    HC(hipSetDevice(e->device));
+    HC(esync(e));
+    const unsigned code = 99u;
+    HC(hipMemcpy(e->d_fuse_err, &code, sizeof code, hipMemcpyHostToDevice));
+    return 0;
 }
 
 extern "C" int vox_hip_decoder_step(vox_hip_engine_t *e, const float *embed, float *logits) {
@@ -1721,9 +1787,10 @@ extern "C" int vox_hip_decoder_step(vox_hip_engine_t *e, const float *embed, flo
         if (enqueue_step(e, e->dec_pos, false, e->dlogits, -1, 1)) return -1;
         HC(hipMemcpyAsync(&tok, e->d_tokens, sizeof(int), hipMemcpyDeviceToHost, e->stream));
         if (logits) HC(hipMemcpyAsync(logits, e->dlogits, (size_t)e->d.vocab * 4, hipMemcpyDeviceToHost, e->stream));
-        HC(hipStreamSynchronize(e->stream));
+        HC(esync(e));
         if (!fused_failed(e)) break;
     }
+    fused_rearm_tick(e, 1);
     e->dec_pos += 1;
     return tok;
 }
@@ -1750,7 +1817,7 @@ extern "C" int vox_hip_decoder_prefill_stream(vox_hip_engine_t *e, int64_t first
         HC(hipMemcpyAsync(&tok, e->d_tokens, sizeof(int), hipMemcpyDeviceToHost, s));
         if (logits) HC(hipMemcpyAsync(logits, e->dlogits, (size_t)e->d.vocab * 4, hipMemcpyDeviceToHost, s));
         HC(hipEventRecord(e->ev1, s));
-        HC(hipStreamSynchronize(s));
+        HC(esync(e));
         if (!fused_failed(e)) break;
     }
     float ms = 0.f; hipEventElapsedTime(&ms, e->ev0, e->ev1);
@@ -1781,7 +1848,7 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
             if (enqueue_step(e, e->dec_pos + i, true, logits_out ? lg + (size_t)i * V : lg, eos_token, 1)) return -1;
         DecState st{};
         HC(hipMemcpyAsync(&st, e->d_st, sizeof st, hipMemcpyDeviceToHost, s));
-        HC(hipStreamSynchronize(s));
+        HC(esync(e));
         if (fused_failed(e)) continue;          // the batch's results are void: run it again (now on the chain)
         const int got = st.n_out;
         if (got > 0) HC(hipMemcpy(tokens_out + done, e->d_tokens, (size_t)got * sizeof(int), hipMemcpyDeviceToHost));
@@ -1789,11 +1856,12 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
             HC(hipMemcpy(logits_out + (size_t)done * V, lg, (size_t)got * V * 4, hipMemcpyDeviceToHost));
         e->dec_pos += got;
         done += got;
+        fused_rearm_tick(e, got);
         if (got > 0) prev_token = tokens_out[done - 1];
         if (st.stop || got < batch) break;
     }
     HC(hipEventRecord(e->ev1, s));
-    HC(hipStreamSynchronize(s));
+    HC(esync(e));
     float ms = 0.f; hipEventElapsedTime(&ms, e->ev0, e->ev1);
     e->timing.decode_ms += ms;
     e->timing.decode_steps += done;
@@ -1807,31 +1875,49 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
 extern "C" void vox_hip_reset_encoder(vox_hip_engine_t *e) {
     if (!e) return;
     hipSetDevice(e->device);
-    hipStreamSynchronize(e->stream);
+    esync(e);
     e->enc_pos = 0; e->mel_q = 0; e->c0_carry = 0; e->enc_res = 0;
     // zero the causal-history rows (start-of-sequence padding)
     if (e->conv_in0.p) hipMemsetAsync(e->conv_in0.p, 0, (size_t)2 * e->d.mel_bins * 4, e->stream);
     if (e->conv_in1.p) hipMemsetAsync(e->conv_in1.p, 0, (size_t)2 * e->d.enc_dim * 4, e->stream);
-    hipStreamSynchronize(e->stream);
+    esync(e);
 }
+// The same without waiting: the host-side counters are reset at once, the history rows are zeroed in stream order
+// (everything already enqueued still sees the old rows, everything enqueued later the new ones).
+extern "C" void vox_hip_reset_encoder_async(vox_hip_engine_t *e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    e->enc_pos = 0; e->mel_q = 0; e->c0_carry = 0; e->enc_res = 0;
+    if (e->conv_in0.p) hipMemsetAsync(e->conv_in0.p, 0, (size_t)2 * e->d.mel_bins * 4, e->stream);
+    if (e->conv_in1.p) hipMemsetAsync(e->conv_in1.p, 0, (size_t)2 * e->d.enc_dim * 4, e->stream);
+}
+// The engine's HIP stream (a hipStream_t) for callers that order their own work against it without a host wait
+// (multi_gpu.py wraps it in torch.cuda.ExternalStream so that RCCL send / recv are stream-ordered with the shard kernels),
+// and the number of host-side waits on that stream so far.
+extern "C" void *vox_hip_stream_handle(vox_hip_engine_t *e) { return e ? (void *)e->stream : nullptr; }
+extern "C" unsigned long long vox_hip_host_syncs(const vox_hip_engine_t *e) { return e ? e->n_host_syncs : 0; }
 extern "C" void vox_hip_reset_decoder(vox_hip_engine_t *e) {
     if (!e) return;
     hipSetDevice(e->device);
-    hipStreamSynchronize(e->stream);
+    esync(e);
     e->dec_pos = 0;
     e->adapter_total = 0; e->adapter_row0 = 0; e->adapter_consumed = 0;
 }
 extern "C" void vox_hip_reset_decoder_kv(vox_hip_engine_t *e) {
     if (!e) return;
     hipSetDevice(e->device);
-    hipStreamSynchronize(e->stream);
+    esync(e);
     e->dec_pos = 0;
 }
 extern "C" int vox_hip_decoder_kv_len(const vox_hip_engine_t *e) { return e ? e->dec_pos : 0; }
 extern "C" int vox_hip_mel_queue_len(const vox_hip_engine_t *e) { return e ? e->mel_q : 0; }
-extern "C" void vox_hip_sync(vox_hip_engine_t *e) { if (e) { hipSetDevice(e->device); hipStreamSynchronize(e->stream); } }
+extern "C" void vox_hip_sync(vox_hip_engine_t *e) { if (e) { hipSetDevice(e->device); esync(e); } }
 extern "C" void vox_hip_get_timing(const vox_hip_engine_t *e, vox_hip_timing_t *t) { if (e && t) *t = e->timing; }
 extern "C" void vox_hip_reset_timing(vox_hip_engine_t *e) { if (e) e->timing = vox_hip_timing_t{}; }
+// Encoder time spent outside vox_hip_stream_encode (a chunk sharded over several engines, host/vox_multi.c): the host
+// measures it around a synchronisation of the stream engine and books it here so that vox_hip_get_timing stays the
+// one place a caller reads phase times from.
+extern "C" void vox_hip_add_encode_ms(vox_hip_engine_t *e, double ms) { if (e && ms > 0) e->timing.encode_ms += ms; }
 
 // ------------------------------------------------------------------------------------
 // kernel-level test / bench surface
@@ -1847,7 +1933,7 @@ extern "C" int vox_hip_linear_bf16(vox_hip_engine_t *e, float *y, const float *x
     HC(hipMemcpy(dw, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
     if (bias) { HC(hipMalloc((void **)&db, (size_t)N * 4)); HC(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice)); }
     if (linear_dev(e, dy, N, dx, K, dw, db, M, K, N, ACT_NONE, nullptr, 0, impl)) return -1;
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipGetLastError());
     HC(hipMemcpy(y, dy, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     hipFree(dx); hipFree(dy); hipFree(dw); if (db) hipFree(db);
@@ -1901,7 +1987,7 @@ extern "C" int vox_hip_causal_attention(vox_hip_engine_t *e, float *out, const f
         g_err = "vox_hip_causal_attention: unsupported head geometry"; rc = -1;
     }
     if (!rc) {
-        HC(hipStreamSynchronize(e->stream));
+        HC(esync(e));
         HC(hipGetLastError());
         HC(hipMemcpy(out, dout, qn * 4, hipMemcpyDeviceToHost));
     }
@@ -1923,10 +2009,15 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
     }
     if (set_state(e, pos, 1, 0)) return -1.0;
     if (getenv("VOX_HIP_GRAPH_TIMING")) {
-        // experiment: the same step captured once into a hipGraph and replayed (no host launch cost)
+        // experiment: the same step captured once into a hipGraph and replayed (no host launch cost).  Only the
+        // launch-per-GEMV chain can be replayed: the fused kernel's hand-off epoch is a launch argument, a replay would
+        // find the previous replay's granules already tagged and read stale data.
+        const bool was_fused = e->use_fused;
+        e->use_fused = false;
+        struct Restore { vox_hip_engine *e; bool f; ~Restore() { e->use_fused = f; } } restore{e, was_fused};
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
         for (int i = 0; i < 3; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);
-        hipStreamSynchronize(e->stream);
+        esync(e);
         bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
             enqueue_step(e, pos, true, e->dlogits, -1, 0);
@@ -1938,7 +2029,7 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
         hipEventRecord(e->ev0, e->stream);
         for (int i = 0; i < iters; i++) hipGraphLaunch(ge, e->stream);
         hipEventRecord(e->ev1, e->stream);
-        hipStreamSynchronize(e->stream);
+        esync(e);
         hipGraphExecDestroy(ge); hipGraphDestroy(g);
     } else {
         for (int i = 0; i < 3; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);   // warm-up
@@ -1946,7 +2037,7 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
         for (int i = 0; i < iters; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);
         hipEventRecord(e->ev1, e->stream);
     }
-    hipStreamSynchronize(e->stream);
+    esync(e);
     float ms = 0.f;
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
     e->dec_pos = saved_pos;
@@ -1996,7 +2087,7 @@ extern "C" double vox_hip_time_empty_launches(vox_hip_engine_t *e, int n, int gr
     hipEventRecord(e->ev0, e->stream);
     for (int i = 0; i < n; i++) hipLaunchKernelGGL(k_boundary_probe, dim3(grid), dim3(256), 0, e->stream, e->dh, 16);
     hipEventRecord(e->ev1, e->stream);
-    hipStreamSynchronize(e->stream);
+    esync(e);
     float ms = 0.f;
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
     return (double)ms * 1e-3 / n;
@@ -2007,7 +2098,7 @@ extern "C" double vox_hip_time_empty_launches_graph(vox_hip_engine_t *e, int n, 
     if (!e || n <= 0 || grid <= 0) return -1.0;
     if (hipSetDevice(e->device) != hipSuccess) return -1.0;
     hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-    hipStreamSynchronize(e->stream);
+    esync(e);
     if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
     for (int i = 0; i < n; i++) hipLaunchKernelGGL(k_boundary_probe, dim3(grid), dim3(256), 0, e->stream, e->dh, 16);
     if (hipStreamEndCapture(e->stream, &g) != hipSuccess || !g) { (void)hipGetLastError(); return -1.0; }
@@ -2017,7 +2108,7 @@ extern "C" double vox_hip_time_empty_launches_graph(vox_hip_engine_t *e, int n, 
         hipEventRecord(e->ev0, e->stream);
         hipGraphLaunch(ge, e->stream);
         hipEventRecord(e->ev1, e->stream);
-        hipStreamSynchronize(e->stream);
+        esync(e);
         float ms = 0.f;
         hipEventElapsedTime(&ms, e->ev0, e->ev1);
         r = (double)ms * 1e-3 / n;
@@ -2054,7 +2145,7 @@ extern "C" double vox_hip_profile_decode(vox_hip_engine_t *e, int iters, int kv_
     if (e->adapter_total - e->adapter_row0 < 1) hipMemsetAsync(e->adapter, 0, (size_t)e->d.dec_dim * 4, e->stream);
     if (set_state(e, pos, 1, 0)) return -1.0;
     for (int i = 0; i < 2; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);
-    hipStreamSynchronize(e->stream);
+    esync(e);
     double sum_us[PK_COUNT] = {0}; long cnt[PK_COUNT] = {0};
     double total = 0;
     for (int it = 0; it < iters; it++) {
@@ -2062,7 +2153,7 @@ extern "C" double vox_hip_profile_decode(vox_hip_engine_t *e, int iters, int kv_
         prof_mark(e, -1);
         enqueue_step(e, pos, true, e->dlogits, -1, 0);
         e->prof_on = false;
-        hipStreamSynchronize(e->stream);
+        esync(e);
         for (size_t i = 1; i < e->prof_used; i++) {
             float ms = 0.f;
             hipEventElapsedTime(&ms, e->prof_ev[i - 1], e->prof_ev[i]);
@@ -2102,7 +2193,7 @@ extern "C" int vox_hip_quantize_decoder_fp8(vox_hip_engine_t *e) {
             quant(L.w13, 2 * DH, DD, &L.w138, &L.s13) || quant(L.w2, DD, DH, &L.w28, &L.s2)) return -1;
     }
     if (quant(e->tok_emb, d.vocab, DD, &e->tok_emb8, &e->stok)) return -1;
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipGetLastError());
     e->use_fp8 = true;
     return 0;
@@ -2140,7 +2231,7 @@ static int self_test(vox_hip_engine *e) {
     float ha[64], hb[64];
     HC(hipMemcpyAsync(ha, d_a, sizeof ha, hipMemcpyDeviceToHost, e->stream));
     HC(hipMemcpyAsync(hb, d_b, sizeof hb, hipMemcpyDeviceToHost, e->stream));
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     bool ok = true;
     for (int i = 0; i < 64; i++) if (fabsf(ha[i] - hb[i]) > 1e-3f * fabsf(hb[i])) ok = false;
     int failed = 0;
@@ -2168,7 +2259,7 @@ static int self_test(vox_hip_engine *e) {
     launch_gemm(e, dx, K, dw, dy0, N, M, N, K, dbias, nullptr, 0, ACT_NONE, 0);
     launch_gemm(e, dx, K, dw, dy1, N, M, N, K, dbias, nullptr, 0, ACT_NONE, 2);
     launch_gemm(e, dx, K, dw, dy2, N, M, N, K, dbias, nullptr, 0, ACT_NONE, 1);
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMemcpy(hy0.data(), dy0, hy0.size() * 4, hipMemcpyDeviceToHost));
     HC(hipMemcpy(hy1.data(), dy1, hy1.size() * 4, hipMemcpyDeviceToHost));
     HC(hipMemcpy(hy2.data(), dy2, hy2.size() * 4, hipMemcpyDeviceToHost));
@@ -2202,7 +2293,7 @@ static int self_test(vox_hip_engine *e) {
                 if (pass == 1) e->use_splitk = false;
                 okp = launch_gemm_planes(e, dp, (size_t)M * K, K, dw, dy0, N, M, N, K, dbias, nullptr, 0, ACT_NONE) == 0;
                 e->use_splitk = sk;
-                okp = okp && hipStreamSynchronize(e->stream) == hipSuccess &&
+                okp = okp && esync(e) == hipSuccess &&
                       hipMemcpy(hy0.data(), dy0, hy0.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
                 for (size_t i = 0; okp && i < hy0.size(); i++) worst = std::max(worst, (double)fabsf(hy0[i] - hy2[i]));
             }
@@ -2240,7 +2331,7 @@ static int self_test(vox_hip_engine *e) {
         hipLaunchKernelGGL(k_attn_enc_mfma, dim3((nq + 127) / 128, nh), dim3(256), 0, e->stream, a);
         a.out = do2;
         hipLaunchKernelGGL((k_attn_rows<64>), dim3((nq + 127) / 128, nh), dim3(128), 0, e->stream, a);
-        HC(hipStreamSynchronize(e->stream));
+        HC(esync(e));
         HC(hipMemcpy(r1.data(), do1, r1.size() * 4, hipMemcpyDeviceToHost));
         HC(hipMemcpy(r2.data(), do2, r2.size() * 4, hipMemcpyDeviceToHost));
         double md = 0;
@@ -2330,7 +2421,7 @@ extern "C" int vox_hip_k_eltwise(vox_hip_engine_t *e, float *a, const float *b, 
     if (b) { db = t.up(b, n); KNULL(db); }
     hipLaunchKernelGGL(k_eltwise, dim3(grid1d(n)), dim3(256), 0, e->stream, da, (const float *)db, s, n, op);
     LAUNCH_CHECK("k_eltwise");
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMemcpy(a, da, n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -2349,7 +2440,7 @@ extern "C" int vox_hip_k_sgemm(vox_hip_engine_t *e, float *C, const float *A, co
                        (const float *)dB, (long)(b_is_nk ? 1 : N), (long)(b_is_nk ? K : 1), M, N, K, (const float *)db,
                        (const float *)nullptr);
     LAUNCH_CHECK("k_sgemm");
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -2375,7 +2466,7 @@ extern "C" int vox_hip_k_conv1d(vox_hip_engine_t *e, float *out, const float *in
                        (const float *)dw, K, (const float *)col, (long)out_len, 1L, c_out, out_len, K, (const float *)nullptr,
                        (const float *)db);
     LAUNCH_CHECK("conv1d");
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMemcpy(out, dout, (size_t)c_out * out_len * 4, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -2392,7 +2483,7 @@ extern "C" int vox_hip_k_rms_norm(vox_hip_engine_t *e, float *out, const float *
     else
         hipLaunchKernelGGL(k_rmsnorm_generic, dim3(seq), dim3(256), 0, e->stream, dout, (const float *)dx, (const float *)dw, hidden, eps);
     LAUNCH_CHECK("rms_norm");
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMemcpy(out, dout, (size_t)seq * hidden * 4, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -2404,7 +2495,7 @@ extern "C" int vox_hip_k_softmax(vox_hip_engine_t *e, float *x, int rows, int co
     float *dx = t.up(x, (size_t)rows * cols); KNULL(dx);
     hipLaunchKernelGGL(k_softmax_rows, dim3(rows), dim3(256), 0, e->stream, dx, cols);
     LAUNCH_CHECK("softmax");
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMemcpy(x, dx, (size_t)rows * cols * 4, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -2421,7 +2512,7 @@ extern "C" int vox_hip_k_rope_freqs(vox_hip_engine_t *e, float *freqs, const int
     hipLaunchKernelGGL(k_rope_freqs, dim3(grid1d((size_t)seq * (dim / 2))), dim3(256), 0, e->stream, dout, (const int *)dpos, seq,
                        dim / 2, (const float *)df);
     LAUNCH_CHECK("rope_freqs");
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMemcpy(freqs, dout, (size_t)seq * (dim / 2) * 2 * 4, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -2436,7 +2527,7 @@ extern "C" int vox_hip_k_apply_rope(vox_hip_engine_t *e, float *x, const float *
     hipLaunchKernelGGL(k_rope_apply, dim3(grid1d((size_t)seq * hidden / 2)), dim3(256), 0, e->stream, dx, hidden, seq, hidden,
                        head_dim, (const float *)df);
     LAUNCH_CHECK("apply_rope");
-    HC(hipStreamSynchronize(e->stream));
+    HC(esync(e));
     HC(hipMemcpy(x, dx, (size_t)seq * hidden * 4, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -2491,7 +2582,7 @@ extern "C" int vox_hip_clone_encoder_weights(vox_hip_engine_t *dst, vox_hip_engi
     const size_t ED = d.enc_dim, EQ = src->enc_qd, EH = d.enc_hidden, DD = d.dec_dim;
     HC(hipSetDevice(src->device));
     if (src->up && src->up->flush()) return -1;
-    HC(hipStreamSynchronize(src->stream));
+    HC(esync(src));
     hipStream_t s = src->stream;
     auto cp = [&](void *dp, const void *sp, size_t bytes) { return peer_copy_async(dst, dp, src, sp, bytes, s); };
     int rc = 0;
@@ -2507,7 +2598,7 @@ extern "C" int vox_hip_clone_encoder_weights(vox_hip_engine_t *dst, vox_hip_engi
         rc |= cp(D.bqkv, S.bqkv, 3 * EQ * 4); rc |= cp(D.bo, S.bo, ED * 4); rc |= cp(D.b2, S.b2, ED * 4); rc |= cp(D.n1, S.n1, ED * 4); rc |= cp(D.n2, S.n2, ED * 4);
     }
     if (rc) return -1;
-    HC(hipStreamSynchronize(s));
+    HC(esync(src));
     return 0;
 }
 
@@ -2518,10 +2609,10 @@ extern "C" int vox_hip_mel_queue_push(vox_hip_engine_t *src, vox_hip_engine_t *d
     HC(hipSetDevice(dst->device));
     if (ensure_keep(dst, dst->conv_in0, (size_t)(2 + dst->mel_q + n) * MB * 4, (size_t)(2 + dst->mel_q) * MB * 4)) return -1;
     HC(hipSetDevice(src->device));
-    HC(hipStreamSynchronize(src->stream));
+    HC(esync(src));
     if (peer_copy_async(dst, (float *)dst->conv_in0.p + (size_t)(2 + dst->mel_q) * MB, src, (const float *)src->conv_in0.p + (size_t)(2 + frame0) * MB,
                         (size_t)n * MB * 4, src->stream)) return -1;
-    HC(hipStreamSynchronize(src->stream));
+    HC(esync(src));
     dst->mel_q += n;
     return 0;
 }

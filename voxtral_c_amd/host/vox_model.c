@@ -24,22 +24,47 @@ static const vox_st_tensor_t *need(const vox_st_file_t *sf, const char *name) {
     return t;
 }
 
-static int up_bf16(vox_ctx_t *ctx, int slot, int layer, const char *name) {
+/* Upload a BF16 tensor byte for byte; *view (optional) = the tensor inside the mmap, as the reference's
+ * load_bf16_direct leaves it (voxtral_encoder.c:42-48). */
+static int up_bf16(vox_ctx_t *ctx, int slot, int layer, const char *name, uint16_t **view) {
     const vox_st_tensor_t *t = need((const vox_st_file_t *)ctx->safetensors, name);
     if (!t) return -1;
     if (t->dtype != VOX_ST_BF16) { fprintf(stderr, "vox_load: %s is not BF16\n", name); return -1; }
+    if (view) *view = (uint16_t *)t->data;
     return vox_hip_upload_bf16((vox_hip_engine_t *)ctx->engine, slot, layer, (const uint16_t *)t->data,
                                (size_t)vox_st_numel(t));
 }
 
-static int up_f32(vox_ctx_t *ctx, int slot, int layer, const char *name) {
+/* the ctx owns the f32 conversions it exposes through the reference's weight views */
+static int own_f32(vox_ctx_t *ctx, float *v) {
+    if (ctx->n_owned_f32 == ctx->cap_owned_f32) {
+        const int nc = ctx->cap_owned_f32 ? ctx->cap_owned_f32 * 2 : 256;
+        float **t = (float **)realloc(ctx->owned_f32, (size_t)nc * sizeof(float *));
+        if (!t) return -1;
+        ctx->owned_f32 = t; ctx->cap_owned_f32 = nc;
+    }
+    ctx->owned_f32[ctx->n_owned_f32++] = v;
+    return 0;
+}
+
+/* Convert to f32 as the reference's load_f32 does (voxtral_encoder.c:32-40), upload, and keep the conversion as the
+ * host view *view (owned by the ctx) - or drop it when no view is asked for. */
+static int up_f32(vox_ctx_t *ctx, int slot, int layer, const char *name, float **view) {
     const vox_st_tensor_t *t = need((const vox_st_file_t *)ctx->safetensors, name);
     if (!t) return -1;
     float *v = vox_st_to_f32(t);
     if (!v) return -1;
     const int rc = vox_hip_upload_f32((vox_hip_engine_t *)ctx->engine, slot, layer, v, (size_t)vox_st_numel(t));
-    free(v);
+    if (view && own_f32(ctx, v) == 0) *view = v; else free(v);
     return rc;
+}
+
+/* f32 view of a tensor the engine takes as bf16 (the conv weights: the reference converts them at load,
+ * voxtral_encoder.c:56-63; identical values). */
+static void view_f32(vox_ctx_t *ctx, const char *name, float **view) {
+    const vox_st_tensor_t *t = vox_st_find((const vox_st_file_t *)ctx->safetensors, name);
+    float *v = t ? vox_st_to_f32(t) : NULL;
+    if (v && own_f32(ctx, v) == 0) *view = v; else free(v);
 }
 
 /* ---- time conditioning (reference voxtral.c:31-80) --------------------------------
@@ -138,6 +163,11 @@ static int discover_dims(const vox_st_file_t *sf, vox_model_dims_t *d) {
             fprintf(stderr, "vox_load: checkpoint geometry out of range (field %d = %d)\n", (int)i, lim[i][0]);
             return -1;
         }
+    if (d->enc_layers > VOX_ENC_LAYERS || d->dec_layers > VOX_DEC_LAYERS || d->dec_dim > VOX_DEC_DIM) {
+        fprintf(stderr, "vox_load: checkpoint deeper / wider than the vox_ctx_t weight views (%d/%d layers, dec_dim %d)\n",
+                d->enc_layers, d->dec_layers, d->dec_dim);
+        return -1;
+    }
     if (d->dec_heads % d->dec_kv_heads != 0 || d->enc_dim % 8 != 0 || d->dec_dim % 8 != 0 || d->enc_hidden % 8 != 0 ||
         d->dec_hidden % 8 != 0) {
         fprintf(stderr, "vox_load: checkpoint geometry not supported (head grouping / alignment)\n");
@@ -204,55 +234,60 @@ vox_ctx_t *vox_load_ex(const char *model_dir, const vox_load_opts_t *opts) {
 
     int rc = 0;
     char nm[384];
-    rc |= up_bf16(ctx, VOXT_TOK_EMB, 0, EMB_PFX ".tok_embeddings.weight");
-    rc |= up_bf16(ctx, VOXT_CONV0_W, 0, ENC_PFX ".conv_layers.0.conv.weight");
-    rc |= up_f32(ctx, VOXT_CONV0_B, 0, ENC_PFX ".conv_layers.0.conv.bias");
-    rc |= up_bf16(ctx, VOXT_CONV1_W, 0, ENC_PFX ".conv_layers.1.conv.weight");
-    rc |= up_f32(ctx, VOXT_CONV1_B, 0, ENC_PFX ".conv_layers.1.conv.bias");
+    rc |= up_bf16(ctx, VOXT_TOK_EMB, 0, EMB_PFX ".tok_embeddings.weight", &ctx->decoder.tok_embeddings_bf16);
+    rc |= up_bf16(ctx, VOXT_CONV0_W, 0, ENC_PFX ".conv_layers.0.conv.weight", NULL);
+    rc |= up_f32(ctx, VOXT_CONV0_B, 0, ENC_PFX ".conv_layers.0.conv.bias", &ctx->encoder.conv0_bias);
+    rc |= up_bf16(ctx, VOXT_CONV1_W, 0, ENC_PFX ".conv_layers.1.conv.weight", NULL);
+    rc |= up_f32(ctx, VOXT_CONV1_B, 0, ENC_PFX ".conv_layers.1.conv.bias", &ctx->encoder.conv1_bias);
+    view_f32(ctx, ENC_PFX ".conv_layers.0.conv.weight", &ctx->encoder.conv0_weight);
+    view_f32(ctx, ENC_PFX ".conv_layers.1.conv.weight", &ctx->encoder.conv1_weight);
     for (int i = 0; i < d->enc_layers && !rc; i++) {
+        vox_enc_layer_t *Lv = &ctx->encoder.layers[i];
 #define EL(sfx) (snprintf(nm, sizeof nm, ENC_PFX ".transformer.layers.%d." sfx, i), nm)
-        rc |= up_bf16(ctx, VOXT_ENC_WQ, i, EL("attention.wq.weight"));
-        rc |= up_bf16(ctx, VOXT_ENC_WK, i, EL("attention.wk.weight"));
-        rc |= up_bf16(ctx, VOXT_ENC_WV, i, EL("attention.wv.weight"));
-        rc |= up_bf16(ctx, VOXT_ENC_WO, i, EL("attention.wo.weight"));
-        rc |= up_bf16(ctx, VOXT_ENC_W1, i, EL("feed_forward.w1.weight"));
-        rc |= up_bf16(ctx, VOXT_ENC_W2, i, EL("feed_forward.w2.weight"));
-        rc |= up_bf16(ctx, VOXT_ENC_W3, i, EL("feed_forward.w3.weight"));
-        rc |= up_f32(ctx, VOXT_ENC_BQ, i, EL("attention.wq.bias"));
-        rc |= up_f32(ctx, VOXT_ENC_BV, i, EL("attention.wv.bias"));
-        rc |= up_f32(ctx, VOXT_ENC_BO, i, EL("attention.wo.bias"));
-        rc |= up_f32(ctx, VOXT_ENC_B2, i, EL("feed_forward.w2.bias"));
-        rc |= up_f32(ctx, VOXT_ENC_ATTN_NORM, i, EL("attention_norm.weight"));
-        rc |= up_f32(ctx, VOXT_ENC_FFN_NORM, i, EL("ffn_norm.weight"));
+        rc |= up_bf16(ctx, VOXT_ENC_WQ, i, EL("attention.wq.weight"), &Lv->wq_weight_bf16);
+        rc |= up_bf16(ctx, VOXT_ENC_WK, i, EL("attention.wk.weight"), &Lv->wk_weight_bf16);
+        rc |= up_bf16(ctx, VOXT_ENC_WV, i, EL("attention.wv.weight"), &Lv->wv_weight_bf16);
+        rc |= up_bf16(ctx, VOXT_ENC_WO, i, EL("attention.wo.weight"), &Lv->wo_weight_bf16);
+        rc |= up_bf16(ctx, VOXT_ENC_W1, i, EL("feed_forward.w1.weight"), &Lv->w1_weight_bf16);
+        rc |= up_bf16(ctx, VOXT_ENC_W2, i, EL("feed_forward.w2.weight"), &Lv->w2_weight_bf16);
+        rc |= up_bf16(ctx, VOXT_ENC_W3, i, EL("feed_forward.w3.weight"), &Lv->w3_weight_bf16);
+        rc |= up_f32(ctx, VOXT_ENC_BQ, i, EL("attention.wq.bias"), &Lv->wq_bias);
+        rc |= up_f32(ctx, VOXT_ENC_BV, i, EL("attention.wv.bias"), &Lv->wv_bias);
+        rc |= up_f32(ctx, VOXT_ENC_BO, i, EL("attention.wo.bias"), &Lv->wo_bias);
+        rc |= up_f32(ctx, VOXT_ENC_B2, i, EL("feed_forward.w2.bias"), &Lv->w2_bias);
+        rc |= up_f32(ctx, VOXT_ENC_ATTN_NORM, i, EL("attention_norm.weight"), &Lv->attention_norm);
+        rc |= up_f32(ctx, VOXT_ENC_FFN_NORM, i, EL("ffn_norm.weight"), &Lv->ffn_norm);
         if (vox_verbose >= 2) fprintf(stderr, "  Encoder layer %d/%d loaded\n", i + 1, d->enc_layers);
     }
-    rc |= up_f32(ctx, VOXT_ENC_FINAL_NORM, 0, ENC_PFX ".transformer.norm.weight");
-    rc |= up_bf16(ctx, VOXT_ADAPTER0, 0, EMB_PFX ".audio_language_projection.0.weight");
-    rc |= up_bf16(ctx, VOXT_ADAPTER1, 0, EMB_PFX ".audio_language_projection.2.weight");
+    rc |= up_f32(ctx, VOXT_ENC_FINAL_NORM, 0, ENC_PFX ".transformer.norm.weight", &ctx->encoder.norm);
+    rc |= up_bf16(ctx, VOXT_ADAPTER0, 0, EMB_PFX ".audio_language_projection.0.weight", &ctx->adapter.linear0_weight_bf16);
+    rc |= up_bf16(ctx, VOXT_ADAPTER1, 0, EMB_PFX ".audio_language_projection.2.weight", &ctx->adapter.linear1_weight_bf16);
 
     ctx->ada_down = (float **)calloc((size_t)d->dec_layers, sizeof(float *));
     ctx->ada_up = (float **)calloc((size_t)d->dec_layers, sizeof(float *));
-    ctx->t_cond = (float *)calloc((size_t)d->dec_dim, sizeof(float));
     ctx->ada_scale = (float *)calloc((size_t)d->dec_layers * d->dec_dim, sizeof(float));
+    if (!ctx->ada_down || !ctx->ada_up || !ctx->ada_scale) rc = -1;
     for (int i = 0; i < d->dec_layers && !rc; i++) {
+        vox_dec_layer_t *Lv = &ctx->decoder.layers[i];
 #define DL(sfx) (snprintf(nm, sizeof nm, "layers.%d." sfx, i), nm)
-        rc |= up_bf16(ctx, VOXT_DEC_WQ, i, DL("attention.wq.weight"));
-        rc |= up_bf16(ctx, VOXT_DEC_WK, i, DL("attention.wk.weight"));
-        rc |= up_bf16(ctx, VOXT_DEC_WV, i, DL("attention.wv.weight"));
-        rc |= up_bf16(ctx, VOXT_DEC_WO, i, DL("attention.wo.weight"));
-        rc |= up_bf16(ctx, VOXT_DEC_W1, i, DL("feed_forward.w1.weight"));
-        rc |= up_bf16(ctx, VOXT_DEC_W2, i, DL("feed_forward.w2.weight"));
-        rc |= up_bf16(ctx, VOXT_DEC_W3, i, DL("feed_forward.w3.weight"));
-        rc |= up_f32(ctx, VOXT_DEC_ATTN_NORM, i, DL("attention_norm.weight"));
-        rc |= up_f32(ctx, VOXT_DEC_FFN_NORM, i, DL("ffn_norm.weight"));
+        rc |= up_bf16(ctx, VOXT_DEC_WQ, i, DL("attention.wq.weight"), &Lv->wq_weight_bf16);
+        rc |= up_bf16(ctx, VOXT_DEC_WK, i, DL("attention.wk.weight"), &Lv->wk_weight_bf16);
+        rc |= up_bf16(ctx, VOXT_DEC_WV, i, DL("attention.wv.weight"), &Lv->wv_weight_bf16);
+        rc |= up_bf16(ctx, VOXT_DEC_WO, i, DL("attention.wo.weight"), &Lv->wo_weight_bf16);
+        rc |= up_bf16(ctx, VOXT_DEC_W1, i, DL("feed_forward.w1.weight"), &Lv->w1_weight_bf16);
+        rc |= up_bf16(ctx, VOXT_DEC_W2, i, DL("feed_forward.w2.weight"), &Lv->w2_weight_bf16);
+        rc |= up_bf16(ctx, VOXT_DEC_W3, i, DL("feed_forward.w3.weight"), &Lv->w3_weight_bf16);
+        rc |= up_f32(ctx, VOXT_DEC_ATTN_NORM, i, DL("attention_norm.weight"), &Lv->attention_norm);
+        rc |= up_f32(ctx, VOXT_DEC_FFN_NORM, i, DL("ffn_norm.weight"), &Lv->ffn_norm);
         const vox_st_tensor_t *t0 = need(sf, DL("ada_rms_norm_t_cond.0.weight"));
         const vox_st_tensor_t *t2 = need(sf, DL("ada_rms_norm_t_cond.2.weight"));
         if (!t0 || !t2) { rc = -1; break; }
-        ctx->ada_down[i] = vox_st_to_f32(t0);
-        ctx->ada_up[i] = vox_st_to_f32(t2);
+        Lv->ada_norm_down = ctx->ada_down[i] = vox_st_to_f32(t0);
+        Lv->ada_norm_up = ctx->ada_up[i] = vox_st_to_f32(t2);
+        if (!ctx->ada_down[i] || !ctx->ada_up[i]) { rc = -1; break; }
         if (vox_verbose >= 2) fprintf(stderr, "  Decoder layer %d/%d loaded\n", i + 1, d->dec_layers);
     }
-    rc |= up_f32(ctx, VOXT_DEC_FINAL_NORM, 0, "norm.weight");
+    rc |= up_f32(ctx, VOXT_DEC_FINAL_NORM, 0, "norm.weight", &ctx->decoder.norm);
     if (!rc) {
         const vox_mel_tables_t *mt = vox_mel_tables();
         rc |= vox_hip_upload_mel_tables((vox_hip_engine_t *)ctx->engine, mt->filters, mt->hann, mt->dft_cos, mt->dft_sin);
@@ -314,7 +349,9 @@ void vox_free(vox_ctx_t *ctx) {
     if (ctx->engine) vox_hip_engine_destroy((vox_hip_engine_t *)ctx->engine);
     if (ctx->ada_down) for (int i = 0; i < ctx->dims.dec_layers; i++) free(ctx->ada_down[i]);
     if (ctx->ada_up) for (int i = 0; i < ctx->dims.dec_layers; i++) free(ctx->ada_up[i]);
-    free(ctx->ada_down); free(ctx->ada_up); free(ctx->t_cond); free(ctx->ada_scale);
+    free(ctx->ada_down); free(ctx->ada_up); free(ctx->ada_scale);
+    for (int i = 0; i < ctx->n_owned_f32; i++) free(ctx->owned_f32[i]);
+    free(ctx->owned_f32);
     if (ctx->safetensors) vox_st_close((vox_st_file_t *)ctx->safetensors);
     if (ctx->tokenizer) vox_tokenizer_free((vox_tokenizer_t *)ctx->tokenizer);
     free(ctx);

@@ -55,6 +55,7 @@ struct vox_stream {
     int nontext_streak, text_since_restart, empty_restarts, waiting_prompt;
     int64_t last_decode_sample;
     int finished, continuous;
+    int failed;                 /* a device-side failure left the stream's state inconsistent: feed / flush / finish return -1 from now on */
 
     /* ring of pending token strings, VOX_MAX_ALT slots per position */
     const char **q;
@@ -216,8 +217,22 @@ static void run_encoder(vox_stream_t *s) {
          * whatever is left (< 8 frames) and every later chunk runs on the stream's own engine as usual */
         int mt = 0;
         const int used = vox_multi_encode_first_chunk(s->ctx, new_mel, &mt);
-        if (used < 0) { fprintf(stderr, "vox_stream: sharded encoder failed: %s\n", vox_hip_last_error()); return; }
+        if (used < 0) {
+            /* By now the mel queue of the stream engine may be half consumed and adapter rows are accounted for that
+             * were never written: there is nothing consistent left to retry on (the device mel queue is the only copy
+             * of the frames).  Fail the stream for good - every later feed / flush / finish returns -1, like the
+             * reference's error convention (voxtral.c:1237) - and stop sharding for the streams that follow. */
+            fprintf(stderr, "vox_stream: sharded encoder failed (%s); this stream is dead, later streams of this model run on one GPU\n",
+                    vox_hip_last_error());
+            s->failed = 1;
+            s->ctx->n_shard_engines = 1;
+            return;
+        }
         if (used > 0) {
+            /* the shards were only enqueued: wait for the stream engine (every other engine's last work is chained into
+             * its stream) so that the encoder time printed at the end - and parsed by benchmark.py - is the real one */
+            vox_hip_sync(s->eng);
+            vox_hip_add_encode_ms(s->eng, now_ms() - t0);
             s->mel_cursor += used;
             s->stem_started = 1;
             vox_enc_mirror_chunk(s->ctx, used / 2);
@@ -389,10 +404,11 @@ vox_stream_t *vox_stream_init(vox_ctx_t *ctx) {
 }
 
 int vox_stream_feed(vox_stream_t *s, const float *samples, int n_samples) {
-    if (!s || s->finished || n_samples <= 0) return -1;
+    if (!s || s->finished || s->failed || n_samples <= 0) return -1;
     vox_mel_feed(s->mel, samples, n_samples);
     s->samples_fed += n_samples;
     run_encoder(s);
+    if (s->failed) return -1;
     run_decoder(s);
     return 0;
 }
@@ -410,18 +426,18 @@ static void feed_right_padding(vox_stream_t *s) {
 }
 
 int vox_stream_flush(vox_stream_t *s) {
-    if (!s || s->finished) return -1;
+    if (!s || s->finished || s->failed) return -1;
     feed_right_padding(s);
     const int saved = s->min_new_mel;
     s->min_new_mel = 1;
     run_encoder(s);
-    run_decoder(s);
+    if (!s->failed) run_decoder(s);
     s->min_new_mel = saved;
-    return 0;
+    return s->failed ? -1 : 0;
 }
 
 int vox_stream_finish(vox_stream_t *s) {
-    if (!s || s->finished) return -1;
+    if (!s || s->finished || s->failed) return -1;
     /* The reference flushes (padding -> encoder -> decoder) and then finishes the mel (-> encoder on the last frame -> decoder)
      * (voxtral.c:1608-1625).  Encoder and decoder outputs do not depend on how the frames are cut into chunks, so outside
      * continuous mode - whose watchdogs look at the state after every decoder run - the padding and the mel tail go through
@@ -434,6 +450,7 @@ int vox_stream_finish(vox_stream_t *s) {
         fprintf(stderr, "Stream finished: %lld real samples (%.1f sec)\n", (long long)s->samples_fed,
                 (double)s->samples_fed / VOX_SAMPLE_RATE);
     run_encoder(s);
+    if (s->failed) return -1;
     run_decoder(s);
     return 0;
 }

@@ -78,28 +78,50 @@ def mel_span(pos0, pos1):
 # engine adapters
 # ---------------------------------------------------------------------------------------
 class HipShardEngine:
-    """vox_hip_shard_* on one GPU (device buffers are raw pointers owned by the engine)."""
+    """vox_hip_shard_* on one GPU (device buffers are raw pointers owned by the engine).
 
-    def __init__(self, model):
+    stream_ordered=True (RCCL): only the *_async entry points are used - every call enqueues on the engine's HIP
+    stream and returns; the communicator issues its sends / receives on that same stream (TorchComm.stream), so the
+    wavefront needs no host wait between begin() and end().  stream_ordered=False (host-staged transports: gloo on a
+    shared GPU in the tests): the synchronous variants."""
+
+    def __init__(self, model, stream_ordered=False):
         import voxtral_c_amd as v
         self.v, self.m, self.e = v, model, model.engine
+        self.stream_ordered = stream_ordered
         h = v.hip
         h.vox_hip_shard_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         h.vox_hip_shard_layer.argtypes = [C.c_void_p, C.c_int]
-        h.vox_hip_shard_kv_export.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        h.vox_hip_shard_kv_import.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        for fn in (h.vox_hip_shard_kv_export, h.vox_hip_shard_kv_export_async, h.vox_hip_shard_kv_import):
+            fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         h.vox_hip_shard_end.argtypes = [C.c_void_p, C.c_void_p]
+        h.vox_hip_shard_end_async.argtypes = [C.c_void_p, C.c_void_p]
         h.vox_hip_adapter_append_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        h.vox_hip_adapter_append_dev_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         h.vox_hip_reset_decoder_kv.argtypes = [C.c_void_p]
+        h.vox_hip_reset_encoder_async.argtypes = [C.c_void_p]
+        h.vox_hip_host_syncs.restype = C.c_ulonglong
+        h.vox_hip_host_syncs.argtypes = [C.c_void_p]
         self.d = model.dims
         self.kv_dim = self.d.enc_heads * self.d.enc_head_dim
         self.n_layers = self.d.enc_layers
         self.window = self.d.enc_window
         self.dec_dim = self.d.dec_dim
+        self.wavefront_syncs = 0          # host waits on the engine stream between begin() and end(), summed over shards
+        self._syncs0 = 0
+
+    def host_syncs(self):
+        return int(self.v.hip.vox_hip_host_syncs(self.e))
 
     def reset(self):
-        self.v.hip.vox_hip_reset_encoder(self.e)
+        if self.stream_ordered:
+            self.v.hip.vox_hip_reset_encoder_async(self.e)
+        else:
+            self.v.hip.vox_hip_reset_encoder(self.e)
         self.v.hip.vox_hip_reset_decoder(self.e)
+
+    def reset_encoder(self):
+        (self.v.hip.vox_hip_reset_encoder_async if self.stream_ordered else self.v.hip.vox_hip_reset_encoder)(self.e)
 
     def queue_mel(self, padded, frame0, n_frames):
         seg = np.ascontiguousarray(padded[frame0 * 160:(frame0 + n_frames - 1) * 160 + 400], np.float32)
@@ -109,19 +131,25 @@ class HipShardEngine:
     def begin(self, n_mel, discard, pos0):
         n = self.v.hip.vox_hip_shard_begin(self.e, n_mel, discard, pos0)
         assert n > 0, self.v.hip.vox_hip_last_error()
+        self._syncs0 = self.host_syncs()
         return n
 
     def layer(self, l):
         assert self.v.hip.vox_hip_shard_layer(self.e, l) == 0
 
     def kv_export(self, l, pos_first, n, dev_ptr):
-        assert self.v.hip.vox_hip_shard_kv_export(self.e, l, pos_first, n, dev_ptr) == 0
+        fn = self.v.hip.vox_hip_shard_kv_export_async if self.stream_ordered else self.v.hip.vox_hip_shard_kv_export
+        assert fn(self.e, l, pos_first, n, dev_ptr) == 0
 
     def kv_import(self, l, pos_first, n, dev_ptr):
         assert self.v.hip.vox_hip_shard_kv_import(self.e, l, pos_first, n, dev_ptr) == 0
 
     def end(self, dev_ptr):
-        m = self.v.hip.vox_hip_shard_end(self.e, dev_ptr)
+        if self.stream_ordered:
+            m = self.v.hip.vox_hip_shard_end_async(self.e, dev_ptr)
+            self.wavefront_syncs += self.host_syncs() - self._syncs0
+        else:
+            m = self.v.hip.vox_hip_shard_end(self.e, dev_ptr)
         assert m >= 0, self.v.hip.vox_hip_last_error()
         return m
 
@@ -131,27 +159,60 @@ class HipShardEngine:
 
 class TorchComm:
     """torch.distributed plumbing. Tensors live on the GPU for RCCL ("nccl") and on the host
-    for gloo (used to exercise the 2-rank path on a single GPU / on CPU)."""
+    for gloo (used to exercise the 2-rank path on a single GPU / on CPU).
 
-    def __init__(self, device=None):
+    RCCL: `stream` is the engine's own HIP stream wrapped as a torch ExternalStream.  ProcessGroupNCCL orders every
+    operation behind the CURRENT stream's tail when it is issued and makes the current stream wait for its completion
+    on wait() - both are stream waits, not host waits - so with the engine stream current, a send sits behind the
+    kernels that produced its buffer and the engine's next kernels sit behind a receive, with the host only enqueueing
+    (ordered() is the context manager that makes the engine stream current)."""
+
+    def __init__(self, device=None, engine_stream=None):
+        import contextlib
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.on_gpu = dist.get_backend() == "nccl"
         self.device = device if self.on_gpu else "cpu"
+        self.stream = None
+        if self.on_gpu and engine_stream:
+            self.stream = torch.cuda.ExternalStream(int(engine_stream), device=torch.device(device))
+        self._null = contextlib.nullcontext
+        self.host_waits = 0               # blocking waits issued by this communicator (gloo: every operation)
+
+    def ordered(self):
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else self._null()
 
     def empty(self, shape):
         return self.torch.empty(shape, dtype=self.torch.float32, device=self.device)
 
-    def send(self, t, dst):
-        self.dist.send(t, dst)
+    def isend(self, t, dst):
+        return self.dist.isend(t, dst)
 
     def recv(self, t, src):
-        self.dist.recv(t, src)
+        """RCCL: enqueued; the current (engine) stream waits for the data.  gloo: blocks until it has arrived."""
+        w = self.dist.irecv(t, src)
+        self.wait(w)
+
+    def wait(self, work):
+        if work is None:
+            return
+        if not self.on_gpu:
+            self.host_waits += 1
+        work.wait()                        # nccl: the current stream waits (no host block); gloo: host block
+
+    def loopback(self, t_out, t_in):
+        """Send t_out to ourselves into t_in (one grouped RCCL send + recv): exercises the stream-ordered point-to-point
+        path with the only peer a 1-GPU box has."""
+        ops = [self.dist.P2POp(self.dist.isend, t_out, self.rank), self.dist.P2POp(self.dist.irecv, t_in, self.rank)]
+        for w in self.dist.batch_isend_irecv(ops):
+            self.wait(w)
 
     def gather_rows(self, t, counts, dst=0):
         """Variable-length gather of [m_r, D] row blocks to rank `dst` (padded to the max count)."""
+        if self.world == 1:
+            return t
         mx = max(counts)
         pad = self.empty((mx, t.shape[1]))
         pad[:t.shape[0]] = t
@@ -171,9 +232,9 @@ class TorchComm:
 
 class Staging:
     """A buffer the engine writes/reads (by pointer) and the communicator sends/receives (as a
-    torch tensor).  RCCL: one GPU tensor, pointer = data_ptr.  gloo next to the HIP engine: a
-    host tensor mirrored by a device buffer (copied around each transfer).  CPU oracle engine:
-    the tensor itself."""
+    torch tensor).  RCCL: one GPU tensor, pointer = data_ptr, no hooks (everything is stream-ordered).  gloo next to
+    the HIP engine: a host tensor mirrored by a device buffer (copied - synchronously - around each transfer).  CPU
+    oracle engine: the tensor itself."""
 
     def __init__(self, tensor, ptr=None, to_host=None, to_dev=None):
         self.tensor, self._ptr, self._to_host, self._to_dev = tensor, ptr, to_host, to_dev
@@ -190,9 +251,15 @@ class Staging:
             self._to_dev()
 
 
-def encode_sharded(eng, comm, padded, n_frames, staging, dst=0):
+def encode_sharded(eng, comm, padded, n_frames, staging, dst=0, self_loop=False, on_encoded=None):
     """Wavefront context-parallel encode. `staging(shape)` returns a Staging buffer.
-    Returns (gathered adapter rows on rank `dst` | None, per-rank row counts)."""
+    Returns (gathered adapter rows on rank `dst` | None, per-rank row counts).
+
+    This function never waits on the host itself: with a stream-ordered engine + RCCL every call below only enqueues
+    (tests assert vox_hip_host_syncs does not move between begin() and end()); host-staged transports block inside
+    their own recv / wait / Staging hooks.  Buffers alternate by layer parity: a receive buffer is overwritten two
+    layers later, behind the import copies that read it (same stream); a send buffer is rewritten only after wait()
+    on the send that read it."""
     rank, world = comm.rank, comm.world
     plan = shard_plan(n_frames, world)
     pos0, pos1 = plan[rank]
@@ -200,143 +267,67 @@ def encode_sharded(eng, comm, padded, n_frames, staging, dst=0):
     eng.queue_mel(padded, f0, f1 - f0)
     n = eng.begin(f1 - f0, discard, pos0)
     assert n == pos1 - pos0, (n, pos0, pos1)
-    tail = min(eng.window - 1, pos0)                       # positions we need from the left
+    tail = min(eng.window - 1, pos0) if rank > 0 else 0     # positions we need from the left
     send_tail = min(eng.window - 1, pos1) if rank + 1 < world else 0
-    # Two receive buffers, alternating by layer: kv_import only ENQUEUES its copies on the engine stream, so the buffer of
-    # layer l - 1 may still be read while layer l's tail arrives.  A buffer is reused two layers later; by then the engine
-    # stream has been synchronised by kv_export - except on a rank that never exports (the last one), which syncs itself.
-    s_ins = [staging((2, max(tail, 1), eng.kv_dim)) for _ in range(2)]
-    s_out = staging((2, max(send_tail, 1), eng.kv_dim))
+    loop_tail = min(eng.window - 1, pos1) if (self_loop and world == 1) else 0
+    s_ins = [staging((2, max(tail, loop_tail, 1), eng.kv_dim)) for _ in range(2)]
+    s_outs = [staging((2, max(send_tail, loop_tail, 1), eng.kv_dim)) for _ in range(2)]
+    sends = [None, None]
     for l in range(eng.n_layers):
-        if rank > 0 and tail > 0:
+        if tail > 0:
             s_in = s_ins[l & 1]
-            if send_tail == 0 and l >= 2:
-                eng.sync()
             comm.recv(s_in.tensor, rank - 1)
-            comm.sync()
             s_in.before_engine_read()
             eng.kv_import(l, pos0 - tail, tail, s_in.ptr())
         eng.layer(l)
         if send_tail > 0:
-            comm.sync()            # the previous layer's send has left the staging buffer
-            eng.kv_export(l, pos1 - send_tail, send_tail, s_out.ptr())    # synchronises the engine stream
+            s_out = s_outs[l & 1]
+            comm.wait(sends[l & 1])            # the send of layer l - 2 has read this buffer
+            eng.kv_export(l, pos1 - send_tail, send_tail, s_out.ptr())
             s_out.after_engine_write()
-            comm.send(s_out.tensor, rank + 1)
+            sends[l & 1] = comm.isend(s_out.tensor, rank + 1)
+        if loop_tail > 0:                      # 1-GPU smoke of the RCCL point-to-point path: export, send to self, import
+            eng.kv_export(l, pos1 - loop_tail, loop_tail, s_outs[l & 1].ptr())
+            comm.loopback(s_outs[l & 1].tensor, s_ins[l & 1].tensor)
+            eng.kv_import(l, pos1 - loop_tail, loop_tail, s_ins[l & 1].ptr())
+    for w in sends:
+        comm.wait(w)
     s_ad = staging(((pos1 - pos0) // 4, eng.dec_dim))
     m = eng.end(s_ad.ptr())
     s_ad.after_engine_write()
     assert m == (pos1 - pos0) // 4
     counts = [(b - a) // 4 for a, b in plan]
+    if on_encoded:
+        on_encoded()
     return comm.gather_rows(s_ad.tensor, counts, dst), counts
 
 
 # ---------------------------------------------------------------------------------------
-# bench driver for N > 1 (called by bench.py)
+# one rank's view of a multi-GPU transcription (bench.py, tests)
 # ---------------------------------------------------------------------------------------
-def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
-    import torch
-    import torch.distributed as dist
-    import voxtral_c_amd as v
-    from audio_util import synth_speech
-
-    backend = os.environ.get("VOX_DIST_BACKEND", "nccl")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # one node, no fabric: keep RCCL's bootstrap off interface / InfiniBand probing (seen to stall
-    # communicator creation for ~2 minutes on boxes without a network)
-    os.environ.setdefault("NCCL_IB_DISABLE", "1")
-    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-    share = os.environ.get("VOX_SHARE_GPU") == "1"          # several ranks on one GPU (gloo only; tests)
-    dev = 0 if share else local_rank
-    torch.cuda.set_device(dev)
-    if backend == "nccl":
-        dist.init_process_group(backend=backend, device_id=torch.device(f"cuda:{dev}"))
-    else:
-        dist.init_process_group(backend=backend)
-    comm = TorchComm(device=f"cuda:{dev}")
-    win = {} if args.preset != "tiny" else dict(enc_window=48, dec_window=64)
-    model = v.Model(mdir, device=dev, **win)
-    session = DistributedSession(model, comm)
-    # one clip per GPU ("owner"); every clip's encoder is sharded over all GPUs, every GPU decodes
-    # its own clip (VOX_DIST_MODE=single: one long clip, decoder on rank 0 only — BASELINE config 4)
-    single = os.environ.get("VOX_DIST_MODE") == "single"
-    if single:
-        audio = synth_speech(args.seconds * world, 1234)
-    else:
-        audios = [synth_speech(args.seconds, 1234 + r) for r in range(world)]
-
-    def one_pass():
-        toks = session.transcribe(audio) if single else session.transcribe_many(audios)
-        comm.barrier()
-        return toks
-
-    for _ in range(args.warmup):
-        one_pass()
-    comm.barrier(); torch.cuda.synchronize()
-    t0 = time.time()
-    toks = None
-    for _ in range(args.steps):
-        toks = one_pass()
-    comm.barrier(); torch.cuda.synchronize()
-    wall = time.time() - t0
-    dev_t = comm.device if comm.on_gpu else "cpu"
-    tmax = torch.tensor([wall], dtype=torch.float64, device=dev_t)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall = float(tmax.item())
-    t = model.timing()                       # of the last pass on this rank
-    agg = torch.tensor([float(t["decode_steps"]), float(len(toks)) if toks is not None else 0.0], dtype=torch.float64, device=dev_t)
-    dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-    dmax = torch.tensor([float(t["decode_ms"])], dtype=torch.float64, device=dev_t)
-    dist.all_reduce(dmax, op=dist.ReduceOp.MAX)
-    if rank == 0:
-        audio_s = args.seconds * world
-        dec_ms = float(dmax.item())
-        out = {
-            "metric": "real-time-factor + decode tokens/sec, Voxtral-4B bf16, 30s audio",
-            "value": round(wall / args.steps / audio_s, 5), "unit": "wall s / audio s (RTF)", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 2),
-            "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 weights, f32 activations/accumulate", "data": "synthetic",
-            "decode_tok_s": round(float(agg[0].item()) / (dec_ms * 1e-3), 1) if dec_ms > 0 else 0.0,
-            "decode_tok_s_per_stream": round(t["decode_steps"] / (t["decode_ms"] * 1e-3), 1) if t["decode_ms"] > 0 else 0.0,
-            "decoder_steps_per_pass": int(agg[1].item()),
-            "config": {"workload": (f"Voxtral-4B ({args.preset} synthetic checkpoint), one {audio_s:g} s clip: encoder positions sharded over "
-                                    f"{world} GPUs (wavefront K/V halo over xGMI), adapter rows gathered to rank 0, single-stream greedy "
-                                    "decode on rank 0") if single else
-                                   (f"Voxtral-4B ({args.preset} synthetic checkpoint), {world} clips of {args.seconds:g} s (one per GPU): each clip's "
-                                    f"encoder positions are sharded over all {world} GPUs (wavefront K/V halo over xGMI, RCCL gather of the "
-                                    "adapter rows to the clip's GPU), then every GPU runs the single-stream greedy decoder of its own clip"),
-                       "audio_seconds": audio_s, "parallelism": f"cp{world} encoder / " + ("1 decoder" if single else f"{world} decoders"),
-                       "backend": backend},
-        }
-        try:        # same live roofline measurement as the 1-GPU line (rank 0's engine)
-            from bench import roofline_block
-            out["roofline"] = roofline_block(v, model, model.dims, float(len(toks)) if toks is not None else 380.0)
-        except Exception as ex:
-            out["roofline"] = {"error": str(ex)}
-        print(json.dumps(out), flush=True)
-    model.close()
-    dist.destroy_process_group()
-
-
 class DistributedSession:
-    """One rank's view of a multi-GPU transcription (used by bench.py and the tests)."""
-
     def __init__(self, model, comm):
         import voxtral_c_amd as v
         self.v, self.model, self.comm = v, model, comm
-        self.eng = HipShardEngine(model)
+        self.eng = HipShardEngine(model, stream_ordered=comm.on_gpu)
         h = v.hip
         h.vox_hip_device_alloc.restype = C.c_void_p
         h.vox_hip_device_alloc.argtypes = [C.c_void_p, C.c_size_t]
         h.vox_hip_device_free.argtypes = [C.c_void_p, C.c_void_p]
         h.vox_hip_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self._dev_bufs = []
+        self._keep = []                    # RCCL staging tensors of the pass in flight (freed after the pass's final sync)
+        self.self_loop = os.environ.get("VOX_DIST_SELF_LOOP") == "1"
+        self.phase_ms = {}                 # of the last pass: encode (mel + wavefront), gather, prefill, decode
+        self._events = []
 
+    # ---- staging buffers ---------------------------------------------------------------------------------------
     def staging(self, shape):
         comm, h, eng = self.comm, self.v.hip, self.model.engine
         t = comm.empty(shape)
         if comm.on_gpu:
-            return Staging(t, C.c_void_p(t.data_ptr()), to_host=comm.sync, to_dev=None)
+            self._keep.append(t)
+            return Staging(t, C.c_void_p(t.data_ptr()))
         nbytes = t.numel() * 4
         dev = h.vox_hip_device_alloc(eng, nbytes)
         self._dev_bufs.append(dev)
@@ -349,33 +340,72 @@ class DistributedSession:
         for d in self._dev_bufs:
             self.v.hip.vox_hip_device_free(self.model.engine, C.c_void_p(d))
         self._dev_bufs = []
+        self._keep = []
 
+    # ---- phase timing: events on the engine stream (RCCL) / host clock (host-staged transports) -------------------
+    def _mark(self, name):
+        if self.comm.on_gpu and self.comm.stream is not None:
+            ev = self.comm.torch.cuda.Event(enable_timing=True)
+            ev.record(self.comm.stream)
+            self._events.append((name, ev))
+        else:
+            self._events.append((name, time.time()))
+
+    def _phases_done(self):
+        acc = {}
+        for (n0, e0), (n1, e1) in zip(self._events, self._events[1:]):
+            if n1 == "start":
+                continue
+            dt = e0.elapsed_time(e1) if self.comm.on_gpu and self.comm.stream is not None else (e1 - e0) * 1e3
+            acc[n1] = acc.get(n1, 0.0) + dt
+        self._events = []
+        return acc
+
+    # ---- transcription ------------------------------------------------------------------------------------------------
     def transcribe_many(self, audios, delay_tokens=6):
         """One clip per rank ("owner").  Every clip's encoder is sharded over ALL ranks (wavefront K/V
         halo, adapter rows gathered to the clip's owner); afterwards every rank decodes its own
         clip, so the strictly sequential decoders of the N streams run side by side.  Returns
-        this rank's token ids."""
+        this rank's token ids.  With RCCL the N wavefronts are enqueued back to back (rank 0 starts clip c + 1 while
+        the later ranks still work on clip c)."""
         assert len(audios) == self.comm.world
         rows_mine = None
-        for owner, audio in enumerate(audios):
-            padded, n_frames = padded_stream(audio, delay_tokens)
-            self.eng.reset()
-            rows, _ = encode_sharded(self.eng, self.comm, padded, n_frames, self.staging, dst=owner)
-            if self.comm.on_gpu and rows is not None:
-                rows = rows.clone()              # outlives the staging buffers of the later clips
-            self._free_staging()
-            if owner == self.comm.rank:
-                rows_mine = rows
+        self.eng.wavefront_syncs = 0
         self.eng.reset()
-        return self._decode_rows(rows_mine, delay_tokens)
+        with self.comm.ordered():
+            for owner, audio in enumerate(audios):
+                padded, n_frames = padded_stream(audio, delay_tokens)
+                self.eng.reset_encoder()
+                self._mark("start")
+                rows, _ = encode_sharded(self.eng, self.comm, padded, n_frames, self.staging, dst=owner, self_loop=self.self_loop,
+                                         on_encoded=lambda: self._mark("encode"))
+                if owner == self.comm.rank:
+                    rows_mine = rows
+                self._mark("gather")
+            toks = self._decode_rows(rows_mine, delay_tokens)
+        self._finish_pass()
+        return toks
 
     def transcribe(self, audio, delay_tokens=6):
         """Sharded encode on all ranks, greedy decode on rank 0. Returns token ids on rank 0."""
         padded, n_frames = padded_stream(audio, delay_tokens)
+        self.eng.wavefront_syncs = 0
         self.eng.reset()
-        rows, counts = encode_sharded(self.eng, self.comm, padded, n_frames, self.staging)
+        with self.comm.ordered():
+            self._mark("start")
+            rows, counts = encode_sharded(self.eng, self.comm, padded, n_frames, self.staging, self_loop=self.self_loop,
+                                          on_encoded=lambda: self._mark("encode"))
+            self._mark("gather")
+            toks = self._decode_rows(rows, delay_tokens) if self.comm.rank == 0 else None
+        self._finish_pass()
+        return toks
+
+    def _finish_pass(self):
+        self.eng.sync()
+        self.comm.sync()
+        ph = self._phases_done()
+        self.phase_ms = {"encode": ph.get("encode", 0.0), "gather": ph.get("gather", 0.0)}
         self._free_staging()
-        return self._decode_rows(rows, delay_tokens) if self.comm.rank == 0 else None
 
     def _decode_rows(self, rows, delay_tokens):
         v, h, comm, model = self.v, self.v.hip, self.comm, self.model
@@ -384,8 +414,8 @@ class DistributedSession:
         if rows is not None:
             total = int(rows.shape[0])
             if comm.on_gpu:
-                comm.sync()
-                h.vox_hip_adapter_append_dev(model.engine, C.c_void_p(rows.data_ptr()), total)
+                self._keep.append(rows)
+                assert h.vox_hip_adapter_append_dev_async(model.engine, C.c_void_p(rows.data_ptr()), total) == 0
             else:
                 arr = np.ascontiguousarray(rows.numpy())
                 h.vox_hip_adapter_append(model.engine, arr.ctypes.data_as(v.f32p), total)
@@ -398,3 +428,140 @@ class DistributedSession:
                 got = h.vox_hip_decoder_run(model.engine, prompt_len, n_steps, first, 2, out.ctypes.data_as(v.i32p), None)
             toks = np.concatenate([[first], out[:got]]).astype(np.int32)
         return toks
+
+
+# ---------------------------------------------------------------------------------------
+# bench driver for N > 1 (called by bench.py)
+# ---------------------------------------------------------------------------------------
+def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
+    """`python bench.py --gpus N` (one rank per GPU, RCCL).  Weak scaling: N clips of `seconds` s, one per GPU.
+
+    Two ways of running the same job are timed in the same process, K steps each, barrier + device synchronisation
+    on both sides, MAX over ranks:
+      sharded  (the north star's path, = `value`): every clip's encoder positions are split over all N GPUs (exact
+               context parallelism: per-layer K/V halo to the right neighbour over xGMI, RCCL gather of the adapter
+               rows to the clip's GPU), then every GPU runs the strictly sequential decoder of its own clip;
+      replica  (`replica` in the JSON): every GPU transcribes its own clip alone through the ordinary voxtral.h stream
+               API - no communication.  The decoder is 95 % of a transcription and does not shard, and an
+               N-way shard of a 30 s encoder (212 rows at N = 8) is launch-bound, so the replica figure is expected to
+               be the better one; both are reported so that the driver's scaling curve can be read.
+    Every rank's clip is the golden 30 s night1968 input, and both passes' token ids are compared with the reference's
+    (`parity`)."""
+    import torch
+    import torch.distributed as dist
+    import voxtral_c_amd as v
+    from bench import headline_audio, parity_block
+
+    share = os.environ.get("VOX_SHARE_GPU") == "1"          # several ranks on one GPU (tests): RCCL refuses that, so gloo
+    backend = os.environ.get("VOX_DIST_BACKEND", "gloo" if share else "nccl")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # one node, no fabric: keep RCCL's bootstrap off interface / InfiniBand probing (seen to stall
+    # communicator creation for ~2 minutes on boxes without a network)
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    dev = 0 if share else local_rank
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group(backend=backend, device_id=torch.device(f"cuda:{dev}"))
+    else:
+        dist.init_process_group(backend=backend)
+    win = {} if args.preset != "tiny" else dict(enc_window=48, dec_window=64)
+    model = v.Model(mdir, device=dev, **win)
+    v.hip.vox_hip_stream_handle.restype = C.c_void_p
+    v.hip.vox_hip_stream_handle.argtypes = [C.c_void_p]
+    comm = TorchComm(device=f"cuda:{dev}", engine_stream=v.hip.vox_hip_stream_handle(model.engine))
+    session = DistributedSession(model, comm)
+    audio, golden, audio_desc = headline_audio(args.seconds)
+    if args.preset != "full":
+        golden = None
+    # VOX_DIST_MODE=single: one clip of N x seconds, decoder on rank 0 only (BASELINE config 4)
+    single = os.environ.get("VOX_DIST_MODE") == "single"
+    if single:
+        audio_all, _, _ = headline_audio(args.seconds * world)
+    dev_t = comm.device if comm.on_gpu else "cpu"
+
+    def allmax(x):
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev_t)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def allsum(x):
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev_t)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def timed(fn):
+        for _ in range(args.warmup):
+            fn()
+        comm.barrier(); torch.cuda.synchronize()
+        v.hip.vox_hip_reset_timing(model.engine)
+        t0 = time.time()
+        r = None
+        for _ in range(args.steps):
+            r = fn()
+            comm.barrier()
+        torch.cuda.synchronize()
+        return allmax(time.time() - t0), r, model.timing()
+
+    # ---- sharded pass ---------------------------------------------------------------------------------------------
+    wall, toks, t = timed((lambda: session.transcribe(audio_all)) if single else (lambda: session.transcribe_many([audio] * world)))
+    phase = {k: allmax(val) for k, val in sorted(session.phase_ms.items())}
+    phase["prefill"] = allmax(t["prefill_ms"] / max(args.steps, 1))
+    phase["decode"] = allmax(t["decode_ms"] / max(args.steps, 1))
+    dec_steps, dec_ms = allsum(t["decode_steps"]), allmax(t["decode_ms"])
+    par = parity_block(toks, golden) if (toks is not None and not single) else {"checked": False, "reason": "no golden for this length / preset"}
+    mism = allsum(par.get("mismatches", 0) if par.get("checked") else 0)
+    checked = allsum(1 if par.get("checked") else 0)
+    wf_syncs = allmax(session.eng.wavefront_syncs)
+    n_tok = allsum(len(toks) if toks is not None else 0)
+
+    # ---- replica pass: every GPU alone on its own clip, ordinary stream API -------------------------------------------
+    rep = None
+    if not single:
+        rwall, rres, rt = timed(lambda: model.transcribe(audio))
+        rpar = parity_block(rres["tokens"], golden)
+        rep = {"value": round(rwall / args.steps / (args.seconds * world), 5), "ms_per_step": round(rwall * 1e3 / args.steps, 2),
+               "decode_tok_s": round(allsum(rt["decode_steps"]) / (allmax(rt["decode_ms"]) * 1e-3), 1) if rt["decode_ms"] > 0 else 0.0,
+               "encode_ms": round(allmax(rt["encode_ms"] / max(args.steps, 1)), 2),
+               "parity_mismatches_all_ranks": int(allsum(rpar.get("mismatches", 0) if rpar.get("checked") else 0)),
+               "parity_checked_ranks": int(allsum(1 if rpar.get("checked") else 0)),
+               "what": "every GPU transcribes its own clip alone (vox_stream_feed + finish), no communication"}
+
+    if rank == 0:
+        audio_s = args.seconds * world
+        out = {
+            "metric": "real-time-factor + decode tokens/sec, Voxtral-4B bf16, 30s audio",
+            "value": round(wall / args.steps / audio_s, 5), "unit": "wall s / audio s (RTF)", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 2),
+            "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 weights, f32 activations/accumulate", "data": "synthetic",
+            "data_note": "weights: seeded synthetic checkpoint of the exact architecture; audio (every rank): " + audio_desc,
+            "decode_tok_s": round(dec_steps / (dec_ms * 1e-3), 1) if dec_ms > 0 else 0.0,
+            "decode_tok_s_per_stream": round(t["decode_steps"] / (t["decode_ms"] * 1e-3), 1) if t["decode_ms"] > 0 else 0.0,
+            "decoder_steps_per_pass": int(n_tok),
+            "phases_ms": {k: round(val, 2) for k, val in phase.items()},
+            "parity": dict(par, mismatches_all_ranks=int(mism), checked_ranks=int(checked)),
+            "replica": rep,
+            "rccl_ranks": world, "backend": backend,
+            "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None,
+            "host_syncs_in_wavefront": int(wf_syncs),
+            "config": {"workload": (f"Voxtral-4B ({args.preset} synthetic checkpoint), one {audio_s:g} s clip: encoder positions sharded over "
+                                    f"{world} GPUs (wavefront K/V halo over xGMI), adapter rows gathered to rank 0, single-stream greedy "
+                                    "decode on rank 0") if single else
+                                   (f"Voxtral-4B ({args.preset} synthetic checkpoint), {world} clips of {args.seconds:g} s (one per GPU): each clip's "
+                                    f"encoder positions are sharded over all {world} GPUs (wavefront K/V halo over xGMI, RCCL gather of the "
+                                    "adapter rows to the clip's GPU), then every GPU runs the single-stream greedy decoder of its own clip"),
+                       "audio_seconds": audio_s,
+                       "parallelism": f"cp{world} encoder (N-way shards of a 30 s encoder are launch-bound: expected slower per clip than the "
+                                      f"replica figure reported beside it) / " + ("1 decoder" if single else f"{world} decoders (replicas)"),
+                       "backend": backend},
+        }
+        try:        # same live roofline measurement as the 1-GPU line (rank 0's engine)
+            from bench import roofline_block
+            out["roofline"] = roofline_block(v, model, model.dims, n_tok / world if n_tok else 380.0, pmc=False)
+        except Exception as ex:
+            out["roofline"] = {"error": str(ex)}
+        print(json.dumps(out), flush=True)
+    comm.barrier()
+    model.close()
+    dist.destroy_process_group()

@@ -359,6 +359,14 @@ def main():
     if v.device_count() < 1:
         raise SystemExit("bench.py: no HIP device (the engine has no CPU fallback)")
     mdir = model_dir(args.preset)
+    # A real Voxtral-Realtime-4B checkpoint directory (consolidated.safetensors + tekken.json), when one exists: the same
+    # benchmark on the real weights ("data": "real").  The golden fixture was generated on the synthetic checkpoint, so
+    # the parity block is then unchecked; tests/test_gpu_cli.py holds the text-level acceptance test for real weights.
+    real_model = os.environ.get("VOX_REAL_MODEL", "")
+    if real_model and args.preset == "full":
+        if not os.path.exists(os.path.join(real_model, "consolidated.safetensors")):
+            raise SystemExit(f"bench.py: VOX_REAL_MODEL={real_model} has no consolidated.safetensors")
+        mdir = real_model
 
     if world > 1 or os.environ.get("VOX_FORCE_DIST") == "1":
         from voxtral_c_amd.multi_gpu import run_distributed_bench
@@ -380,7 +388,7 @@ def main():
     load_s = time.time() - t0
     dims = model.dims            # geometry as read from the checkpoint by vox_load
     audio, golden, audio_desc = headline_audio(args.seconds)
-    if args.preset != "full" or args.weights != "bf16":
+    if args.preset != "full" or args.weights != "bf16" or mdir == real_model:
         golden = None
 
     if args.mode == "stream":
@@ -418,8 +426,9 @@ def main():
         "value": round(rtf, 5), "unit": "wall s / audio s (RTF)", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16 weights, f32 activations/accumulate (fp32 FMA GEMV, f32 MFMA GEMM)",
-        "data": "synthetic",
-        "data_note": "weights: seeded synthetic checkpoint of the exact architecture (no real weights offline); audio: " + audio_desc,
+        "data": "real" if mdir == real_model else "synthetic",
+        "data_note": ("weights: real checkpoint " + real_model if mdir == real_model else
+                      "weights: seeded synthetic checkpoint of the exact architecture (no real weights offline)") + "; audio: " + audio_desc,
         "parity": parity, "active_paths": path_names,
         "decode_tok_s": round(decode_tok_s, 1), "decode_ms_per_token": round(dec_ms / max(dec_steps, 1), 4),
         "encode_ms": round(enc_ms / args.steps, 2), "prefill_ms": round(pre_ms / args.steps, 2),

@@ -236,7 +236,11 @@ def golden_audio(g):
     """The case's input: stored in the fixture for the reference's own sample clips (SURVEY 8(d):
     night1968 / jfk.wav - /root/reference does not exist on the GPU box), regenerated for synthetic ones."""
     if "audio_i16" in g.files:
-        return g["audio_i16"].astype(np.float32) / 32768.0
+        a = g["audio_i16"].astype(np.float32) / 32768.0
+        if "audio_total_samples" in g.files:            # the stored clip tiled to the case's length (tools/make_golden.py LONG_CASES)
+            n = int(g["audio_total_samples"])
+            a = np.tile(a, -(-n // len(a)))[:n].copy()
+        return a
     meta = g["meta"]
     return synth_speech(float(meta[1]), int(meta[2]))
 
@@ -399,6 +403,88 @@ def test_stream_full_size_streaming_feeds_match_reference_golden(vox):
         res = check_stream("full_stream", g, run_case(m, g, 8000, 0.5, True))
     assert res["ok"], res
     assert res["ref_steps"] >= 250 and res["n_distinct_ref"] > 90, res
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "stream_full_continuous.npz")), reason="fixture not generated")
+def test_stream_full_size_continuous_restart_matches_reference_golden(vox):
+    """BASELINE config 3 THROUGH A RESTART at the real 4B geometry: the 30 s night1968 clip tiled to 176 s, 0.5 s feeds,
+    -I 0.5, continuous mode.  After ~160 s the decoder's physical KV length passes 2000 and the reference resets the whole
+    stream - new mel context with fresh left padding, encoder KV and conv state cleared, new prompt (voxtral.c:378,
+    1137-1187) - and carries on.  Every step before and after the reset is compared with the reference's own run."""
+    g = gold("stream_full_continuous.npz")
+    with vox.Model(model_dir("full")) as m:
+        res = check_stream("full_continuous", g, run_case(m, g, 8000, 0.5, True))
+    assert res["ok"], res
+    assert res["ref_steps"] > 2050, res          # i.e. the run did cross kv_cache_len > 2000 and decoded on after it
+
+
+def test_in_library_eight_shards_at_full_geometry_match_reference_golden(vox):
+    """BASELINE config 4's encoder split at the real width: VOX_DEVICES = eight engines (all on this box's one GPU), the
+    30 s golden clip -> shards of 212 rows (the planes GEMM with split-K, 128-query attention tiles with a 749-row halo
+    from the left neighbour) must reproduce the reference's 386 ids.  Also: the sharded chunk's time is part of the
+    engine's encode_ms (it used to be only enqueued inside the bracket: 4 ms reported for 160 ms of work)."""
+    g = gold("stream_full_batch.npz")
+    audio = golden_audio(g)
+    os.environ["VOX_DEVICES"] = "0,0,0,0,0,0,0,0"
+    try:
+        with vox.Model(model_dir("full")) as m:
+            assert m.ctx.n_shard_engines == 8
+            got = m.transcribe(audio)["tokens"]
+            t = m.timing()
+    finally:
+        del os.environ["VOX_DEVICES"]
+    assert np.array_equal(np.asarray(got), g["tokens"]), int((np.asarray(got)[:len(g["tokens"])] != g["tokens"][:len(got)]).sum())
+    assert t["encode_ms"] > 8.0, t
+
+
+def test_fused_decode_fallback_is_a_suspension_not_a_verdict(vox):
+    """A hand-off time-out of the fused decode kernel (injected) makes the engine repeat the batch on the launch-per-GEMV
+    chain - same ids - and stay there for 256 clean steps, after which the fused kernel is live again."""
+    import ctypes as C
+    h = vox.hip
+    h.vox_hip_fuse_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long)]
+    h.vox_hip_debug_inject_fuse_timeout.argtypes = [C.c_void_p]
+    g = gold("stream_full_batch.npz")
+    audio = golden_audio(g)
+
+    def stats(m):
+        f, a, r = C.c_int(), C.c_int(), C.c_long()
+        rc = h.vox_hip_fuse_stats(m.engine, C.byref(f), C.byref(a), C.byref(r))
+        return rc, f.value, a.value, r.value
+
+    with vox.Model(model_dir("full")) as m:
+        rc, f, a, r = stats(m)
+        if rc != 0:
+            pytest.skip("engine without the fused decode kernel")
+        assert (f, a, r) == (0, 1, 0)
+        assert h.vox_hip_debug_inject_fuse_timeout(m.engine) == 0
+        t1 = m.transcribe(audio)["tokens"]                   # 386 steps: batch repeated on the chain, re-armed after 256
+        rc, f, a, r = stats(m)
+        assert f == 1 and a == 1 and r == 0, (f, a, r)
+        assert "dec_fused" in m.active_paths()[1]
+        t2 = m.transcribe(audio)["tokens"]
+    assert np.array_equal(np.asarray(t1), g["tokens"]) and np.array_equal(np.asarray(t2), g["tokens"])
+
+
+def test_reference_weight_views_are_filled(small):
+    """vox_ctx_t starts with the reference's fields (voxtral.h:154-204): the bf16 views point at the checkpoint's bytes,
+    the f32 views hold the load_f32 conversions, the big f32 variants are NULL ("NULL if bf16")."""
+    import ctypes as C
+    from oracle.vox_oracle import Weights
+    c = small.ctx
+    w = Weights(model_dir("small"), vo.PRESETS["small"])
+    d = small.dims
+    L0 = c.decoder.layers[0]
+    assert L0.wq_weight is None and L0.wq_weight_bf16 and c.decoder.tok_embeddings is None
+    got = np.ctypeslib.as_array(C.cast(L0.wq_weight_bf16, C.POINTER(C.c_uint16)), shape=(d.dec_heads * d.dec_head_dim, d.dec_dim))
+    assert np.array_equal(got, w.bf("layers.0.attention.wq.weight"))
+    E1 = c.encoder.layers[1]
+    got = np.ctypeslib.as_array(C.cast(E1.wo_bias, C.POINTER(C.c_float)), shape=(d.enc_dim,))
+    assert np.array_equal(got, w.f32("mm_streams_embeddings.embedding_module.whisper_encoder.transformer.layers.1.attention.wo.bias"))
+    got = np.ctypeslib.as_array(C.cast(c.encoder.conv1_weight, C.POINTER(C.c_float)), shape=(d.enc_dim, d.enc_dim * 3))
+    assert np.array_equal(got.ravel(), w.f32("mm_streams_embeddings.embedding_module.whisper_encoder.conv_layers.1.conv.weight").ravel())
+    assert c.kv_cache_k is None and c.use_bf16 == 1 and c.delay_tokens == 6
+    assert abs(c.t_cond[0] - np.cos(6.0)) < 1e-6
 
 
 def test_fp8_decode_weights_track_bf16(vox):

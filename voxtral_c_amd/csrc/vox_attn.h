@@ -609,18 +609,38 @@ __global__ __launch_bounds__(256) void k_attn_small(const AttnArgs a, int key_lo
 }
 
 // Merge split-K partials.  grid = (n_heads, n_q), block = HD threads.
+// The partials come from other CUs' previous kernel (every load a trip to L2 / memory): all (max, sum) pairs and a batch of
+// 16 output values are requested before anything is computed on them; the arithmetic and its order are unchanged.
 template <int HD>
 __global__ __launch_bounds__(HD) void k_attn_combine(float *out, int ldo, const float *part_o,
                                                      const float *part_ml, int n_heads, int nsplit) {
     const int head = blockIdx.x, qi = blockIdx.y, d = threadIdx.x;
     const size_t base = ((size_t)qi * n_heads + head) * nsplit;
-    float mm = -1e30f;
-    for (int s = 0; s < nsplit; s++) mm = fmaxf(mm, part_ml[(base + s) * 2]);
-    float ll = 0.f, ov = 0.f;
-    for (int s = 0; s < nsplit; s++) {
-        const float f = expf(part_ml[(base + s) * 2] - mm);
-        ll += part_ml[(base + s) * 2 + 1] * f;
-        ov += part_o[(base + s) * HD + d] * f;
+    float mm = -1e30f, ll = 0.f, ov = 0.f;
+    if (nsplit <= 16) {
+        float2 ml[16]; float o[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const int sc = min(s, nsplit - 1);
+            ml[s] = *reinterpret_cast<const float2 *>(part_ml + (base + sc) * 2);
+            o[s] = part_o[(base + sc) * HD + d];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; s++) if (s < nsplit) mm = fmaxf(mm, ml[s].x);
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+            if (s < nsplit) {
+                const float f = expf(ml[s].x - mm);
+                ll += ml[s].y * f;
+                ov += o[s] * f;
+            }
+    } else {
+        for (int s = 0; s < nsplit; s++) mm = fmaxf(mm, part_ml[(base + s) * 2]);
+        for (int s = 0; s < nsplit; s++) {
+            const float f = expf(part_ml[(base + s) * 2] - mm);
+            ll += part_ml[(base + s) * 2 + 1] * f;
+            ov += part_o[(base + s) * HD + d] * f;
+        }
     }
     out[(size_t)qi * ldo + head * HD + d] = ll > 0.f ? ov * (1.0f / ll) : 0.f;
 }

@@ -68,6 +68,7 @@ struct DecFuseArgs {
     unsigned long long spin_limit;   // wall_clock64 ticks
     unsigned long long *trace;       // optional (tuning): [2 blocks][16] wall-clock stamps of the phases, blocks 0 and 255
     int spread_groups;               // test switch: group = blockIdx / 32 (members spread over all XCDs) instead of blockIdx % 8
+    int wo_serial_reduce;            // A/B switch: the round-2 per-row wave reductions of the Wo partial product
     unsigned long long *tl;          // optional (tuning): per-workgroup timeline, see tl_begin / tl_end
 };
 // stamps stay in registers until the end (no stores in the middle of the memory schedule)
@@ -558,15 +559,41 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     if (wo_n > 0) {
         const float4 x0 = *reinterpret_cast<const float4 *>(att + lane * 8);
         const float4 x1 = *reinterpret_cast<const float4 *>(att + lane * 8 + 4);
-        float mine = 0.f;
+        if (a.wo_serial_reduce) {
+            // A/B (VOX_HIP_FUSE_SERIAL_WO): one wave-wide reduction per row, 13-16 in a row - 1.36 us between "wo landed" and
+            // "wo done" in the round-2 timeline (profiles/r02_fuse_timeline_kv232.txt), on the critical path of every layer
+            float mine = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            if (i < wo_n) {
-                const float s = df_wave_sum<USE_DPP>(dot8_bf16(wv[i], x0, x1, 0.f));
-                if (lane == i) mine = s;
+            for (int i = 0; i < 16; i++) {
+                if (i < wo_n) {
+                    const float s = df_wave_sum<USE_DPP>(dot8_bf16(wv[i], x0, x1, 0.f));
+                    if (lane == i) mine = s;
+                }
             }
+            if (lane < wo_n) a.wo_part[(size_t)g * DF_D + wo_row0 + lane] = mine;
+        } else {
+            // The 16 row sums of a wave as ONE transposed reduction through LDS (the K/V tile area is dead by now: every DMA has
+            // landed and every reader is past the barrier above): lane l parks its 16 partial dots in column l of a [16][68]
+            // scratch (row stride 68 floats: the reads below then hit 16 distinct 16-byte slots per service group), lane
+            // (row = l >> 2, quarter = l & 3) adds 16 of them in a fixed order, two quad steps finish the row.  LDS operations
+            // of one wave execute in order, so no barrier is needed between the stores and the loads.
+            float *wr = reinterpret_cast<float *>(tiles) + wave * (16 * 68);
+#pragma unroll
+            for (int i = 0; i < 16; i++) wr[i * 68 + lane] = dot8_bf16(wv[i], x0, x1, 0.f);      // rows past wo_n repeat the last one: never stored
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int row = lane >> 2, q = lane & 3;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float4 v = *reinterpret_cast<const float4 *>(wr + row * 68 + q * 16 + 4 * c);
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+            s += __shfl_xor(s, 1, 4);
+            s += __shfl_xor(s, 2, 4);
+            if (q == 0 && row < wo_n) a.wo_part[(size_t)g * DF_D + wo_row0 + row] = s;
         }
-        if (lane < wo_n) a.wo_part[(size_t)g * DF_D + wo_row0 + lane] = mine;
     }
     DF_MARK(10);
     if (a.trace && tid == 0 && (blockIdx.x == 0 || blockIdx.x == DF_BLOCKS - 1)) {

@@ -33,6 +33,7 @@
 #include "vox_kernel_api.h"
 #include "vox_decfuse.h"
 #include "vox_skinny.h"
+#include "vox_rowsgemm.h"
 
 using namespace vox;
 
@@ -191,6 +192,8 @@ struct vox_hip_engine {
     int enc_qd = 0, dec_qd = 0, dec_kvd = 0;
     size_t mem_used = 0;
     bool use_skinny = true;
+    bool use_rowsgemm = true;     // 33 .. 128-row chunks (decoder prefill, encoder flush pass) on k_rowsgemm (vox_rowsgemm.h)
+    int rg_small = 0;             // A/B (VOX_HIP_RG_SMALL): also run <= 32-row encoder chunks on that path instead of k_skinny
     bool use_dpp = true, use_mfma = true, use_gemv2 = true, use_gemv3 = true, use_splitk = true, use_bf16x3 = true, use_attn_mfma = true;
 
     // weights
@@ -980,13 +983,14 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
     uint16_t *xnp = (uint16_t *)e->sgu.p, *hp = xnp + (size_t)3 * n * c.D;
     float *part = (float *)e->ssplitk.p;
     const size_t lds1 = (size_t)SK_WPB * 4096, lds2 = (size_t)SK_WPB * 2 * 4096;
+    static const int sk_dbg = getenv("VOX_HIP_SK_DBG") ? atoi(getenv("VOX_HIP_SK_DBG")) : 0;      // tuning only: wrong results
     if (L > 0)      // attention_norm of layer 0 (no partials, no bias: x is left as it is)
         hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)nullptr, 0, n, c.D, (const float *)nullptr,
                            (const float *)e->enc[0].n1, c.eps, xn, c.D, xnp);
     for (int l = 0; l < L; l++) {
         EncLayer &Ly = e->enc[l];
         {   // attention_norm(x) . [wq; wk; wv]^T + bias, RoPE, K/V into the merged buffer and the rings
-            SkinnyArgs a{};
+            SkinnyArgs a{}; a.dbg = sk_dbg;
             a.Xp = xnp; a.xp_plane = (size_t)n * c.D; a.n = n; a.W = Ly.wqkv; a.N = N3; a.K = c.D; a.bias = Ly.bqkv; a.Y = qkv; a.ldy = N3;
             a.rope_cols = c.QD + c.KVD; a.head_dim = c.hd; a.rope_tab = tab; a.kring = Ly.kring; a.vring = Ly.vring;
             a.ring_cap = e->enc_ring_cap; a.kv_dim = c.KVD; a.pos0 = pos0; a.q_cols = c.QD;
@@ -994,20 +998,20 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
         }
         if (enc_attention(e, c, qkv, attn, n, pos0, Ly.kring, Ly.vring, e->enc_ring_cap)) return -1;
         {   // wo as K-split partials, then x += . + bo and ffn_norm in one launch
-            SkinnyArgs a{};
+            SkinnyArgs a{}; a.dbg = sk_dbg;
             a.X = attn; a.ldx = c.QD; a.n = n; a.W = Ly.wo; a.N = c.D; a.K = c.QD; a.partial = part;
             hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, false>), dim3(c.D / 32, so), dim3(64 * SK_WPB), lds1, s, a);
             hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)part, so, n, c.D, (const float *)Ly.bo,
                                (const float *)Ly.n2, c.eps, xn, c.D, xnp);
         }
         {   // silu(xn w1^T) * (xn w3^T), written as bf16 planes for the w2 launch
-            SkinnyArgs a{};
+            SkinnyArgs a{}; a.dbg = sk_dbg;
             a.Xp = xnp; a.xp_plane = (size_t)n * c.D; a.n = n; a.W = Ly.w13; a.W2 = Ly.w13 + (size_t)c.H * c.D; a.N = c.H; a.K = c.D;
             a.Yp = hp; a.yp_plane = (size_t)n * c.H;
             hipLaunchKernelGGL((k_skinny<SK_SWIGLU, 1, true>), dim3(c.H / 32, 1), dim3(64 * SK_WPB), lds2, s, a);
         }
         {   // w2 partials, then x += . + b2 and the next norm (next layer's attention_norm, or the final norm into `out`)
-            SkinnyArgs a{};
+            SkinnyArgs a{}; a.dbg = sk_dbg;
             a.Xp = hp; a.xp_plane = (size_t)n * c.H; a.n = n; a.W = Ly.w2; a.N = c.D; a.K = c.H; a.partial = part;
             hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, true>), dim3(c.D / 32, s2), dim3(64 * SK_WPB), lds1, s, a);
             const bool last = l + 1 == L;
@@ -1023,11 +1027,164 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------
+// 1 .. 128 rows on k_rowsgemm (vox_rowsgemm.h): weight tiles across the waves of a workgroup, the activation K range in LDS,
+// K split over blockIdx.y, raw partial sums consumed by k_qkv_finish / k_rows_finish / k_swiglu_finish.
+// ------------------------------------------------------------------------------------
+struct RgPlan { int wpb, cpw, cw, S, nb, ntile; size_t lds; };
+static RgPlan rg_plan(int n, int N, int K, bool f32x = false) {
+    RgPlan p{};
+    const int mt = (n + 31) / 32, nchunks = K / 64;
+    p.wpb = N >= 2048 ? 8 : 4;
+    // two weight tiles per wave (every activation fragment read from LDS feeds two MFMAs) for the wide GEMMs of <= 64 rows
+    static const int force_nb = getenv("VOX_HIP_RG_NB") ? atoi(getenv("VOX_HIP_RG_NB")) : 0;
+    p.ntile = (mt <= 2 && N >= 4096) ? 2 : 1;
+    if (force_nb == 1 || (force_nb == 2 && mt <= 2 && N >= 512)) p.ntile = force_nb;
+    p.nb = (N + 32 * p.ntile * p.wpb - 1) / (32 * p.ntile * p.wpb);
+    // chunks per round: two LDS stages of 3 planes x 32 mt rows x cpw x 128 B must fit (mt * cpw <= 6: 144 KB)
+    static const int force_cpw = getenv("VOX_HIP_RG_CPW") ? atoi(getenv("VOX_HIP_RG_CPW")) : 0;
+    p.cpw = mt <= 3 ? 2 : 1;
+    if ((force_cpw == 1 || force_cpw == 2) && force_cpw * mt <= 6) p.cpw = force_cpw;
+    // register budget of the 512-thread variants (256 VGPRs): two weight register sets of NB x cpw x 4 fragments + 16 NB mt
+    // accumulators (+ the f32 rows of the next round) - one chunk per round where two would spill
+    if (p.wpb == 8 && (p.ntile == 2 || f32x)) p.cpw = 1;
+    p.lds = (size_t)2 * 3 * 32 * mt * p.cpw * 128;
+    // one workgroup per CU (the stages take up to 144 KB of its LDS): as many K splits as fill the chip without a second wave
+    // of workgroups - 288 workgroups on 256 CUs ran 75 us where 216 ran 54 (gpurun_out/p6)
+    static const int target = getenv("VOX_HIP_RG_WGS") ? atoi(getenv("VOX_HIP_RG_WGS")) : 256;      // tuning: workgroups per launch
+    const int S = std::max(1, std::min(nchunks, target / p.nb));
+    int cw = (nchunks + S - 1) / S;
+    cw = ((cw + p.cpw - 1) / p.cpw) * p.cpw;
+    p.cw = cw; p.S = (nchunks + cw - 1) / cw;
+    return p;
+}
+static bool rowsgemm_ok(const vox_hip_engine *e, int n, const RowsCfg &c) {
+    return e->use_rowsgemm && e->use_mfma && n >= 1 && n <= 128 && c.D % 64 == 0 && c.QD % 64 == 0 && c.H % 64 == 0 &&
+           (c.QD + 2 * c.KVD) % 4 == 0 && c.hd % 4 == 0 && c.KVD % 4 == 0 && c.QD % 4 == 0;
+}
+// partial[S][n][N] = x . W^T split over K; x as planes (Xp) or f32 rows (X).  Returns S (the number of partial slices) or -1.
+static int launch_rowsgemm(vox_hip_engine *e, const uint16_t *Xp, size_t xp_plane, const float *X, int ldx, int n,
+                           const uint16_t *W, int N, int K, float *partial) {
+    const RgPlan p = rg_plan(n, N, K, Xp == nullptr);
+    RowsGemmArgs a{};
+    a.Xp = Xp; a.xp_plane = xp_plane; a.X = X; a.ldx = ldx; a.n = n; a.mt = (n + 31) / 32; a.W = W; a.N = N; a.K = K; a.cw = p.cw;
+    a.partial = partial;
+    static const int rg_dbg = getenv("VOX_HIP_RG_DBG") ? atoi(getenv("VOX_HIP_RG_DBG")) : 0;       // tuning only: wrong results
+    a.dbg = rg_dbg;
+    const dim3 grid(p.nb, p.S), block(64 * p.wpb);
+    hipStream_t s = e->stream;
+#define RG_LAUNCH(WPB, CPW, NBT)                                                                                         \
+    do {                                                                                                                 \
+        if (Xp) hipLaunchKernelGGL((k_rowsgemm<WPB, CPW, RG_X_PLANES, NBT>), grid, block, p.lds, s, a);                  \
+        else hipLaunchKernelGGL((k_rowsgemm<WPB, CPW, RG_X_F32, NBT>), grid, block, p.lds, s, a);                        \
+    } while (0)
+    if (p.ntile == 2) {
+        if (p.wpb == 8) { if (p.cpw == 2) RG_LAUNCH(8, 2, 2); else RG_LAUNCH(8, 1, 2); }
+        else { if (p.cpw == 2) RG_LAUNCH(4, 2, 2); else RG_LAUNCH(4, 1, 2); }
+    } else {
+        if (p.wpb == 8) { if (p.cpw == 2) RG_LAUNCH(8, 2, 1); else RG_LAUNCH(8, 1, 1); }
+        else { if (p.cpw == 2) RG_LAUNCH(4, 2, 1); else RG_LAUNCH(4, 1, 1); }
+    }
+#undef RG_LAUNCH
+    return p.S;
+}
+static size_t rg_partial_bytes(int n, int N, int K) {       // (the f32-activation plan never has fewer chunks per workgroup: its S is the larger one)
+    return (size_t)std::max(rg_plan(n, N, K, false).S, rg_plan(n, N, K, true).S) * n * N * 4;
+}
+
+// Decoder attention of `n` prefill rows over the KV ring (the rows' own K/V are in the ring already).
+static int dec_attention_rows(vox_hip_engine *e, const RowsCfg &c, float *qkv, float *attn, int n, int pos0, float *kring, float *vring, int ring_cap) {
+    hipStream_t s = e->stream;
+    const int N3 = c.QD + 2 * c.KVD;
+    const int max_len = std::min(pos0 + n, c.window);
+    const int nsplit = (max_len + DEC_SPLIT_KEYS - 1) / DEC_SPLIT_KEYS;
+    AttnArgs a{};
+    a.out = attn; a.ldo = c.QD; a.q = qkv; a.ldq = N3; a.n_q = n; a.qpos0 = pos0;
+    a.kB = nullptr; a.vB = nullptr; a.ldB = 0; a.posB0 = INT_MAX; a.last_key = pos0 + n - 1;
+    a.kA = kring; a.vA = vring; a.capA = ring_cap; a.ldA = c.KVD;
+    a.n_heads = c.heads; a.n_kv_heads = c.kv_heads; a.scale = 1.0f / sqrtf((float)c.hd); a.window = c.window; a.st = nullptr;
+    a.split_keys = DEC_SPLIT_KEYS;
+    if (nsplit > 1) {
+        if (ensure(e, e->spart_o, (size_t)n * c.heads * nsplit * c.hd * 4)) return -1;
+        if (ensure(e, e->spart_ml, (size_t)n * c.heads * nsplit * 2 * 4)) return -1;
+        a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
+    }
+    if (e->use_dpp) hipLaunchKernelGGL((k_attn_dec<128, 4, true>), dim3(c.kv_heads, nsplit, n), dim3(256), 0, s, a, nsplit);
+    else hipLaunchKernelGGL((k_attn_dec<128, 4, false>), dim3(c.kv_heads, nsplit, n), dim3(256), 0, s, a, nsplit);
+    if (nsplit > 1)
+        hipLaunchKernelGGL((k_attn_combine<128>), dim3(c.heads, n), dim3(128), 0, s, attn, c.QD,
+                           (const float *)a.part_o, (const float *)a.part_ml, c.heads, nsplit);
+    return 0;
+}
+
+// All layers of one stack on n <= 128 rows x[n][D] (in place).  Encoder: final norm into `out` (f32 rows); decoder prefill:
+// out = nullptr, only the KV rings matter (voxtral_decoder.c:410-558).  The RoPE table of the chunk is in e->srope.
+// Per layer: qkv GEMM, qkv finish (bias, RoPE, KV append), attention (+ combine), wo GEMM, finish (residual + ffn_norm (+ ada)
+// -> planes), w1;w3 GEMM, SwiGLU finish (-> planes), w2 GEMM, finish (residual + the next norm -> planes) = 9 - 10 launches.
+static int rows_mid_layers(vox_hip_engine *e, float *x, int n, int pos0, const RowsCfg &c, bool is_enc, float *out) {
+    const int N3 = c.QD + 2 * c.KVD, L = is_enc ? e->d.enc_layers : e->d.dec_layers;
+    hipStream_t s = e->stream;
+    size_t pb = std::max(std::max(rg_partial_bytes(n, N3, c.D), rg_partial_bytes(n, c.D, c.QD)),
+                         std::max(rg_partial_bytes(n, 2 * c.H, c.D), rg_partial_bytes(n, c.D, c.H)));
+    if (ensure(e, e->ssplitk, pb)) return -1;
+    if (ensure(e, e->sgu, (size_t)3 * n * (c.D + c.H) * 2)) return -1;       // bf16 planes of the normalised rows and of the gated hidden rows
+    if (ensure(e, e->sqkv, (size_t)n * N3 * 4) || ensure(e, e->sattn, (size_t)n * c.QD * 4)) return -1;
+    uint16_t *xnp = (uint16_t *)e->sgu.p, *hp = xnp + (size_t)3 * n * c.D;
+    float *part = (float *)e->ssplitk.p, *qkv = (float *)e->sqkv.p, *attn = (float *)e->sattn.p, *tab = (float *)e->srope.p;
+    const int ring_cap = is_enc ? e->enc_ring_cap : e->dec_ring_cap;
+    // the chunk's K/V rows may go to their ring slots before attention when they cannot overwrite a row the window still needs
+    const bool append_early = !is_enc || n <= ring_cap - c.window;
+    auto norm_of = [&](int l, int which) -> const float * {      // which: 0 attention_norm, 1 ffn_norm
+        if (is_enc) return which ? e->enc[l].n2 : e->enc[l].n1;
+        return which ? e->dec[l].n2 : e->dec[l].n1;
+    };
+    if (L > 0)
+        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)nullptr, 0, n, c.D, (const float *)nullptr,
+                           norm_of(0, 0), c.eps, (float *)nullptr, 0, xnp, (const float *)nullptr);
+    for (int l = 0; l < L; l++) {
+        const uint16_t *wqkv = is_enc ? e->enc[l].wqkv : e->dec[l].wqkv, *wo = is_enc ? e->enc[l].wo : e->dec[l].wo;
+        const uint16_t *w13 = is_enc ? e->enc[l].w13 : e->dec[l].w13, *w2 = is_enc ? e->enc[l].w2 : e->dec[l].w2;
+        float *kring = is_enc ? e->enc[l].kring : e->dec[l].kring, *vring = is_enc ? e->enc[l].vring : e->dec[l].vring;
+        const float *bqkv = is_enc ? e->enc[l].bqkv : nullptr, *bo = is_enc ? e->enc[l].bo : nullptr, *b2 = is_enc ? e->enc[l].b2 : nullptr;
+        const float *ada = is_enc ? nullptr : e->dec[l].ada;
+        int S = launch_rowsgemm(e, xnp, (size_t)n * c.D, nullptr, 0, n, wqkv, N3, c.D, part);
+        hipLaunchKernelGGL(k_qkv_finish, dim3(grid1d((size_t)n * N3 / 4)), dim3(256), 0, s, qkv, N3, (const float *)part, S, n, bqkv,
+                           (const float *)tab, c.QD + c.KVD, c.hd, append_early ? kring : (float *)nullptr, vring, ring_cap, c.KVD, pos0, c.QD);
+        if (is_enc) {
+            if (enc_attention(e, c, qkv, attn, n, pos0, kring, vring, ring_cap)) return -1;
+            if (!append_early) {
+                const int keep = std::min(n, c.window);
+                hipLaunchKernelGGL(k_ring_append, dim3(grid1d((size_t)keep * c.KVD / 4)), dim3(256), 0, s,
+                                   kring, vring, ring_cap, c.KVD, qkv, N3, c.QD, c.QD + c.KVD, n - keep, keep, pos0 + n - keep);
+            }
+        } else if (dec_attention_rows(e, c, qkv, attn, n, pos0, kring, vring, ring_cap)) return -1;
+        S = launch_rowsgemm(e, nullptr, 0, attn, c.QD, n, wo, c.D, c.QD, part);
+        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)part, S, n, c.D, bo,
+                           norm_of(l, 1), c.eps, (float *)nullptr, 0, xnp, ada);
+        S = launch_rowsgemm(e, xnp, (size_t)n * c.D, nullptr, 0, n, w13, 2 * c.H, c.D, part);
+        hipLaunchKernelGGL(k_swiglu_finish, dim3(grid1d((size_t)n * c.H / 4)), dim3(256), 0, s, hp, (size_t)n * c.H, (const float *)part, S, n, c.H);
+        S = launch_rowsgemm(e, hp, (size_t)n * c.H, nullptr, 0, n, w2, c.D, c.H, part);
+        const bool last = l + 1 == L;
+        const float *next_norm = last ? (is_enc ? e->enc_final_norm : (const float *)nullptr) : norm_of(l + 1, 0);
+        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)part, S, n, c.D, b2,
+                           next_norm, c.eps, last ? out : (float *)nullptr, c.D, last ? (uint16_t *)nullptr : xnp, (const float *)nullptr);
+    }
+    if (L == 0 && out)
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, s, out, c.D, x, c.D, e->enc_final_norm, (const float *)nullptr, c.D, c.eps);
+    LAUNCH_CHECK("rows-gemm layer launches");
+    return 0;
+}
+
 static int encoder_rows_dev(vox_hip_engine *e, float *x, int n, float *out) {
     const RowsCfg c = enc_cfg(e);
     if (ensure_rows_scratch(e, n, c)) return -1;
     hipLaunchKernelGGL(k_rope_table, dim3(grid1d((size_t)n * c.hd / 2)), dim3(256), 0, e->stream,
                        (float *)e->srope.p, e->enc_inv_freq, e->enc_pos, n, c.hd / 2);
+    if (rowsgemm_ok(e, n, c) && (n > 32 || e->rg_small || !skinny_ok(e, n, c))) {
+        if (rows_mid_layers(e, x, n, e->enc_pos, c, true, out)) return -1;
+        e->enc_pos += n;
+        return 0;
+    }
     if (skinny_ok(e, n, c)) return encoder_rows_skinny(e, x, n, out);
     for (int l = 0; l < e->d.enc_layers; l++) {
         EncLayer &L = e->enc[l];
@@ -1462,18 +1619,24 @@ extern "C" int vox_hip_memcpy(vox_hip_engine_t *e, void *dst, const void *src, s
 // ------------------------------------------------------------------------------------
 static int decoder_prefill_dev(vox_hip_engine *e, float *x, int n) {
     const RowsCfg c = dec_cfg(e);
-    for (int off = 0; off < n; off += PREFILL_CHUNK) {
-        const int m = std::min(PREFILL_CHUNK, n - off);
+    for (int off = 0; off < n;) {
+        // prompts of up to 128 rows (the stream's 38) run as one k_rowsgemm chunk, longer ones in 512-row GEMM chunks
+        const int m = (n - off <= 128 && e->use_rowsgemm) ? n - off : std::min(PREFILL_CHUNK, n - off);
         if (ensure_rows_scratch(e, m, c)) return -1;
         hipLaunchKernelGGL(k_rope_table, dim3(grid1d((size_t)m * c.hd / 2)), dim3(256), 0, e->stream,
                            (float *)e->srope.p, e->dec_inv_freq, e->dec_pos, m, c.hd / 2);
         float *xc = x + (size_t)off * c.D;
+        if (rowsgemm_ok(e, m, c)) {
+            if (rows_mid_layers(e, xc, m, e->dec_pos, c, false, nullptr)) return -1;
+            e->dec_pos += m; off += m;
+            continue;
+        }
         for (int l = 0; l < e->d.dec_layers; l++) {
             DecLayer &L = e->dec[l];
             if (run_layer_rows(e, xc, m, e->dec_pos, c, L.wqkv, nullptr, L.wo, nullptr, L.w13, L.w2, nullptr,
                                L.n1, L.n2, L.ada, L.kring, L.vring, e->dec_ring_cap)) return -1;
         }
-        e->dec_pos += m;
+        e->dec_pos += m; off += m;
     }
     LAUNCH_CHECK("decoder prefill launches");
     return 0;
@@ -1567,6 +1730,8 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl : nullptr;
                 static const int spread = getenv("VOX_HIP_FUSE_SPREAD") ? 1 : 0;    // test: group members on all XCDs
                 a.spread_groups = spread;
+                static const int serial_wo = getenv("VOX_HIP_FUSE_SERIAL_WO") ? 1 : 0;
+                a.wo_serial_reduce = serial_wo;
                 const bool emb = (l == 0 && build_embed);
                 if (e->use_dpp) {
                     if (emb) hipLaunchKernelGGL((k_dec_attn_fused<true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
@@ -1932,7 +2097,20 @@ extern "C" int vox_hip_linear_bf16(vox_hip_engine_t *e, float *y, const float *x
     HC(hipMemcpy(dx, x, (size_t)M * K * 4, hipMemcpyHostToDevice));
     HC(hipMemcpy(dw, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
     if (bias) { HC(hipMalloc((void **)&db, (size_t)N * 4)); HC(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice)); }
-    if (linear_dev(e, dy, N, dx, K, dw, db, M, K, N, ACT_NONE, nullptr, 0, impl)) return -1;
+    if (impl == 4 || impl == 5) {
+        // test surface of k_rowsgemm (vox_rowsgemm.h): 4 = activations as bf16 planes, 5 = f32 rows; partials added by k_splitk_reduce
+        if (M > 128 || K % 64) { g_err = "vox_hip_linear_bf16: impl 4 / 5 need M <= 128 and K % 64 == 0"; return -1; }
+        uint16_t *dp = nullptr; float *part = nullptr;
+        HC(hipMalloc((void **)&dp, (size_t)3 * M * K * 2));
+        HC(hipMalloc((void **)&part, rg_partial_bytes(M, N, K)));
+        hipLaunchKernelGGL(k_split_planes, dim3(grid1d((size_t)M * K / 4)), dim3(256), 0, e->stream, dp, (size_t)M * K, (const float *)dx, K, M, K);
+        const int S = impl == 4 ? launch_rowsgemm(e, dp, (size_t)M * K, nullptr, 0, M, dw, N, K, part)
+                                : launch_rowsgemm(e, nullptr, 0, dx, K, M, dw, N, K, part);
+        GemmArgs a{nullptr, 0, dw, dy, N, M, N, K, db, nullptr, 0, ACT_NONE, S, 0, part};
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((size_t)M * N)), dim3(256), 0, e->stream, a);
+        HC(esync(e));
+        hipFree(dp); hipFree(part);
+    } else if (linear_dev(e, dy, N, dx, K, dw, db, M, K, N, ACT_NONE, nullptr, 0, impl)) return -1;
     HC(esync(e));
     HC(hipGetLastError());
     HC(hipMemcpy(y, dy, (size_t)M * N * 4, hipMemcpyDeviceToHost));
@@ -2351,6 +2529,20 @@ static int self_test(vox_hip_engine *e) {
     if (hipFuncSetAttribute((const void *)k_skinny<SK_SWIGLU, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_WPB * 2 * 4096) != hipSuccess) {
         (void)hipGetLastError();
         e->use_skinny = false;
+    }
+    {   // k_rowsgemm: up to 3 planes x 128 rows x 2 chunks (or 96 rows x 4 chunks) of activations in LDS
+        const int rg_lds = 2 * 3 * 32 * 6 * 128;        // the largest request the launcher can make (mt * cpw <= 6)
+#define RG_FN(WPB, CPW) (const void *)k_rowsgemm<WPB, CPW, RG_X_PLANES, 1>, (const void *)k_rowsgemm<WPB, CPW, RG_X_F32, 1>, \
+                        (const void *)k_rowsgemm<WPB, CPW, RG_X_PLANES, 2>, (const void *)k_rowsgemm<WPB, CPW, RG_X_F32, 2>
+        const void *fns[] = {RG_FN(8, 2), RG_FN(8, 1), RG_FN(4, 2), RG_FN(4, 1)};
+#undef RG_FN
+        for (const void *f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, rg_lds) != hipSuccess) {
+                (void)hipGetLastError();
+                e->use_rowsgemm = false;
+            }
+        if (getenv("VOX_HIP_NO_ROWSGEMM")) e->use_rowsgemm = false;
+        e->rg_small = getenv("VOX_HIP_RG_SMALL") ? 1 : 0;
     }
     hipFree(dx); hipFree(dy0); hipFree(dy1); hipFree(dy2); hipFree(dw); hipFree(dbias);
     if (failed) {

@@ -42,6 +42,7 @@ struct SkinnyArgs {
     int rope_cols, head_dim;              // SK_QKV: columns [0, rope_cols) are rotated (q then k), pairs (2c, 2c+1)
     const float *rope_tab;                // [n][head_dim/2][2] cos, sin of this chunk's positions
     float *kring, *vring; int ring_cap, kv_dim, pos0, q_cols;   // k columns start at q_cols, v columns at q_cols + kv_dim
+    int dbg;                              // tuning only (VOX_HIP_SK_DBG, results are WRONG): 1 no X loads, 2 no W loads, 4 no MFMAs, 8 no epilogue
 };
 
 // x[m][k..k+7] (f32) -> three bf16x8 fragments (hi, mid, lo): exact split, vox_gemm.h split3
@@ -113,9 +114,21 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
 #pragma unroll
             // plain (L1-allocating) loads on purpose: in fragment layout one instruction takes 32 bytes from each of 32 rows,
             // and the four instructions of a chunk share their 128-byte lines - a non-temporal load would fetch each line 4 x
-            for (int b = 0; b < NB; b++) wqc[b][s] = *reinterpret_cast<const uint4 *>(wrow[b] + c * 64 + s * 16);
+            for (int b = 0; b < NB; b++) {
+                if (a.dbg & 2) wqc[b][s] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+                else wqc[b][s] = *reinterpret_cast<const uint4 *>(wrow[b] + c * 64 + s * 16);
+            }
     };
     auto issue_x = [&](float4 (&xq)[MT][4][XR], int c) {
+        if (a.dbg & 1) {
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int t = 0; t < MT; t++)
+#pragma unroll
+                    for (int p = 0; p < XR; p++) xq[t][s][p] = make_float4(1.f, 1.f, 1.f, 1.f);
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -130,6 +143,13 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
             }
     };
     auto compute = [&](const uint4 (&wqc)[NB][4], const float4 (&xq)[MT][4][XR]) {
+        if (a.dbg & 4) {
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int t = 0; t < MT; t++) acc[b][t][0] += __uint_as_float(wqc[b][0].x) + xq[t][0][0].x + __uint_as_float(wqc[b][3].w) + xq[t][3][XR - 1].w;
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             bf16x8_t fa[MT][3];
@@ -187,6 +207,7 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
     __syncthreads();
 
     // ---- epilogue over the tile: e -> (tile t, r, lane) -> row m = 32 t + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31
+    if ((a.dbg & 8) && red[tid] != 12345.678f) return;
     for (int e = tid; e < MT * 1024; e += 64 * SK_WPB) {
         const int t = e >> 10, r = (e >> 6) & 15, ln = e & 63;
         const int m = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
@@ -227,7 +248,7 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
 // planes (optional): the normalised row also as bf16 planes [3][n][D] for the XS skinny launches that consume it.
 __global__ __launch_bounds__(256) void k_rows_finish(float *x, int ldx, const float *partial, int nsplit, int n, int D,
                                                      const float *bias, const float *norm_w, float eps, float *out_norm, int ldo,
-                                                     uint16_t *planes) {
+                                                     uint16_t *planes, const float *ada = nullptr) {
     __shared__ float red[4];
     const int m = blockIdx.x, tid = threadIdx.x;
     float *xr = x + (size_t)m * ldx;
@@ -235,9 +256,18 @@ __global__ __launch_bounds__(256) void k_rows_finish(float *x, int ldx, const fl
     for (int i = tid * 4; i < D; i += 1024) {
         float4 v = *reinterpret_cast<const float4 *>(xr + i);
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = 0; z < nsplit; z++) {
-            const float4 p = *reinterpret_cast<const float4 *>(partial + ((size_t)z * n + m) * D + i);
-            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        // The partials were written by other CUs' previous kernel: every load is a trip to L2 / memory (~1 us).  Request a
+        // batch of 8 before adding any of them (clamped index + select instead of a branch, so that the loads do not end up
+        // behind a wait one by one: 10 splits took 8.8 us that way); the additions stay in split order.
+        for (int z0 = 0; z0 < nsplit; z0 += 8) {
+            float4 p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p[u] = *reinterpret_cast<const float4 *>(partial + ((size_t)min(z0 + u, nsplit - 1) * n + m) * D + i);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const bool on = z0 + u < nsplit;
+                s.x += on ? p[u].x : 0.f; s.y += on ? p[u].y : 0.f; s.z += on ? p[u].z : 0.f; s.w += on ? p[u].w : 0.f;
+            }
         }
         if (bias) { const float4 b = *reinterpret_cast<const float4 *>(bias + i); s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w; }
         v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;                 // x + (proj + bias): the reference's order (vox_add_inplace)
@@ -249,12 +279,16 @@ __global__ __launch_bounds__(256) void k_rows_finish(float *x, int ldx, const fl
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
     const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)D + eps);
-    float *orow = out_norm + (size_t)m * ldo;
+    float *orow = out_norm ? out_norm + (size_t)m * ldo : nullptr;
     for (int i = tid * 4; i < D; i += 1024) {
         const float4 v = *reinterpret_cast<const float4 *>(xr + i);      // own elements, written above by this thread
         const float4 g = *reinterpret_cast<const float4 *>(norm_w + i);
-        const float4 o = make_float4(v.x * inv * g.x, v.y * inv * g.y, v.z * inv * g.z, v.w * inv * g.w);
-        *reinterpret_cast<float4 *>(orow + i) = o;
+        float4 o = make_float4(v.x * inv * g.x, v.y * inv * g.y, v.z * inv * g.z, v.w * inv * g.w);
+        if (ada) {                                                       // decoder ffn_norm: x_norm *= 1 + ada_scale (voxtral_decoder.c:678-682)
+            const float4 sc = *reinterpret_cast<const float4 *>(ada + i);
+            o.x *= (1.0f + sc.x); o.y *= (1.0f + sc.y); o.z *= (1.0f + sc.z); o.w *= (1.0f + sc.w);
+        }
+        if (orow) *reinterpret_cast<float4 *>(orow + i) = o;
         if (planes) {
             uint32_t h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
             split3(o.x, h0, m0, l0); split3(o.y, h1, m1, l1); split3(o.z, h2, m2, l2); split3(o.w, h3, m3, l3);

@@ -272,6 +272,12 @@ unsigned vox_hip_active_paths(const vox_hip_engine_t *e);
 int vox_hip_fuse_stats(const vox_hip_engine_t *e, int *failures, int *armed, long *rearm_in);
 /* Test hook: the next check after a synchronisation behaves as if a hand-off had timed out. */
 int vox_hip_debug_inject_fuse_timeout(vox_hip_engine_t *e);
+/* Test hook: residual-stream taps of the decode steps that run at the listed KV positions (n <= 16): x at the start of every
+ * layer, x after every attention block, x after the last layer = [2 L + 1][dec_dim] per position (the inputs of the reference's
+ * vox_rms_norm calls inside vox_decoder_forward, voxtral_decoder.c:653-694).  Copied in stream order; the kernels are unchanged.
+ * vox_hip_debug_tap_read writes [n][2 L + 1][dec_dim] and ends the tapping. */
+int vox_hip_debug_tap_config(vox_hip_engine_t *e, const int *positions, int n);
+int vox_hip_debug_tap_read(vox_hip_engine_t *e, float *out);
 
 /* Experiment: seconds per pass over ONE decoder layer's five kernels run back to back (weights
  * stay in the 256 MB Infinity Cache), for comparison with the streamed per-layer time. */

@@ -72,6 +72,9 @@ class RefLib:
         L.vox_load_wav.restype = C.c_void_p
         L.vox_load_wav.argtypes = [C.c_char_p, i32p]
         L.voxref_hook_reset.argtypes = [C.c_int, C.c_int]
+        L.voxref_tap_config.argtypes = [i32p, C.c_int, C.c_int, C.c_int]
+        L.voxref_taps.restype = f32p
+        L.voxref_tap_counts.restype = i32p
         L.voxref_hook_tokens.restype = i32p
         L.voxref_hook_logits.restype = f32p
         self.libc = C.CDLL(None)
@@ -220,7 +223,7 @@ class RefLib:
         return tok, logits
 
     def transcribe_stream(self, ctx, samples, feed_sizes=None, interval=None, continuous=False,
-                          vocab=0, max_logit_rows=0, delay_ms=None):
+                          vocab=0, max_logit_rows=0, delay_ms=None, tap_steps=None, tap_hidden=0, tap_vectors=0):
         """Drive the reference stream API like main.c does and capture everything.
 
         Returns dict(tokens=[ids per decoder step], logits=[rows, vocab] or None,
@@ -231,6 +234,9 @@ class RefLib:
         if delay_ms is not None:
             L.vox_set_delay(ctx, int(delay_ms))
         L.voxref_hook_reset(int(vocab), int(max_logit_rows))
+        if tap_steps is not None:      # residual-stream taps of a few decoder steps (oracle/ref_hooks.c)
+            ts = np.ascontiguousarray(tap_steps, np.int32)
+            L.voxref_tap_config(ts.ctypes.data_as(i32p), len(ts), int(tap_hidden), int(tap_vectors))
         st = L.vox_stream_init(ctx)
         if not st:
             raise RuntimeError("vox_stream_init failed")
@@ -267,5 +273,11 @@ class RefLib:
         logits = None
         if vocab and rows:
             logits = np.ctypeslib.as_array(L.voxref_hook_logits(), shape=(rows, vocab)).copy()
+        taps = None
+        if tap_steps is not None:
+            cnt = np.ctypeslib.as_array(L.voxref_tap_counts(), shape=(16,))[:len(tap_steps)].copy()
+            assert (cnt == tap_vectors).all(), cnt
+            taps = np.ctypeslib.as_array(L.voxref_taps(), shape=(len(tap_steps), tap_vectors, tap_hidden)).copy()
+            L.voxref_tap_config(None, 0, 0, 0)
         L.vox_stream_free(st)
-        return dict(tokens=toks, logits=logits, pieces=pieces)
+        return dict(tokens=toks, logits=logits, pieces=pieces, taps=taps)

@@ -55,3 +55,37 @@ int __wrap_vox_decoder_forward(void *ctx, const float *input_embeds, float *logi
     }
     return tok;
 }
+
+/* ---- residual-stream taps ------------------------------------------------------------------------------------------
+ * -Wl,--wrap=vox_rms_norm: every RMSNorm the decoder applies to ONE row (vox_decoder_forward: attention_norm and ffn_norm
+ * of each layer, then the final norm - voxtral_decoder.c:653-694) sees the residual stream as its input.  For a few chosen
+ * decoder steps the inputs are recorded in call order: [2 L + 1][hidden] per step = x at the start of every layer, x after
+ * every attention block, x after the last layer.  Goldens at this level pin the depth of the stack, not only its logits. */
+void __real_vox_rms_norm(float *out, const float *x, const float *weight, int seq_len, int hidden, float eps);
+
+#define TAP_MAX_STEPS 16
+static int    g_tap_steps[TAP_MAX_STEPS], g_tap_n = 0, g_tap_hidden = 0, g_tap_per_step = 0;
+static int    g_tap_count[TAP_MAX_STEPS];
+static float *g_taps = NULL;        /* [g_tap_n][g_tap_per_step][g_tap_hidden] */
+
+void voxref_tap_config(const int *steps, int n, int hidden, int vectors_per_step) {
+    free(g_taps); g_taps = NULL; g_tap_n = 0;
+    if (n <= 0 || n > TAP_MAX_STEPS || hidden <= 0 || vectors_per_step <= 0) return;
+    g_taps = (float *)calloc((size_t)n * vectors_per_step * hidden, sizeof(float));
+    if (!g_taps) return;
+    memcpy(g_tap_steps, steps, (size_t)n * sizeof(int));
+    memset(g_tap_count, 0, sizeof g_tap_count);
+    g_tap_n = n; g_tap_hidden = hidden; g_tap_per_step = vectors_per_step;
+}
+const float *voxref_taps(void) { return g_taps; }
+const int *voxref_tap_counts(void) { return g_tap_count; }
+
+void __wrap_vox_rms_norm(float *out, const float *x, const float *weight, int seq_len, int hidden, float eps) {
+    if (g_taps && seq_len == 1 && hidden == g_tap_hidden)
+        for (int i = 0; i < g_tap_n; i++)
+            if (g_tap_steps[i] == g_n && g_tap_count[i] < g_tap_per_step) {
+                memcpy(g_taps + ((size_t)i * g_tap_per_step + g_tap_count[i]) * hidden, x, (size_t)hidden * sizeof(float));
+                g_tap_count[i]++;
+            }
+    __real_vox_rms_norm(out, x, weight, seq_len, hidden, eps);
+}

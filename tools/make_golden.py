@@ -77,6 +77,9 @@ FULL_CASES = [
 LONG_CASES = [
     ("full_continuous", "full", 30.0, 0, 8000, 0.5, True, None, "benchmark/night1968/45s_right_through_the_billboard.wav",
      dict(tile_to=176 * 16000, max_logit_rows=2400, stride=160)),
+    # the 300 s batch line of bench.py (the 30 s clip tiled, ONE feed: a 16 946-position encoder chunk, 3761 decoder steps, KV to 3799)
+    ("full_batch300", "full", 30.0, 0, None, None, False, None, "benchmark/night1968/45s_right_through_the_billboard.wav",
+     dict(tile_to=300 * 16000, max_logit_rows=3800, stride=256)),
 ]
 
 
@@ -177,6 +180,21 @@ def main():
         print(f"{name}: {len(out['tokens'])} steps, {int(out['n_distinct'])} distinct tokens, "
               f"{len(out['pieces'])} pieces, min margin {mg.min() if mg is not None else None}, "
               f"margin hist {out['margin_hist'].tolist() if mg is not None else None}", flush=True)
+
+    # ---- residual-stream taps of the headline configuration (three decoder steps, every layer) ----
+    if args.only == "taps":
+        R = libs.get("full") or RefLib("full")
+        d = vo.PRESETS["full"]
+        audio, audio_i16 = case_audio(R, "benchmark/night1968/45s_right_through_the_billboard.wav", 30.0, 0)
+        steps = [0, 193, 385]
+        ctx = R.load(model_dir("full"))
+        r = R.transcribe_stream(ctx, audio, vocab=0, tap_steps=steps, tap_hidden=d.dec_dim, tap_vectors=2 * d.dec_layers + 1)
+        R.free(ctx)
+        np.savez_compressed(os.path.join(GOLD, "taps_full_batch.npz"), steps=np.array(steps, np.int32), taps=r["taps"].astype(np.float32),
+                            tokens=r["tokens"].astype(np.int32))
+        t = r["taps"]
+        print("taps_full_batch:", t.shape, "rms per layer at step 193:", np.sqrt((t[1] ** 2).mean(axis=1)).round(3).tolist())
+        return
 
     # ---- stage-level goldens on the tiny model (reference functions called directly) ----
     if not args.only or args.only == "stage":

@@ -528,8 +528,11 @@ __device__ __forceinline__ float as_dpp_max(float v) {
                  fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48))));
 }
 
-template <bool USE_DPP>
-__global__ __launch_bounds__(256) void k_attn_small(const AttnArgs a, int key_lo) {
+// NW waves per workgroup, 32 / NW query rows per wave (NW = 8: the score and P.V phases are serial chains of ~650 / ~250 cycles per
+// row; with 8 rows per wave they were 2.2 + 1.7 us of a 12.9 us launch).
+template <bool USE_DPP, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_attn_small(const AttnArgs a, int key_lo) {
+    constexpr int RPW = 32 / NW, NTH = 64 * NW;
     __shared__ __attribute__((aligned(16))) float qs[32][64];
     __shared__ float ks[64][65];
     __shared__ __attribute__((aligned(16))) float vs[64][64];
@@ -537,13 +540,13 @@ __global__ __launch_bounds__(256) void k_attn_small(const AttnArgs a, int key_lo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, z = blockIdx.y, nz = gridDim.y;
     const int n = a.n_q, t0 = key_lo + z * 64;
-    for (int i = tid; i < 512; i += 256) {
+    for (int i = tid; i < 512; i += NTH) {
         const int r = i >> 4, c = (i & 15) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < n) v = *reinterpret_cast<const float4 *>(a.q + (size_t)r * a.ldq + h * 64 + c);
         *reinterpret_cast<float4 *>(&qs[r][c]) = v;
     }
-    for (int i = tid; i < 1024; i += 256) {
+    for (int i = tid; i < 1024; i += NTH) {
         const int key = i >> 4, c = (i & 15) * 4;
         const int pos = t0 + key;
         float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(256) void k_attn_small(const AttnArgs a, int key_lo
         *reinterpret_cast<float4 *>(&vs[key][c]) = vv;
     }
     __syncthreads();
-    {   // scores and the slice's softmax statistics: wave = 8 query rows, lane = key
+    {   // scores and the slice's softmax statistics: wave = RPW query rows, lane = key
         float kr[64];
 #pragma unroll
         for (int d = 0; d < 64; d++) kr[d] = ks[lane][d];
@@ -568,8 +571,8 @@ __global__ __launch_bounds__(256) void k_attn_small(const AttnArgs a, int key_lo
         // one row at a time (unrolling the 8 rows makes the compiler hoist all 512 q values into registers: 256 VGPRs + spills,
         // 23 us); the reductions are DPP row steps + readlane, not ds_bpermute butterflies
 #pragma unroll 1
-        for (int r = 0; r < 8; r++) {
-            const int row = wave * 8 + r, P = a.qpos0 + row;
+        for (int r = 0; r < RPW; r++) {
+            const int row = wave * RPW + r, P = a.qpos0 + row;
             float s = 0.f;
 #pragma unroll
             for (int d = 0; d < 64; d += 4) {
@@ -589,20 +592,22 @@ __global__ __launch_bounds__(256) void k_attn_small(const AttnArgs a, int key_lo
         }
     }
     __syncthreads();
-    {   // P.V: wave = 8 query rows, lane = dim
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    {   // P.V: wave = RPW query rows, lane = dim
+        float acc[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; r++) acc[r] = 0.f;
 #pragma unroll 4
         for (int k4 = 0; k4 < 64; k4 += 4) {
             const float v0 = vs[k4][lane], v1 = vs[k4 + 1][lane], v2 = vs[k4 + 2][lane], v3 = vs[k4 + 3][lane];
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const float4 p4 = *reinterpret_cast<const float4 *>(&ps[wave * 8 + r][k4]);
+            for (int r = 0; r < RPW; r++) {
+                const float4 p4 = *reinterpret_cast<const float4 *>(&ps[wave * RPW + r][k4]);
                 acc[r] = fmaf(p4.x, v0, acc[r]); acc[r] = fmaf(p4.y, v1, acc[r]); acc[r] = fmaf(p4.z, v2, acc[r]); acc[r] = fmaf(p4.w, v3, acc[r]);
             }
         }
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int row = wave * 8 + r;
+        for (int r = 0; r < RPW; r++) {
+            const int row = wave * RPW + r;
             if (row < n) a.part_o[(((size_t)row * a.n_heads + h) * nz + z) * 64 + lane] = acc[r];
         }
     }

@@ -261,6 +261,9 @@ struct vox_hip_engine {
     std::vector<int> prof_kind;
     size_t prof_used = 0;
     unsigned long long n_host_syncs = 0;      // esync() calls (tests: no host wait inside a sharded wavefront)
+    // debug taps of the decoder's residual stream (vox_hip_debug_tap_config): at the decode steps whose KV position is listed,
+    // x at the start of every layer, x after every attention block and x after the last layer are copied to d_taps in stream order
+    std::vector<int> tap_pos; float *d_taps = nullptr;
 };
 
 // Every host-side wait on the engine stream goes through here and is counted (vox_hip_host_syncs): the multi-GPU
@@ -640,7 +643,7 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
         F(L.wqkv); F(L.wo); F(L.w13); F(L.w2); F(L.n1); F(L.n2); F(L.ada); F(L.kring); F(L.vring);
         F(L.wqkv8); F(L.wo8); F(L.w138); F(L.w28); F(L.sqkv); F(L.so); F(L.s13); F(L.s2);
     }
-    F(e->tok_emb8); F(e->stok);
+    F(e->tok_emb8); F(e->stok); F(e->d_taps);
     F(e->hann); F(e->cosT); F(e->sinT); F(e->filtT); F(e->enc_inv_freq); F(e->dec_inv_freq); F(e->dec_rope);
     F(e->d_st); F(e->dx); F(e->dx2); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
     F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_gq); F(e->d_gp); F(e->d_wo_part); F(e->d_fuse_err);
@@ -937,8 +940,14 @@ static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float 
         if (ensure(e, e->spart_o, (size_t)n * c.heads * ks * c.hd * 4)) return -1;
         if (ensure(e, e->spart_ml, (size_t)n * c.heads * ks * 2 * 4)) return -1;
         a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
-        if (e->use_dpp) hipLaunchKernelGGL(k_attn_small<true>, dim3(c.heads, ks), dim3(256), 0, s, a, lo);
-        else hipLaunchKernelGGL(k_attn_small<false>, dim3(c.heads, ks), dim3(256), 0, s, a, lo);
+        static const int nw4 = getenv("VOX_HIP_ATTN_SMALL_4W") ? 1 : 0;        // A/B: the round-2 geometry (4 waves x 8 rows)
+        if (nw4) {
+            if (e->use_dpp) hipLaunchKernelGGL((k_attn_small<true, 4>), dim3(c.heads, ks), dim3(256), 0, s, a, lo);
+            else hipLaunchKernelGGL((k_attn_small<false, 4>), dim3(c.heads, ks), dim3(256), 0, s, a, lo);
+        } else {
+            if (e->use_dpp) hipLaunchKernelGGL((k_attn_small<true, 8>), dim3(c.heads, ks), dim3(512), 0, s, a, lo);
+            else hipLaunchKernelGGL((k_attn_small<false, 8>), dim3(c.heads, ks), dim3(512), 0, s, a, lo);
+        }
         hipLaunchKernelGGL((k_attn_combine<64>), dim3(c.heads, n), dim3(64), 0, s, attn, c.QD,
                            (const float *)a.part_o, (const float *)a.part_ml, c.heads, ks);
         return 0;
@@ -1712,6 +1721,12 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     // while the other 255 workgroups may not have fetched x yet - in place that is a race that only bites when workgroups
     // of one launch start far apart (two models sharing the GPU: found by test_two_decoders_sharing_the_gpu_stay_correct).
     float *xin = e->dx, *xalt = e->dx2;
+    int tap_i = -1;
+    for (size_t i = 0; i < e->tap_pos.size(); i++) if (e->tap_pos[i] == kv_pos) tap_i = (int)i;
+    auto tap = [&](int slot, const float *src) {      // slot 2l: layer l's input, 2l + 1: after its attention block, 2L: the stack's output
+        if (tap_i < 0) return;
+        hipMemcpyAsync(e->d_taps + ((size_t)tap_i * (2 * d.dec_layers + 1) + slot) * DD, src, (size_t)DD * 4, hipMemcpyDeviceToDevice, s);
+    };
     static const int tl_layer = getenv("VOX_HIP_FUSE_TL_LAYER") ? atoi(getenv("VOX_HIP_FUSE_TL_LAYER")) : 13;
     for (int l = 0; l < d.dec_layers; l++) {
         DecLayer &L = e->dec[l];
@@ -1742,6 +1757,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 }
                 prof_mark(e, PK_QKV);
             }
+            tap(2 * l, xin);              // (layer 0 of a stream step builds x inside the launch above and writes it to xin)
             if (!(e->skip_kinds & (1u << PK_SWIGLU))) {
                 // x += sum of the wo partials -> ffn_norm * (1 + ada) -> silu(W1 x) * (W3 x)
                 W13xArgs a{};
@@ -1758,6 +1774,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 }
                 prof_mark(e, PK_SWIGLU);
             }
+            tap(2 * l + 1, xalt);         // x' = x + attention block, written by k_gemv_w13x's block 0
             if (!(e->skip_kinds & (1u << PK_W2))) {
                 static const int old_w2 = getenv("VOX_HIP_OLD_W2") ? 1 : 0;         // A/B switch: the k_gemv3 launch this replaced
                 if (old_w2) {
@@ -1800,6 +1817,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             else launch_gemv2<PRO_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
             prof_mark(e, PK_QKV);
         }
+        tap(2 * l, e->dx);
         if (!(e->skip_kinds & (1u << PK_ATTN)))
         {   // attention over the KV window (voxtral_decoder.c:667-673)
             AttnArgs a{};
@@ -1837,6 +1855,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             else launch_gemv2<PRO_NONE, EPI_RESID, 3, 8, 1, 1>(e, a);
             prof_mark(e, PK_WO);
         }
+        tap(2 * l + 1, e->dx);
         if (!(e->skip_kinds & (1u << PK_SWIGLU)))
         {   // RMSNorm * (1+ada) -> silu(W1 x) * (W3 x)
             GemvArgs a{};
@@ -1866,6 +1885,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             prof_mark(e, PK_W2);
         }
     }
+    tap(2 * d.dec_layers, xin);
     {   // final norm -> tied-embedding logits -> per-block argmax (voxtral_decoder.c:694-704)
         GemvArgs a{};
         a.W = e->tok_emb; a.x = xin; a.norm_w = e->dec_final_norm; a.eps = d.dec_eps; a.y = logits_dst;
@@ -1923,6 +1943,32 @@ static void fused_rearm_tick(vox_hip_engine *e, int steps) {
         fprintf(stderr, "vox_hip: fused decode kernel re-armed after %d time-out(s)\n", e->fuse_failures);
     }
 }
+// Debug taps of the decoder's residual stream (parity tests at the depth of the stack, not only at its logits): the decode
+// steps that run at the listed KV positions copy x at the start of every layer, x after every attention block and x after
+// the last layer - [2 L + 1][dec_dim] per position, in that order - into a device buffer, in stream order (no effect on the
+// kernels).  vox_hip_debug_tap_read fetches [n][2 L + 1][dec_dim] and ends the tapping.  n <= 16.
+extern "C" int vox_hip_debug_tap_config(vox_hip_engine_t *e, const int *positions, int n) {
+    if (!e || n < 0 || n > 16) return -1;
+    HC(hipSetDevice(e->device));
+    HC(esync(e));
+    if (e->d_taps) { hipFree(e->d_taps); e->d_taps = nullptr; }
+    e->tap_pos.clear();
+    if (n == 0) return 0;
+    const size_t elems = (size_t)n * (2 * e->d.dec_layers + 1) * e->d.dec_dim;
+    HC(hipMalloc((void **)&e->d_taps, elems * 4));
+    HC(hipMemset(e->d_taps, 0, elems * 4));
+    e->tap_pos.assign(positions, positions + n);
+    return 0;
+}
+extern "C" int vox_hip_debug_tap_read(vox_hip_engine_t *e, float *out) {
+    if (!e || !e->d_taps || !out) return -1;
+    HC(hipSetDevice(e->device));
+    HC(esync(e));
+    HC(hipMemcpy(out, e->d_taps, e->tap_pos.size() * (2 * e->d.dec_layers + 1) * e->d.dec_dim * 4, hipMemcpyDeviceToHost));
+    hipFree(e->d_taps); e->d_taps = nullptr; e->tap_pos.clear();
+    return 0;
+}
+
 // fuse_failures so far / is the fused kernel live right now / steps left of a suspension (tests, bench)
 extern "C" int vox_hip_fuse_stats(const vox_hip_engine_t *e, int *failures, int *armed, long *rearm_in) {
     if (!e) return -1;

@@ -31,8 +31,16 @@ def model_dir(preset, seed=1234):
     """Deterministic synthetic checkpoint for `preset` (generated on first use)."""
     d = os.path.join(MODEL_ROOT, f"{preset}_{seed}")
     if not os.path.exists(os.path.join(d, "tekken.json")):
+        # several processes may ask at once (the ranks of `bench.py --gpus N` on a fresh box): one generates, the others wait
+        import fcntl
         os.makedirs(MODEL_ROOT, exist_ok=True)
-        subprocess.check_call([synth_model_bin(), d, preset, str(seed)])
+        with open(os.path.join(MODEL_ROOT, f".{preset}_{seed}.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if not os.path.exists(os.path.join(d, "tekken.json")):      # tekken.json is written last (tools/synth_model.c)
+                    subprocess.check_call([synth_model_bin(), d, preset, str(seed)])
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     return d
 
 

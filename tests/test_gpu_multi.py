@@ -132,3 +132,15 @@ def test_bench_self_launches_two_ranks_and_matches_the_reference_golden():
     assert out["decoder_steps_per_pass"] == 2 * 386
     assert out["replica"]["parity_checked_ranks"] == 2 and out["replica"]["parity_mismatches_all_ranks"] == 0
     assert out["replica"]["value"] > 0 and out["value"] > 0
+
+
+def test_bench_falls_back_to_the_replica_line_when_the_sharded_pass_fails():
+    """The RCCL point-to-point path cannot run with more than one rank before the first multi-GPU node does: if it raises (or
+    hangs past its time limit) the job must still end with ONE honest JSON line - the replica figure, and what happened."""
+    env = dict(os.environ, VOX_FORCE_DIST="1", VOX_DIST_INJECT_FAIL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--preset", "small", "--seconds", "12"]
+    out = _bench_json(cmd, env)
+    assert out["sharded_pass"]["completed"] is False and "injected" in out["sharded_pass"]["reason"]
+    assert out["value"] == out["replica"]["value"] > 0 and out["config"]["parallelism"] == "1 replicas"

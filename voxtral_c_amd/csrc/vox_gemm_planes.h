@@ -41,11 +41,17 @@ constexpr int gp_stage_bytes(int TN) { return 3 * GP_PLANE_BYTES + 64 * TN * GP_
 // TN = 4 shares every A fragment between four B tiles (10 reads per 24 MFMAs).
 enum { GP_EPI_STD = 0, GP_EPI_SWIGLU = 1, GP_EPI_ROPE = 2 };
 
-template <int NSTAGE, int TN, int EPI = GP_EPI_STD>
+// BD ("B direct", round 3): the weight fragments do not go through LDS at all - a lane's B operand (W[col][k .. k + 7], 16 bytes)
+// is loaded straight from global memory into the register the MFMA reads, one slice ahead, with plain (L1-allocating) loads
+// (fragment layout: an instruction takes 32 bytes from each of 32 rows, the two k steps of a slice and the next slice share the
+// 128-byte line).  The kernel is bound by the LDS-DMA transport (~15 B/clk/CU, header): this takes the B quarter of every stage
+// (8 of 32 KB at TN = 2) off that path and a quarter of the fragment reads off the LDS.
+template <int NSTAGE, int TN, int EPI = GP_EPI_STD, bool BD = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gp_smem[];
-    constexpr int STAGE = gp_stage_bytes(TN);
+    constexpr int STAGE = BD ? 3 * GP_PLANE_BYTES : gp_stage_bytes(TN);
     constexpr int NINSTR = STAGE / 1024, IPW = NINSTR / 4;          // DMA instructions (1 KB each) per stage, per wave
+    static_assert(!BD || NSTAGE == 2, "the direct-B pipeline is written for two stages (everything of slice t is waited for at the top of iteration t)");
     constexpr int BN = 64 * TN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,6 +115,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
     const int kt1 = (a.ksplit > 1) ? min(nk_total, kt0 + a.kper) : nk_total;
     const int nk = kt1 - kt0;
 
+    // BD: this lane's weight rows (one per N tile of the wave) and the loader of a slice's fragments
+    const uint16_t *bsrc[TN];
+#pragma unroll
+    for (int tt = 0; tt < TN; tt++) {
+        const int row = wn * (32 * TN) + tt * 32 + li;               // row of the workgroup's B tile
+        int wrow = min(bn0 + row, N - 1);
+        if constexpr (EPI == GP_EPI_SWIGLU) wrow = ((row >> 5) & 1) * N + min((int)blockIdx.x * 64 + (row >> 6) * 32 + (row & 31), N - 1);
+        bsrc[tt] = a.W + (size_t)wrow * K + lg * 8;
+    }
+    uint4 bcur[TN][2], bnxt[TN][2];
+    auto load_b = [&](uint4 (&b)[TN][2], int kt) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+            for (int tt = 0; tt < TN; tt++) b[tt][k2] = *reinterpret_cast<const uint4 *>(bsrc[tt] + (size_t)kt * GP_K + k2 * 16);
+    };
+
     auto compute = [&](const unsigned char *st) {
 #pragma unroll
         for (int k2 = 0; k2 < 2; k2++) {
@@ -120,7 +143,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
                 for (int p = 0; p < 3; p++)
                     af[tt][p] = *reinterpret_cast<const bf16x8_t *>(st + p * GP_PLANE_BYTES + aoff[tt] + ((c ^ asw[tt]) << 4));
 #pragma unroll
-            for (int tt = 0; tt < TN; tt++) bf[tt] = *reinterpret_cast<const bf16x8_t *>(st + boff[tt] + ((c ^ bsw[tt]) << 4));
+            for (int tt = 0; tt < TN; tt++) {
+                if constexpr (BD) { union { uint4 u; bf16x8_t v; } cv; cv.u = bcur[tt][k2]; bf[tt] = cv.v; }
+                else bf[tt] = *reinterpret_cast<const bf16x8_t *>(st + boff[tt] + ((c ^ bsw[tt]) << 4));
+            }
 #pragma unroll
             for (int p = 2; p >= 0; p--)                       // small terms first
 #pragma unroll
@@ -130,7 +156,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][p], bf[tn], acc[tm][tn], 0, 0, 0);
         }
     };
-    {
+    if constexpr (BD) {
+        if (nk > 0) { load_b(bcur, kt0); issue(kt0, 0); }
+        for (int t = 0; t < nk; t++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice t: this wave's DMAs (issued an iteration ago) and its B fragments
+            __syncthreads();                               // everybody's part of slice t is in; everybody is done reading slice t - 1
+            if (t + 1 < nk) { load_b(bnxt, kt0 + t + 1); issue(kt0 + t + 1, (t + 1) & 1); }
+            compute(gp_smem + (size_t)(t & 1) * STAGE);
+            if (t + 1 < nk) {
+#pragma unroll
+                for (int tt = 0; tt < TN; tt++) { bcur[tt][0] = bnxt[tt][0]; bcur[tt][1] = bnxt[tt][1]; }
+            }
+        }
+    } else {
 #pragma unroll
         for (int s = 0; s < NSTAGE - 1; s++)
             if (s < nk) issue(kt0 + s, s);

@@ -242,6 +242,11 @@ struct vox_hip_engine {
     bool use_planes = true;       // large-M GEMMs on pre-split bf16 planes (k_gemm_planes)
     bool use_epi = true, use_attn_small = true, use_staged_upload = true;     // A/B switches, read once per engine (self_test)
     int gp_tn = 2;                // MFMA tiles per wave along N in k_gemm_planes (2: 128 x 128 workgroup tile, 4: 128 x 256)
+    // k_gemm_planes with the weight fragments straight from global memory to registers (VOX_HIP_GP_BDIRECT=1).  Measured and NOT
+    // kept as the default: 1627-row pass, qkv 114.8 -> 137.7 us, w1;w3 158 -> 190 us (gpurun_out/p13) - the fragment-layout loads
+    // (32 bytes from each of 32 rows per instruction, issued twice: both row halves of the tile need them) cost more than the
+    // quarter of the LDS-DMA transport they take away.
+    bool gp_bd = false;
     Buf splanes;                  // [3][n][max(D, QD, H)] bf16
     Uploader *up = nullptr;       // staged weight ingest: lives until vox_hip_upload_done (vox_load calls it) or the engine's end
     unsigned long long *d_fuse_tl = nullptr;      // VOX_HIP_FUSE_TL: [3 kernels][1024 workgroups][3] timeline of the layer-13 launches
@@ -385,14 +390,19 @@ static int launch_gemm_planes(vox_hip_engine *e, const uint16_t *Xp, size_t plan
                               int epi = GP_EPI_STD, const GemmArgs *extra = nullptr) {
     GemmArgs a{nullptr, 0, W, Y, ldy, M, N, K, bias, resid, ldr, act, 1, 0, nullptr};
     a.Xp = Xp; a.xp_plane = plane; a.ldxp = ldxp;
+    const size_t lds_bd = (size_t)2 * 3 * GP_PLANE_BYTES;          // direct-B variants: two stages of A planes only
     if (epi == GP_EPI_SWIGLU) {       // N = hidden columns, W = [w1; w3]; output = bf16 planes of the gated hidden rows
         a.Yp = extra->Yp; a.yp_plane = extra->yp_plane;
-        hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_SWIGLU>), dim3((N + 63) / 64, (M + GB_M - 1) / GB_M), dim3(256), (size_t)2 * gp_stage_bytes(2), e->stream, a);
+        const dim3 grid((N + 63) / 64, (M + GB_M - 1) / GB_M);
+        if (e->gp_bd) hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_SWIGLU, true>), grid, dim3(256), lds_bd, e->stream, a);
+        else hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_SWIGLU>), grid, dim3(256), (size_t)2 * gp_stage_bytes(2), e->stream, a);
         return 0;
     }
     if (epi == GP_EPI_ROPE) {
         a.rope_tab = extra->rope_tab; a.rope_cols = extra->rope_cols; a.head_dim = extra->head_dim;
-        hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_ROPE>), dim3((N + 127) / 128, (M + GB_M - 1) / GB_M), dim3(256), (size_t)2 * gp_stage_bytes(2), e->stream, a);
+        const dim3 grid((N + 127) / 128, (M + GB_M - 1) / GB_M);
+        if (e->gp_bd) hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_ROPE, true>), grid, dim3(256), lds_bd, e->stream, a);
+        else hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_ROPE>), grid, dim3(256), (size_t)2 * gp_stage_bytes(2), e->stream, a);
         return 0;
     }
     if (M <= 0 || N <= 0) return 0;
@@ -405,8 +415,9 @@ static int launch_gemm_planes(vox_hip_engine *e, const uint16_t *Xp, size_t plan
         ksplit = std::min(std::min(std::max(1, resident / (tm * tn)), nk / 4), 16);
         if (ksplit < 2) ksplit = 1;
     }
-    auto kern = TN == 2 ? k_gemm_planes<2, 2> : k_gemm_planes<2, 4>;
-    const size_t lds = (size_t)st * gp_stage_bytes(TN);
+    auto kern = e->gp_bd ? (TN == 2 ? k_gemm_planes<2, 2, GP_EPI_STD, true> : k_gemm_planes<2, 4, GP_EPI_STD, true>)
+                         : (TN == 2 ? k_gemm_planes<2, 2> : k_gemm_planes<2, 4>);
+    const size_t lds = e->gp_bd ? lds_bd : (size_t)st * gp_stage_bytes(TN);
     if (ksplit > 1) {
         if (ensure(e, e->ssplitk, (size_t)ksplit * M * N * 4)) return -1;
         a.ksplit = ksplit; a.kper = (nk + ksplit - 1) / ksplit; a.partial = (float *)e->ssplitk.p;
@@ -980,13 +991,21 @@ static bool skinny_ok(const vox_hip_engine *e, int n, const RowsCfg &c) {
 }
 static int skinny_split(int K) { return std::max(1, std::min(16, (K / 64) / SK_WPB)); }      // one chunk per wave when K allows
 
+static int launch_rowsgemm(vox_hip_engine *e, const uint16_t *Xp, size_t xp_plane, const float *X, int ldx, int n,
+                           const uint16_t *W, int N, int K, float *partial);
+static size_t rg_partial_bytes(int n, int N, int K);
+
 static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
     const RowsCfg c = enc_cfg(e);
     const int N3 = c.QD + 2 * c.KVD, L = e->d.enc_layers, pos0 = e->enc_pos;
     float *xn = (float *)e->sxn.p, *qkv = (float *)e->sqkv.p, *attn = (float *)e->sattn.p, *tab = (float *)e->srope.p;
     hipStream_t s = e->stream;
     const int so = skinny_split(c.QD), s2 = skinny_split(c.H);
-    if (ensure(e, e->ssplitk, (size_t)std::max(so, s2) * n * c.D * 4)) return -1;
+    // A/B (VOX_HIP_SK_W2_RG): w2 on k_rowsgemm - measured 9.1 vs 10.2 us for the launch, but its 20 K splits (10 here) cost
+    // k_rows_finish 7.4 instead of 5.9 us: no gain at 25 rows (gpurun_out/p12)
+    static const int sk_w2_rg = getenv("VOX_HIP_SK_W2_RG") ? 1 : 0;
+    const bool w2_rg = e->use_rowsgemm && sk_w2_rg;
+    if (ensure(e, e->ssplitk, std::max((size_t)std::max(so, s2) * n * c.D * 4, w2_rg ? rg_partial_bytes(n, c.D, c.H) : (size_t)0))) return -1;
     // bf16 planes of the normalised rows [3][n][D] and of the gated hidden rows [3][n][H] (sgu is free on this path)
     if (ensure(e, e->sgu, (size_t)3 * n * (c.D + c.H) * 2)) return -1;
     uint16_t *xnp = (uint16_t *)e->sgu.p, *hp = xnp + (size_t)3 * n * c.D;
@@ -1020,11 +1039,16 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
             hipLaunchKernelGGL((k_skinny<SK_SWIGLU, 1, true>), dim3(c.H / 32, 1), dim3(64 * SK_WPB), lds2, s, a);
         }
         {   // w2 partials, then x += . + b2 and the next norm (next layer's attention_norm, or the final norm into `out`)
-            SkinnyArgs a{}; a.dbg = sk_dbg;
-            a.Xp = hp; a.xp_plane = (size_t)n * c.H; a.n = n; a.W = Ly.w2; a.N = c.D; a.K = c.H; a.partial = part;
-            hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, true>), dim3(c.D / 32, s2), dim3(64 * SK_WPB), lds1, s, a);
+            int s2n = s2;
+            if (w2_rg) {
+                s2n = launch_rowsgemm(e, hp, (size_t)n * c.H, nullptr, 0, n, Ly.w2, c.D, c.H, part);
+            } else {
+                SkinnyArgs a{}; a.dbg = sk_dbg;
+                a.Xp = hp; a.xp_plane = (size_t)n * c.H; a.n = n; a.W = Ly.w2; a.N = c.D; a.K = c.H; a.partial = part;
+                hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, true>), dim3(c.D / 32, s2), dim3(64 * SK_WPB), lds1, s, a);
+            }
             const bool last = l + 1 == L;
-            hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)part, s2, n, c.D, (const float *)Ly.b2,
+            hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)part, s2n, n, c.D, (const float *)Ly.b2,
                                (const float *)(last ? e->enc_final_norm : e->enc[l + 1].n1), c.eps, last ? out : xn, c.D,
                                last ? (uint16_t *)nullptr : xnp);
         }
@@ -2503,6 +2527,7 @@ static int self_test(vox_hip_engine *e) {
     if (getenv("VOX_HIP_NO_BF16X3")) e->use_bf16x3 = false;
     {   // (2b) the planes GEMM (pre-split activations, LDS-DMA pipeline) on the same problem, with and without split-K
         if (getenv("VOX_HIP_GP_TN")) e->gp_tn = atoi(getenv("VOX_HIP_GP_TN")) == 4 ? 4 : 2;
+        if (getenv("VOX_HIP_GP_BDIRECT")) e->gp_bd = true;
         bool okp = hipFuncSetAttribute((const void *)k_gemm_planes<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(2)) == hipSuccess &&
                    hipFuncSetAttribute((const void *)k_gemm_planes<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(4)) == hipSuccess &&
                    hipFuncSetAttribute((const void *)k_gemm_planes<2, 2, GP_EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(2)) == hipSuccess &&

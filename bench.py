@@ -150,8 +150,12 @@ def cpu_baseline(model_dir_full, preset_dims):
         est = t_enc * 1696 / 100 + t_pre + 386 * t_step
         measured = None
         try:       # the unmodified reference CLI run end to end on a GPU-box host (tools/cpu_baseline_cli.py), committed per round
-            with open(os.path.join(ROOT, "profiles", "r02_cpu_baseline_cli.json")) as fh:
-                measured = json.load(fh)
+            for prof in ("r03_cpu_baseline_cli.json", "r02_cpu_baseline_cli.json"):
+                fp = os.path.join(ROOT, "profiles", prof)
+                if os.path.exists(fp):
+                    with open(fp) as fh:
+                        measured = dict(json.load(fh), source="profiles/" + prof)
+                    break
         except Exception:
             pass
         return {"value": round(est / 30.0, 2), "unit": "wall s / audio s (RTF), 30 s clip, extrapolated from the sample",
@@ -224,7 +228,7 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True):
         traffic, traffic_source = live_pmc_traffic(DOM_KERNEL_SUBSTR)
     if traffic is None:
         why = traffic_source
-        for prof in ("r02_pmc_decode_summary.json", "r01_pmc_decode_summary.json"):
+        for prof in ("r03_pmc_decode_summary.json", "r02_pmc_decode_summary.json", "r01_pmc_decode_summary.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", prof)) as fh:
                     pm = json.load(fh)["kernels"]

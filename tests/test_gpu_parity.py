@@ -836,3 +836,70 @@ def test_decoder_residual_stream_matches_reference_at_every_layer(vox):
     diag("taps_full_batch", fused=fused, worst_rel=float(rel.max()), worst_abs=float(err.max()),
          rel_by_tap=rel.max(axis=0), scale_by_tap=scale.max(axis=0))
     assert scale.min() > 1e-3 and rel.max() < 2e-4, (float(rel.max()), np.unravel_index(rel.argmax(), rel.shape))
+
+
+# ---------------------------------------------------------------------------------------
+# k_rowsgemm (vox_rowsgemm.h): the 1 .. 128-row weight-streaming GEMM of the decoder prefill and the encoder flush pass
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N", [(1, 1280, 256), (16, 1280, 6144), (17, 1280, 6144), (25, 5120, 1280), (32, 2048, 1280), (33, 1280, 10240),
+                                   (38, 3072, 6144), (38, 9216, 3072), (64, 4096, 3072), (65, 1280, 1000), (68, 5120, 1280),
+                                   (96, 1280, 2048), (97, 3072, 18432), (128, 1280, 1280), (7, 192, 96)])
+def test_rowsgemm_matches_the_scalar_reference_kernel(tiny, M, K, N):
+    """Both activation forms (4: producer-split bf16 planes by LDS-DMA, 5: f32 rows split in the kernel) against the plain fp32
+    FMA kernel (impl 3) on the same device: every 32-row tile count (1 .. 4), row counts around the tile edges (the accumulator
+    registers a straight-line MFMA body must not read early: rows 16 .. 31 at one tile were wrong in the first version), both
+    workgroup widths (N < 2048: 4 waves), one and two weight tiles per wave (N >= 4096 at <= 64 rows), K ranges that do not
+    divide evenly into rounds, N that is not a multiple of the workgroup's 128 / 256 / 512 rows."""
+    rng = np.random.default_rng(M * 131 + K + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = vo.f32_to_bf16((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    b = rng.standard_normal(N).astype(np.float32)
+    ref = tiny.linear_bf16(x, w, b, impl=3)
+    for impl in (4, 5):
+        y = tiny.linear_bf16(x, w, b, impl=impl)
+        err = float(np.abs(y - ref).max())
+        assert err < 5e-5, (impl, err, np.nonzero(np.abs(y - ref).max(axis=1) > 5e-5)[0][:16])
+
+
+def test_few_rows_paths_agree_with_the_large_m_paths(vox):
+    """The same encoder chunks (1 .. 128 rows, after a big first chunk and on a cold window) and the same decoder prefills
+    (1 .. 128 rows, then three greedy steps) on two engines of one process: one with the k_rowsgemm path switched off
+    (VOX_HIP_NO_ROWSGEMM: <= 32 rows on k_skinny, more on the 128 x 128 GEMM tiles), one with it on for every size
+    (VOX_HIP_RG_SMALL).  Same arithmetic up to summation order: 2e-5 relative."""
+    os.environ["VOX_HIP_NO_ROWSGEMM"] = "1"
+    try:
+        ma = vox.Model(model_dir("small"))
+    finally:
+        del os.environ["VOX_HIP_NO_ROWSGEMM"]
+    os.environ["VOX_HIP_RG_SMALL"] = "1"
+    try:
+        mb = vox.Model(model_dir("small"))
+    finally:
+        del os.environ["VOX_HIP_RG_SMALL"]
+    d = ma.dims
+    worst = 0.0
+    try:
+        for sizes in ([25, 25, 25], [1], [17], [32], [33], [38, 64, 68], [96, 100, 128, 3], [800, 25, 68, 129, 31]):
+            outs = []
+            for m in (ma, mb):
+                m.reset_encoder(); m.reset_counters()
+                rr = np.random.default_rng(sum(sizes))
+                outs.append([m.encoder_forward_incremental(rr.standard_normal((n, d.enc_dim)).astype(np.float32)) for n in sizes])
+            for n, a, b in zip(sizes, outs[0], outs[1]):
+                e = float(np.abs(a - b).max() / (np.abs(a).max() + 1e-30))
+                worst = max(worst, e)
+                assert e < 2e-5, ("encoder", sizes, n, e)
+        for n in (1, 2, 31, 38, 64, 65, 100, 128, 129):
+            res = []
+            for m in (ma, mb):
+                m.reset_counters()
+                rr = np.random.default_rng(100 + n)
+                emb = (rr.standard_normal((n + 3, d.dec_dim)) * 0.5).astype(np.float32)
+                m.decoder_prefill(emb[:n])
+                res.append(np.stack([m.decoder_forward(emb[n + i])[1] for i in range(3)]))
+            e = float(np.abs(res[0] - res[1]).max() / (np.abs(res[0]).max() + 1e-30))
+            worst = max(worst, e)
+            assert e < 2e-5, ("prefill", n, e)
+    finally:
+        ma.close(); mb.close()
+    diag("few_rows_paths", worst_rel=worst)

@@ -69,6 +69,7 @@ struct DecFuseArgs {
     unsigned long long *trace;       // optional (tuning): [2 blocks][16] wall-clock stamps of the phases, blocks 0 and 255
     int spread_groups;               // test switch: group = blockIdx / 32 (members spread over all XCDs) instead of blockIdx % 8
     int wo_serial_reduce;            // A/B switch: the round-2 per-row wave reductions of the Wo partial product
+    int merge_three_trips;           // A/B switch: long-context merge with the (max, sum) and the value fetches one after the other
     unsigned long long *tl;          // optional (tuning): per-workgroup timeline, see tl_begin / tl_end
 };
 // stamps stay in registers until the end (no stores in the middle of the memory schedule)
@@ -477,6 +478,14 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
             // all slices, 16 in flight, and adds them up in slice order.
             float *mlv = xs + 2080;                    // [32 slices][4 heads][2]
             float *scl = xs + 2080 + 256;              // [4 heads][32 slices]
+            // Round 3: the thread's own (head, dim) granules of all slices are requested BEFORE the (max, sum) pairs are waited
+            // for - loads return in order, so the two fetches share one trip to L2 instead of following each other (the merge
+            // took 4.6 us at 1900 keys, profiles/r02_fuse_timeline_kv1900.txt).  VOX_HIP_FUSE_MERGE3 = the old three trips.
+            u64 gv[32];
+            if (!a.merge_three_trips) {
+#pragma unroll
+                for (int u = 0; u < 32; u++) gv[u] = df_load_granule(gp + (size_t)min(u, ns - 1) * DF_GP + h * DF_HD + d);
+            }
             if (tid < ns * 8) {
                 const u64 *src = gp + (size_t)(tid >> 3) * DF_GP + 4 * DF_HD + (tid & 7);
                 mlv[tid] = df_wait_granule(src, epoch, a, 2u);
@@ -496,12 +505,13 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
             }
             __syncthreads();
             {
-                u64 gv[32];
                 const unsigned long long t0 = wall_clock64();
                 for (unsigned it = 0;; it++) {
                     bool ok = true;
+                    if (it > 0 || a.merge_three_trips) {
 #pragma unroll
-                    for (int u = 0; u < 32; u++) gv[u] = df_load_granule(gp + (size_t)min(u, ns - 1) * DF_GP + h * DF_HD + d);
+                        for (int u = 0; u < 32; u++) gv[u] = df_load_granule(gp + (size_t)min(u, ns - 1) * DF_GP + h * DF_HD + d);
+                    }
 #pragma unroll
                     for (int u = 0; u < 32; u++) ok = ok && (unsigned)(gv[u] >> 32) == epoch;
                     if (ok) break;

@@ -924,6 +924,9 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
     return 0;
 }
 
+// k_rows_finish: one float4 column group per thread (whole waves, at most 1024 threads)
+static inline int rf_threads(int D) { return std::min(1024, std::max(64, ((D / 4 + 63) / 64) * 64)); }
+
 static RowsCfg enc_cfg(const vox_hip_engine *e) {
     const vox_hip_dims_t &d = e->d;
     return RowsCfg{d.enc_dim, e->enc_qd, e->enc_qd, d.enc_hidden, d.enc_heads, d.enc_heads, d.enc_head_dim,
@@ -1013,7 +1016,7 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
     const size_t lds1 = (size_t)SK_WPB * 4096, lds2 = (size_t)SK_WPB * 2 * 4096;
     static const int sk_dbg = getenv("VOX_HIP_SK_DBG") ? atoi(getenv("VOX_HIP_SK_DBG")) : 0;      // tuning only: wrong results
     if (L > 0)      // attention_norm of layer 0 (no partials, no bias: x is left as it is)
-        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)nullptr, 0, n, c.D, (const float *)nullptr,
+        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)nullptr, 0, n, c.D, (const float *)nullptr,
                            (const float *)e->enc[0].n1, c.eps, xn, c.D, xnp);
     for (int l = 0; l < L; l++) {
         EncLayer &Ly = e->enc[l];
@@ -1029,7 +1032,7 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
             SkinnyArgs a{}; a.dbg = sk_dbg;
             a.X = attn; a.ldx = c.QD; a.n = n; a.W = Ly.wo; a.N = c.D; a.K = c.QD; a.partial = part;
             hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, false>), dim3(c.D / 32, so), dim3(64 * SK_WPB), lds1, s, a);
-            hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)part, so, n, c.D, (const float *)Ly.bo,
+            hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, so, n, c.D, (const float *)Ly.bo,
                                (const float *)Ly.n2, c.eps, xn, c.D, xnp);
         }
         {   // silu(xn w1^T) * (xn w3^T), written as bf16 planes for the w2 launch
@@ -1048,7 +1051,7 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
                 hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, true>), dim3(c.D / 32, s2), dim3(64 * SK_WPB), lds1, s, a);
             }
             const bool last = l + 1 == L;
-            hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)part, s2n, n, c.D, (const float *)Ly.b2,
+            hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, s2n, n, c.D, (const float *)Ly.b2,
                                (const float *)(last ? e->enc_final_norm : e->enc[l + 1].n1), c.eps, last ? out : xn, c.D,
                                last ? (uint16_t *)nullptr : xnp);
         }
@@ -1172,7 +1175,7 @@ static int rows_mid_layers(vox_hip_engine *e, float *x, int n, int pos0, const R
         return which ? e->dec[l].n2 : e->dec[l].n1;
     };
     if (L > 0)
-        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)nullptr, 0, n, c.D, (const float *)nullptr,
+        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)nullptr, 0, n, c.D, (const float *)nullptr,
                            norm_of(0, 0), c.eps, (float *)nullptr, 0, xnp, (const float *)nullptr);
     for (int l = 0; l < L; l++) {
         const uint16_t *wqkv = is_enc ? e->enc[l].wqkv : e->dec[l].wqkv, *wo = is_enc ? e->enc[l].wo : e->dec[l].wo;
@@ -1192,14 +1195,14 @@ static int rows_mid_layers(vox_hip_engine *e, float *x, int n, int pos0, const R
             }
         } else if (dec_attention_rows(e, c, qkv, attn, n, pos0, kring, vring, ring_cap)) return -1;
         S = launch_rowsgemm(e, nullptr, 0, attn, c.QD, n, wo, c.D, c.QD, part);
-        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)part, S, n, c.D, bo,
+        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, S, n, c.D, bo,
                            norm_of(l, 1), c.eps, (float *)nullptr, 0, xnp, ada);
         S = launch_rowsgemm(e, xnp, (size_t)n * c.D, nullptr, 0, n, w13, 2 * c.H, c.D, part);
         hipLaunchKernelGGL(k_swiglu_finish, dim3(grid1d((size_t)n * c.H / 4)), dim3(256), 0, s, hp, (size_t)n * c.H, (const float *)part, S, n, c.H);
         S = launch_rowsgemm(e, hp, (size_t)n * c.H, nullptr, 0, n, w2, c.D, c.H, part);
         const bool last = l + 1 == L;
         const float *next_norm = last ? (is_enc ? e->enc_final_norm : (const float *)nullptr) : norm_of(l + 1, 0);
-        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(256), 0, s, x, c.D, (const float *)part, S, n, c.D, b2,
+        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, S, n, c.D, b2,
                            next_norm, c.eps, last ? out : (float *)nullptr, c.D, last ? (uint16_t *)nullptr : xnp, (const float *)nullptr);
     }
     if (L == 0 && out)
@@ -1231,13 +1234,31 @@ static int encoder_rows_dev(vox_hip_engine *e, float *x, int n, float *out) {
     return 0;
 }
 
+// y[M][N] = act(x[M][K] . W^T + bias) for the small GEMMs around the encoder stack (conv stem as im2col GEMMs, adapter):
+// at streaming sizes (M = 6 .. 50 rows, 10 - 31 MB of weights each) the 128 x 128 tiles + split-K took 18 - 52 us per launch;
+// <= 32 rows go through k_rowsgemm (f32 rows split in the kernel) + the same fixed-order reduce with the fused epilogue.
+static int gemm_small_rows(vox_hip_engine *e, const float *X, int ldx, const uint16_t *W, float *Y, int ldy, int M, int N, int K,
+                           const float *bias, int act) {
+    static const bool off = getenv("VOX_HIP_NO_RG_SMALLGEMM") != nullptr;       // A/B
+    // (<= 32 rows only: conv1 13.9 -> 10.7 us, adapter0 19.6 -> 14.9 us at 25 / 6 rows; at the flush pass's 34 - 68 rows the whole
+    // encode got 0.14 ms SLOWER on the 2-layer model - gpurun_out/p14 - so those stay on the 128 x 128 tiles)
+    if (!off && e->use_rowsgemm && e->use_mfma && M >= 1 && M <= 32 && K % 64 == 0 && ldx % 4 == 0) {
+        if (ensure(e, e->ssplitk, rg_partial_bytes(M, N, K))) return -1;
+        const int S = launch_rowsgemm(e, nullptr, 0, X, ldx, M, W, N, K, (float *)e->ssplitk.p);
+        GemmArgs a{nullptr, 0, W, Y, ldy, M, N, K, bias, nullptr, 0, act, S, 0, (float *)e->ssplitk.p};
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((size_t)M * N)), dim3(256), 0, e->stream, a);
+        return 0;
+    }
+    return launch_gemm(e, X, ldx, W, Y, ldy, M, N, K, bias, nullptr, 0, act);
+}
+
 // Adapter on device: in [m*4, enc_dim] contiguous == [m, 4*enc_dim]; out [m, dec_dim].
 static int adapter_dev(vox_hip_engine *e, const float *in, int m, float *out) {
     const int DD = e->d.dec_dim, K0 = e->d.enc_dim * 4;
     if (ensure(e, e->smid, (size_t)m * DD * 4)) return -1;
     float *mid = (float *)e->smid.p;
-    if (launch_gemm(e, in, K0, e->adapter0, mid, DD, m, DD, K0, nullptr, nullptr, 0, ACT_GELU)) return -1;
-    if (launch_gemm(e, mid, DD, e->adapter1, out, DD, m, DD, DD, nullptr, nullptr, 0, ACT_NONE)) return -1;
+    if (gemm_small_rows(e, in, K0, e->adapter0, mid, DD, m, DD, K0, nullptr, ACT_GELU)) return -1;
+    if (gemm_small_rows(e, mid, DD, e->adapter1, out, DD, m, DD, DD, nullptr, ACT_NONE)) return -1;
     LAUNCH_CHECK("adapter launches");
     return 0;
 }
@@ -1293,7 +1314,7 @@ static int conv_stem_dev(vox_hip_engine *e, int n, float **xout) {
     float *col = (float *)e->sim2col.p;
     hipLaunchKernelGGL(k_im2col3, dim3(grid1d((size_t)n * MB * 3)), dim3(256), 0, s, col, (const float *)in0, n, MB, 1);
     float *c0_new = in1 + (size_t)(1 + e->c0_carry) * ED;
-    if (launch_gemm(e, col, MB * 3, e->conv0_w, c0_new, ED, n, ED, MB * 3, e->conv0_b, nullptr, 0, ACT_GELU)) return -1;
+    if (gemm_small_rows(e, col, MB * 3, e->conv0_w, c0_new, ED, n, ED, MB * 3, e->conv0_b, ACT_GELU)) return -1;
     // roll the mel history: rows 0,1 <- last two frames seen. n == 1 reproduces the
     // reference's tail update, which zeroes the older slot (voxtral.c:604-609, tc == 1).
     if (n >= 2) {
@@ -1323,7 +1344,7 @@ static int conv_stem_dev(vox_hip_engine *e, int n, float **xout) {
         hipLaunchKernelGGL(k_im2col3, dim3(grid1d((size_t)nq * ED * 3)), dim3(256), 0, s, col, (const float *)in1, nq, ED, 2);
         if (ensure(e, e->sx, (size_t)nq * ED * 4)) return -1;
         float *x = (float *)e->sx.p;
-        if (launch_gemm(e, col, ED * 3, e->conv1_w, x, ED, nq, ED, ED * 3, e->conv1_b, nullptr, 0, ACT_GELU)) return -1;
+        if (gemm_small_rows(e, col, ED * 3, e->conv1_w, x, ED, nq, ED, ED * 3, e->conv1_b, ACT_GELU)) return -1;
         *xout = x;
         // history row <- last consumed conv0 frame; carry row <- odd leftover
         HC(hipMemcpyAsync(in1, in1 + (size_t)(2 * nq) * ED, (size_t)ED * 4, hipMemcpyDeviceToDevice, s));
@@ -1771,6 +1792,10 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.spread_groups = spread;
                 static const int serial_wo = getenv("VOX_HIP_FUSE_SERIAL_WO") ? 1 : 0;
                 a.wo_serial_reduce = serial_wo;
+                static const int merge3 = getenv("VOX_HIP_FUSE_MERGE3") ? 1 : 0;
+                // (one shared trip pays while a member's slice is one 64-key tile - 1.576 vs 1.589 ms per step at 1900 keys; with
+                // two tiles per member the members finish further apart, the early loads miss and are repeated: 1.731 vs 1.710 at 3800)
+                a.merge_three_trips = merge3 || f_split > 64;
                 const bool emb = (l == 0 && build_embed);
                 if (e->use_dpp) {
                     if (emb) hipLaunchKernelGGL((k_dec_attn_fused<true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);

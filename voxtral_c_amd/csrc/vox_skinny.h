@@ -246,25 +246,28 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
 // x[m] += bias + sum_s partial[s][m]  (split order), then out_norm[m] = rmsnorm(x[m]) * w (+ada) — one block per row.
 // Covers "x += wo(attn) + bo -> ffn_norm" and "x += w2(h) + b2 -> next layer's attention_norm / the final norm".
 // planes (optional): the normalised row also as bf16 planes [3][n][D] for the XS skinny launches that consume it.
-__global__ __launch_bounds__(256) void k_rows_finish(float *x, int ldx, const float *partial, int nsplit, int n, int D,
-                                                     const float *bias, const float *norm_w, float eps, float *out_norm, int ldo,
-                                                     uint16_t *planes, const float *ada = nullptr) {
-    __shared__ float red[4];
-    const int m = blockIdx.x, tid = threadIdx.x;
+// block = one row, blockDim = a multiple of 64 up to 1024 (the launchers use D / 4 threads: one float4 column group per
+// thread, so that all of a row's partial loads are in flight together - with 256 threads a 3072-wide row of the decoder took
+// three passes of up to three load batches each: 8.7 us for 24 splits).
+__global__ __launch_bounds__(1024) void k_rows_finish(float *x, int ldx, const float *partial, int nsplit, int n, int D,
+                                                      const float *bias, const float *norm_w, float eps, float *out_norm, int ldo,
+                                                      uint16_t *planes, const float *ada = nullptr) {
+    __shared__ float red[16];
+    const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     float *xr = x + (size_t)m * ldx;
     float ss = 0.f;
-    for (int i = tid * 4; i < D; i += 1024) {
+    for (int i = tid * 4; i < D; i += nth * 4) {
         float4 v = *reinterpret_cast<const float4 *>(xr + i);
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         // The partials were written by other CUs' previous kernel: every load is a trip to L2 / memory (~1 us).  Request a
-        // batch of 8 before adding any of them (clamped index + select instead of a branch, so that the loads do not end up
+        // batch of 16 before adding any of them (clamped index + select instead of a branch, so that the loads do not end up
         // behind a wait one by one: 10 splits took 8.8 us that way); the additions stay in split order.
-        for (int z0 = 0; z0 < nsplit; z0 += 8) {
-            float4 p[8];
+        for (int z0 = 0; z0 < nsplit; z0 += 16) {
+            float4 p[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) p[u] = *reinterpret_cast<const float4 *>(partial + ((size_t)min(z0 + u, nsplit - 1) * n + m) * D + i);
+            for (int u = 0; u < 16; u++) p[u] = *reinterpret_cast<const float4 *>(partial + ((size_t)min(z0 + u, nsplit - 1) * n + m) * D + i);
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 16; u++) {
                 const bool on = z0 + u < nsplit;
                 s.x += on ? p[u].x : 0.f; s.y += on ? p[u].y : 0.f; s.z += on ? p[u].z : 0.f; s.w += on ? p[u].w : 0.f;
             }
@@ -278,9 +281,11 @@ __global__ __launch_bounds__(256) void k_rows_finish(float *x, int ldx, const fl
     ss = wave_sum(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
-    const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)D + eps);
+    float tot = 0.f;
+    for (int w = 0; w < (nth >> 6); w++) tot += red[w];
+    const float inv = 1.0f / sqrtf(tot / (float)D + eps);
     float *orow = out_norm ? out_norm + (size_t)m * ldo : nullptr;
-    for (int i = tid * 4; i < D; i += 1024) {
+    for (int i = tid * 4; i < D; i += nth * 4) {
         const float4 v = *reinterpret_cast<const float4 *>(xr + i);      // own elements, written above by this thread
         const float4 g = *reinterpret_cast<const float4 *>(norm_w + i);
         float4 o = make_float4(v.x * inv * g.x, v.y * inv * g.y, v.z * inv * g.z, v.w * inv * g.w);

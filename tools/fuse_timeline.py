@@ -41,6 +41,11 @@ if r.shape[1] >= 19:
         att = m & (st[:, 7] - st[:, 6] > 0.3)
         print(f"   g{g}: {st[m, 5].max():6.2f} | {st[m, 6].min():6.2f}..{st[m, 6].max():6.2f} | {st[att, 7].max() if att.any() else -1:6.2f} ({int(att.sum())} members) | "
               f"{st[m, 8].min():6.2f}..{st[m, 8].max():6.2f} | {r[m, 3].max():6.2f}")
+    print("   attention members of groups 0 and 1 (j: dots done, published, sweep1 done, [first tile in, scores done,] attention end | the group's last publish):")
+    for g in (0, 1):
+        m = (blk % 8) == g
+        for i in np.nonzero(m & (st[:, 7] - st[:, 6] > 0.3))[0]:
+            print(f"   g{g} j{blk[i] // 8}: {st[i, 4]:6.2f} {st[i, 5]:6.2f} {st[i, 6]:6.2f} [{st[i, 11]:6.2f} {st[i, 12]:6.2f}] {st[i, 7]:6.2f} | {st[m, 5].max():6.2f}")
 r = rows[rows[:, 0] == 1]
 if r.shape[1] >= 11:
     st = r[:, 6:11]

@@ -70,6 +70,7 @@ struct DecFuseArgs {
     int spread_groups;               // test switch: group = blockIdx / 32 (members spread over all XCDs) instead of blockIdx % 8
     int wo_serial_reduce;            // A/B switch: the round-2 per-row wave reductions of the Wo partial product
     int merge_three_trips;           // A/B switch: long-context merge with the (max, sum) and the value fetches one after the other
+    int attn_gqa;                    // round 3: K / V tiles read from LDS once for the 4 heads of a group (0 = once per head, A/B)
     unsigned long long *tl;          // optional (tuning): per-workgroup timeline, see tl_begin / tl_end
 };
 // stamps stay in registers until the end (no stores in the middle of the memory schedule)
@@ -85,6 +86,7 @@ __device__ __forceinline__ u64 df_load_granule(const u64 *g) {
 // Once ANY wait of ANY launch has timed out (*err != 0: e.g. the 256 workgroups were not co-resident because another
 // process or stream held CUs), every later wait gives up at once: the launches already queued behind the failure then
 // drain in microseconds instead of one time-out each, and the host re-runs the batch on the launch-per-GEMV chain.
+//
 __device__ __forceinline__ float df_wait_granule(const u64 *g, unsigned epoch, const DecFuseArgs &a, unsigned code) {
     u64 v = df_load_granule(g);
     if ((unsigned)(v >> 32) != epoch) {
@@ -144,19 +146,22 @@ constexpr int DF_LDS_BYTES = 2 * DF_D * 4 + 4 * DF_TILE_BYTES + 1024 + 512;
 // 16-byte broadcast read of one valid address, so that every workgroup issues the same number of memory operations and
 // the hand-counted s_waitcnt values below hold for all of them.
 __device__ __forceinline__ void df_tile_op(const DecFuseArgs &a, int g, int t0, int last, unsigned kt_lds, unsigned vt_lds, int wave, int lane,
-                                           int k, bool real) {
+                                           int k, bool real, int slot0) {
     const int pair = 4 * wave + (k >> 1);
     const int key = 2 * pair + (lane >> 5);
-    int t = t0 + key; if (t > last) t = last;
-    const size_t row = (size_t)(t % a.kv_cap) * DF_DKV + g * DF_HD;
+    // ring slot of key t0 + key (clamped to last): slot0 = t0 % kv_cap is computed once per tile by the caller (a 32-bit
+    // modulo per lane and operation cost the attention members ~0.3 us right in front of their publish)
+    int sl = slot0 + min(key, last - t0); if (sl >= a.kv_cap) sl -= a.kv_cap;
+    const size_t row = (size_t)sl * DF_DKV + g * DF_HD;
     const int cs = lane & 31;
     const float *src = (k & 1) ? a.vring + row + (cs << 2) : a.kring + row + ((cs ^ (key & 31)) << 2);
     if (!real) src = a.kring;
     glds16(src, ((k & 1) ? vt_lds : kt_lds) + (unsigned)pair * 1024u);
 }
 __device__ __forceinline__ void df_tile_dma(const DecFuseArgs &a, int g, int t0, int last, unsigned kt_lds, unsigned vt_lds, int wave, int lane) {
+    const int slot0 = __builtin_amdgcn_readfirstlane(t0 % a.kv_cap);
 #pragma unroll
-    for (int k = 0; k < 8; k++) df_tile_op(a, g, t0, last, kt_lds, vt_lds, wave, lane, k, true);
+    for (int k = 0; k < 8; k++) df_tile_op(a, g, t0, last, kt_lds, vt_lds, wave, lane, k, true, slot0);
 }
 
 template <bool EMBED, bool USE_DPP>
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     const unsigned char *wo_base = reinterpret_cast<const unsigned char *>(a.wo) + (size_t)(DF_NQ * g) * 2 + lane * 16;
 #define DF_WO_PTR(i) (wo_base + (size_t)min(wo_row0 + (i), wo_rmax) * (DF_DQ * 2))
     const int tile_last = att_block ? s_hi : 0;
+    const int tile_slot0 = __builtin_amdgcn_readfirstlane(att_block ? s_lo % a.kv_cap : 0);
     DF_MARK(1);
 
     // ---- the activation vector -----------------------------------------------------------------------------------
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
             if (blockIdx.x == 0) *reinterpret_cast<float4 *>(a.x_out + e) = v;
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) df_tile_op(a, g, s_lo, tile_last, lds_addr(tiles), lds_addr(tiles + DF_TILE_BYTES), wave, lane, k, att_block);
+        for (int k = 0; k < 8; k++) df_tile_op(a, g, s_lo, tile_last, lds_addr(tiles), lds_addr(tiles + DF_TILE_BYTES), wave, lane, k, att_block, tile_slot0);
 #pragma unroll
         for (int i = 0; i < 16; i++) wv[i] = ld_stream(reinterpret_cast<const uint4 *>(DF_WO_PTR(i)));
         asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     if (att_block) {
         if constexpr (!EMBED) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) df_tile_op(a, g, s_lo, tile_last, lds_addr(tiles), lds_addr(tiles + DF_TILE_BYTES), wave, lane, k, true);
+            for (int k = 0; k < 8; k++) df_tile_op(a, g, s_lo, tile_last, lds_addr(tiles), lds_addr(tiles + DF_TILE_BYTES), wave, lane, k, true, tile_slot0);
         }
     }
 #undef DF_PIECE
@@ -365,7 +371,9 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     }
     __syncthreads();                       // xs / nw are dead from here on: 24 KB of scratch for the attention stage
     DF_MARK(5);
-    if (!att_block) { DF_LATE_WO(0) DF_LATE_WO(4) DF_LATE_WO(8) DF_LATE_WO(12) }
+    if (!att_block) {
+        DF_LATE_WO(0) DF_LATE_WO(4) DF_LATE_WO(8) DF_LATE_WO(12)
+    }
 
     float *qs = xs;                        // [512] the group's q
     float *kvn = xs + 512;                 // [256] this step's k | v of head g
@@ -373,6 +381,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     float *sc = xs + 1280;                 // [4 heads][2 halves][64 keys] partial scores
     float *pt = xs + 1792;                 // [4 heads][64 keys] softmax numerators of the current tile
     float *cr = xs + 2048;                 // [4] rescale of the running output, [4] running max, [4] running sum
+    float *sc8 = xs + 2560;                // [4 heads][8 dim slices][64 keys] partial scores, then [4 key quarters][4 heads][128] partial outputs
 
     // ---- hand-off 1 (attention members only): sweep the group's 768 granules ------------------------------------------------
     if (att_block) {
@@ -413,6 +422,76 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
                 if (tid < 32) *reinterpret_cast<float4 *>(kt + key * 512 + ((tid ^ (key & 31)) << 4)) = *reinterpret_cast<const float4 *>(kvn + tid * 4);
                 else if (tid < 64) *reinterpret_cast<float4 *>(vt + key * 512 + ((tid - 32) << 4)) = *reinterpret_cast<const float4 *>(kvn + DF_HD + (tid - 32) * 4);
                 __syncthreads();
+            }
+            if (ti == 0) DF_MARK(11);
+            if (a.attn_gqa) {
+                // Round 3: K and V rows are read from LDS ONCE for the 4 query heads that share them (they were read once per head:
+                // 2 x 128 KB of LDS traffic per tile, ~0.9 us of the 2.4 us a member spent between its sweep and its partial).
+                //   scores: wave -> 16 of the 128 dims for all 4 heads, lane -> key; the 8 partial sums per (head, key) meet in LDS;
+                //   PV: thread -> (quarter of the tile's keys, dim) for all 4 heads; the 4 quarter sums meet in LDS.
+                {
+                    const unsigned char *krow = kt + lane * 512;
+                    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int ch = 4 * wave + c;
+                        const float4 kv4 = *reinterpret_cast<const float4 *>(krow + ((ch ^ (lane & 31)) << 4));
+#pragma unroll
+                        for (int hh = 0; hh < 4; hh++) {
+                            const float4 q4 = *reinterpret_cast<const float4 *>(qs + hh * DF_HD + ch * 4);
+                            s4[hh] = fmaf(q4.x, kv4.x, s4[hh]); s4[hh] = fmaf(q4.y, kv4.y, s4[hh]);
+                            s4[hh] = fmaf(q4.z, kv4.z, s4[hh]); s4[hh] = fmaf(q4.w, kv4.w, s4[hh]);
+                        }
+                    }
+#pragma unroll
+                    for (int hh = 0; hh < 4; hh++) sc8[(hh * 8 + wave) * 64 + lane] = s4[hh];
+                }
+                __syncthreads();
+                if (ti == 0) DF_MARK(12);
+                if (wave < 4) {   // one wave per head: online softmax over this tile's keys
+                    float s = 0.f;
+#pragma unroll
+                    for (int w8 = 0; w8 < 8; w8++) s += sc8[(wave * 8 + w8) * 64 + lane];
+                    s *= a.scale;
+                    if (t0 + lane > s_hi) s = -INFINITY;
+                    const float m_old = cr[4 + wave], l_old = cr[8 + wave];
+                    const float m_new = fmaxf(m_old, df_wave_max<USE_DPP>(s));
+                    const float p = expf(s - m_new);
+                    const float corr = expf(m_old - m_new);
+                    const float l_new = l_old * corr + df_wave_sum<USE_DPP>(p);
+                    pt[wave * 64 + lane] = p;
+                    if (lane == 0) { cr[wave] = corr; cr[4 + wave] = m_new; cr[8 + wave] = l_new; }
+                }
+                __syncthreads();
+                {   // quarter sums: keys 16 kq .. 16 kq + 15 of the tile, dim dd, all 4 heads
+                    // only the tile's valid keys: the rows past s_hi hold whatever the ring slot had (0 x NaN would poison the sum)
+                    const int kq = tid >> 7;
+                    const float *vcol = reinterpret_cast<const float *>(vt) + dd;
+                    const int nv = min(DF_TILE, s_hi - t0 + 1);
+                    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int k0 = 16 * kq + 4 * i;
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) v[u] = k0 + u < nv ? vcol[(k0 + u) * 128] : 0.f;
+#pragma unroll
+                        for (int hh = 0; hh < 4; hh++) {
+                            const float4 p4 = *reinterpret_cast<const float4 *>(pt + hh * 64 + k0);
+                            a4[hh] = fmaf(p4.x, v[0], a4[hh]); a4[hh] = fmaf(p4.y, v[1], a4[hh]);
+                            a4[hh] = fmaf(p4.z, v[2], a4[hh]); a4[hh] = fmaf(p4.w, v[3], a4[hh]);
+                        }
+                    }
+#pragma unroll
+                    for (int hh = 0; hh < 4; hh++) sc8[(kq * 4 + hh) * DF_HD + dd] = a4[hh];     // the score area is free again
+                }
+                __syncthreads();
+                {
+                    const float accv = (sc8[(0 * 4 + ho) * DF_HD + dd] + sc8[(1 * 4 + ho) * DF_HD + dd]) +
+                                       (sc8[(2 * 4 + ho) * DF_HD + dd] + sc8[(3 * 4 + ho) * DF_HD + dd]);
+                    o_acc = o_acc * cr[ho] + accv;
+                }
+                continue;
             }
             {   // partial scores: this thread's key x 64 dims of head hs
                 const unsigned char *krow = kt + lane * 512;

@@ -1796,6 +1796,8 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 // (one shared trip pays while a member's slice is one 64-key tile - 1.576 vs 1.589 ms per step at 1900 keys; with
                 // two tiles per member the members finish further apart, the early loads miss and are repeated: 1.731 vs 1.710 at 3800)
                 a.merge_three_trips = merge3 || f_split > 64;
+                static const int attn_old = getenv("VOX_HIP_FUSE_ATTN_PER_HEAD") ? 1 : 0;
+                a.attn_gqa = !attn_old;
                 const bool emb = (l == 0 && build_embed);
                 if (e->use_dpp) {
                     if (emb) hipLaunchKernelGGL((k_dec_attn_fused<true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);

@@ -1,0 +1,90 @@
+// Micro-benchmark: how fast do 256 workgroups fetch a [18432][3072] bf16 matrix once, by per-instruction access pattern?
+//   FRAG : MFMA 32x32x16 operand layout straight from memory - an instruction takes 32 bytes from each of 32 rows, the four
+//          instructions of a 64-column chunk share their 128-byte lines (what k_rowsgemm / k_skinny do for the weights)
+//   HALF : 16x16x32 operand layout - 64 bytes from each of 16 rows per instruction
+//   LINE : whole 128-byte lines - 8 rows x 128 bytes per instruction (what an LDS-staged path would issue)
+//   DMA  : LINE through global_load_lds_dwordx4 into LDS (no registers)
+// Work split as in k_rowsgemm's decoder w1;w3 launch at 38 rows: grid 36 x 7, 8 waves x 64 rows per workgroup, 7 rounds of one
+// 64-column chunk, DEPTH rounds requested ahead.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+enum { FRAG, HALF, LINE, DMA };
+constexpr int K2 = 3072 * 2, ROUNDS = 7;
+__device__ __forceinline__ void glds16(const void *g, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory");
+}
+template <int PAT, int DEPTH, bool NT>
+__global__ __launch_bounds__(512) void k_frag(const unsigned char *W, unsigned *sink) {
+    extern __shared__ unsigned char lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = (blockIdx.x * 8 + wave) * 64;
+    const size_t kb0 = (size_t)blockIdx.y * ROUNDS * 128;
+    u32x4 acc = {0, 0, 0, 0};
+    u32x4 r[DEPTH][8];
+    auto issue = [&](int rd, u32x4 (&dst)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            size_t off;
+            if (PAT == FRAG) off = (size_t)(row0 + (i & 1) * 32 + (lane & 31)) * K2 + kb0 + rd * 128 + (i >> 1) * 32 + (lane >> 5) * 16;
+            else if (PAT == HALF) off = (size_t)(row0 + (i >> 1) * 16 + (lane & 15)) * K2 + kb0 + rd * 128 + (i & 1) * 64 + (lane >> 4) * 16;
+            else off = (size_t)(row0 + i * 8 + (lane >> 3)) * K2 + kb0 + rd * 128 + (lane & 7) * 16;
+            if (PAT == DMA) glds16(W + off, (unsigned)(size_t)lds + (unsigned)((((rd % DEPTH) * 8 + wave) * 8 + i) * 1024));
+            else if (NT) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(W + off));
+            else dst[i] = *reinterpret_cast<const u32x4 *>(W + off);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) issue(d, r[d]);
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        if (PAT == DMA) {
+            if (rd + DEPTH <= ROUNDS) { if (DEPTH == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else if (DEPTH == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            acc.x ^= reinterpret_cast<unsigned *>(lds)[(((rd % DEPTH) * 8 + wave) * 8) * 256 + lane];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc ^= r[rd % DEPTH][i];
+        }
+        if (rd + DEPTH < ROUNDS) issue(rd + DEPTH, r[rd % DEPTH]);
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[blockIdx.x] = 1;
+}
+template <int PAT, int DEPTH, bool NT>
+static void run(const char *name, const unsigned char *buf, size_t bufbytes, unsigned *sink) {
+    const size_t per_launch = (size_t)18432 * K2;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int reps = 40; size_t ofs = 0;
+    const int ldsb = PAT == DMA ? DEPTH * 65536 : 0;
+    hipFuncSetAttribute((const void *)k_frag<PAT, DEPTH, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int i = 0; i < reps + 3; i++) {
+        if (i == 3) hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((k_frag<PAT, DEPTH, NT>), dim3(36, 7), dim3(512), ldsb, 0, buf + ofs, sink);
+        ofs = (ofs + per_launch + 4096) % (bufbytes - per_launch - 8192); ofs &= ~(size_t)4095;
+    }
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / reps;
+    printf("%-44s %6.2f us/launch  %5.2f TB/s  (%s)\n", name, us, per_launch / us / 1e6, hipGetErrorString(hipGetLastError()));
+}
+int main() {
+    const size_t bufbytes = (size_t)4 << 30;
+    unsigned char *buf; unsigned *sink;
+    if (hipMalloc(&buf, bufbytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    hipMalloc(&sink, 1 << 20); hipMemset(buf, 1, bufbytes);
+    run<FRAG, 1, false>("FRAG plain, 1 round ahead", buf, bufbytes, sink);
+    run<FRAG, 2, false>("FRAG plain, 2 rounds ahead", buf, bufbytes, sink);
+    run<FRAG, 3, false>("FRAG plain, 3 rounds ahead", buf, bufbytes, sink);
+    run<FRAG, 7, false>("FRAG plain, all 7 rounds up front", buf, bufbytes, sink);
+    run<FRAG, 2, true>("FRAG non-temporal, 2 rounds ahead", buf, bufbytes, sink);
+    run<HALF, 2, false>("HALF plain, 2 rounds ahead", buf, bufbytes, sink);
+    run<HALF, 7, false>("HALF plain, all up front", buf, bufbytes, sink);
+    run<LINE, 1, false>("LINE plain, 1 round ahead", buf, bufbytes, sink);
+    run<LINE, 2, false>("LINE plain, 2 rounds ahead", buf, bufbytes, sink);
+    run<LINE, 2, true>("LINE non-temporal, 2 rounds ahead", buf, bufbytes, sink);
+    run<LINE, 3, true>("LINE non-temporal, 3 rounds ahead", buf, bufbytes, sink);
+    run<LINE, 7, true>("LINE non-temporal, all up front", buf, bufbytes, sink);
+    run<DMA, 1, false>("DMA (LINE -> LDS), 1 round ahead", buf, bufbytes, sink);
+    run<DMA, 2, false>("DMA (LINE -> LDS), 2 rounds ahead", buf, bufbytes, sink);
+    return 0;
+}

@@ -51,48 +51,55 @@ __device__ __forceinline__ int rg_sw(int r) { return (P % 16 == 0) ? (r & 15) : 
 
 // grid = (ceil(N / (32 NB WPB)), ceil(K / 64 / cw)); block = 64 WPB; dynamic LDS = 2 stages x 3 planes x 32 mt rows x CPW x 128 B.
 //
-// NB = weight tiles per wave (1, or 2 for mt <= 2): every activation fragment read from LDS then feeds NB x 3 MFMAs.  With
-// NB = 1 the fragment reads of the 8 waves (48 ds_read_b128 per wave and round at mt = 2) keep the CU's LDS exactly as busy as
-// its matrix pipes, and the two did not overlap: 19 us of "compute" for 10 us of MFMAs (gpurun_out/p9, decoder w1;w3 at 38 rows).
+// MFMA shape: v_mfma_f32_16x16x32_bf16.  The first version used the 32x32x16 shape, whose operand layout makes a weight load
+// instruction take 32 bytes from each of 32 rows (four instructions share every 128-byte line).  tools/micro/frag_bw.hip
+// measures that pattern on this launch's exact split (36 x 7 workgroups, 113 MB): 3.9 TB/s however many rounds are in flight,
+// against 5.3 TB/s for 64 bytes from each of 16 rows - the 16x16x32 layout - and 5.9 for whole lines; the "latency" the
+// weights seemed to be bound by was the address path.  The smaller shape also pads 38 rows to 48 instead of 64 (68 to 80
+// instead of 96), needs one activation fragment per 2 NB weight tiles and k step (18 ds_read_b128 per wave and round at 38 rows
+// instead of 24) and 4 accumulator registers per tile pair instead of 16.
+//
+// NB = 32-row weight groups per wave (1, or 2 for n <= 64): a wave owns 2 NB weight tiles of 16 rows; every activation
+// fragment read from LDS feeds 2 NB x 3 MFMAs.
 //
 // Software pipeline over the rounds (CPW chunks each) of a workgroup's K range - measured without it (gpurun_out/p6): weights
 // 27 us + MFMAs 20 us + activations 7 us + skeleton 9 us ADDED UP to 75 us, because every round waited for its loads and then
-// computed.  Now the activations of round r + 1 (LDS-DMA into the other LDS stage - only the 4-row groups that hold real rows:
+// computed.  Now the activations of round r + 1 (LDS-DMA into the other LDS stage - only the row groups that hold real rows:
 // the DMA path moves ~15 B/clk/CU, vox_gemm_planes.h - or f32 rows held in registers until after the MFMAs) and its weights
-// (second register set) are requested before the MFMAs of round r.  (A third stage - two rounds in flight - was measured and
-// bought nothing: gpurun_out/p8.)
+// (second register set) are requested before the MFMAs of round r.  (Deeper: a third LDS stage, and later three weight
+// register sets, were measured and bought nothing - gpurun_out/p8, rg3.)
 template <int WPB, int CPW, int XMODE, int NB>
 __global__ __launch_bounds__(64 * WPB) void k_rowsgemm(const RowsGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds[];
     constexpr int P = 8 * CPW;                                   // 16-byte slots per activation row and plane
     constexpr int NT = 64 * WPB;
-    constexpr int MTMAX = NB == 2 ? 2 : 4;
-    // (row, slot) items of an f32 activation stage per thread, at most: mt * cpw <= 6 -> 96 rows x 16 slots / threads
+    constexpr int WT = 2 * NB;                                   // 16-row weight tiles per wave
+    constexpr int MTMAX = NB == 2 ? 4 : 8;                       // 16-row activation tiles
+    // (row, slot) items of an f32 activation stage per thread, at most: rows * P / threads
     constexpr int RG_F32_ITEMS = WPB == 8 ? 3 : 6;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lg = lane >> 5;
-    const int mt = a.mt, rows = 32 * mt;
+    const int li = lane & 15, kb = lane >> 4;
+    const int mt = (a.n + 15) >> 4, rows = 16 * mt;
     const int plane_bytes = rows * P * 16, stage_bytes = 3 * plane_bytes;
     const int nchunks = a.K / 64;
     const int c_begin = blockIdx.y * a.cw, c_end = min(nchunks, c_begin + a.cw);
     const int row0 = (blockIdx.x * WPB + wave) * 32 * NB;        // this wave's weight tiles: rows [row0, row0 + 32 NB)
-    const uint16_t *wrow[NB];
+    const uint16_t *wrow[WT];
 #pragma unroll
-    for (int b = 0; b < NB; b++) wrow[b] = a.W + (size_t)min(row0 + b * 32 + li, a.N - 1) * a.K + lg * 8;
+    for (int q = 0; q < WT; q++) wrow[q] = a.W + (size_t)min(row0 + q * 16 + li, a.N - 1) * a.K + kb * 8;
 
-    // Weight fragments of a round: plain (L1-allocating) loads - in fragment layout an instruction takes 32 bytes from each of
-    // 32 rows and the four instructions of a chunk share their 128-byte lines (vox_skinny.h measured the non-temporal form at
-    // 4 x the line fetches).  Chunks past the range re-read the last valid one and are never multiplied.
-    auto load_w = [&](uint4 (&wr)[NB][CPW][4], int cb) {
+    // Weight fragments of a round: plain (L1-allocating) loads, 64 bytes from each of 16 rows per instruction, the two k steps of
+    // a chunk share their 128-byte lines.  Chunks past the range re-read the last valid one and are never multiplied.
+    auto load_w = [&](uint4 (&wr)[WT][CPW][2], int cb) {
 #pragma unroll
         for (int c = 0; c < CPW; c++)
 #pragma unroll
-            for (int s = 0; s < 4; s++)
+            for (int q = 0; q < WT; q++)
 #pragma unroll
-                for (int b = 0; b < NB; b++) {
-                    if (a.dbg & 2) wr[b][c][s] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-                    else wr[b][c][s] = *reinterpret_cast<const uint4 *>(wrow[b] + (size_t)min(cb + c, nchunks - 1) * 64 + s * 16);
+                for (int ks = 0; ks < 2; ks++) {
+                    if (a.dbg & 2) wr[q][c][ks] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+                    else wr[q][c][ks] = *reinterpret_cast<const uint4 *>(wrow[q] + (size_t)min(cb + c, nchunks - 1) * 64 + ks * 32);
                 }
     };
     // Activations of chunks [cb, cb + nc) into LDS stage `st`: [plane][row][slot], slot s of row r at physical slot s ^ rg_sw(r).
@@ -149,64 +156,67 @@ __global__ __launch_bounds__(64 * WPB) void k_rowsgemm(const RowsGemmArgs a) {
         }
     };
 
-    f32x16 acc[NB][MTMAX];
+    f32x4 acc[WT][MTMAX];
 #pragma unroll
-    for (int b = 0; b < NB; b++)
+    for (int q = 0; q < WT; q++)
 #pragma unroll
-        for (int t = 0; t < MTMAX; t++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[b][t][r] = 0.f;
+        for (int t = 0; t < MTMAX; t++) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // MFMAs of one round: A = activation fragment (row = lane & 31 of tile t, 8 k of half lane >> 5), B = weight fragment.
+    // MFMAs of one round: A = activation fragment (row = lane & 15 of tile t, 8 k of quarter lane >> 4), B = weight fragment.
     // One straight-line body per tile count (switch below), NOT "if (t < mt)" around the MFMAs of each tile: with the MFMAs of
     // the later tiles branched over at run time, the epilogue read the last accumulator registers of tile 0 before the matrix
     // pipe had written them (rows 19 .. 31 of every 32 x 32 tile wrong at mt = 1, right at mt = 2: tools/rg_gemm_check2.py) -
     // the wait states between an MFMA and a read of its result are inserted per basic block.
-    auto compute_mt = [&](const uint4 (&wr)[NB][CPW][4], int st, int nc, auto MTc) {
+    auto compute_mt = [&](const uint4 (&wr)[WT][CPW][2], int st, int nc, auto MTc) {
         constexpr int MT = decltype(MTc)::value;
         const unsigned char *stage = rg_lds + (size_t)st * stage_bytes;
 #pragma unroll
         for (int c = 0; c < CPW; c++) {
-            if (a.dbg & 4) { acc[0][0][c] += __uint_as_float(wr[0][c][0].x) + __uint_as_float(wr[NB - 1][c][3].w); continue; }
+            if (a.dbg & 4) { acc[0][0][c] += __uint_as_float(wr[0][c][0].x) + __uint_as_float(wr[WT - 1][c][1].w); continue; }
             if (c < nc) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const int ls = c * 8 + s * 2 + lg;
+                for (int ks = 0; ks < 2; ks++) {
+                    const int ls = c * 8 + ks * 4 + kb;
 #pragma unroll
                     for (int t = 0; t < MT; t++) {
-                        const int r = t * 32 + li;
+                        const int r = t * 16 + li;
                         const unsigned char *src = stage + (size_t)(r * P + (ls ^ rg_sw<P>(r))) * 16;
                         bf16x8_t fa[3];
 #pragma unroll
                         for (int p = 0; p < 3; p++) fa[p] = *reinterpret_cast<const bf16x8_t *>(src + p * plane_bytes);
 #pragma unroll
-                        for (int b = 0; b < NB; b++) {
+                        for (int q = 0; q < WT; q++) {
                             union { uint4 u; bf16x8_t v; } fb;
-                            fb.u = wr[b][c][s];
+                            fb.u = wr[q][c][ks];
 #pragma unroll
                             for (int p = 2; p >= 0; p--)         // small terms first
-                                acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[p], fb.v, acc[b][t], 0, 0, 0);
+                                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[p], fb.v, acc[q][t], 0, 0, 0);
                         }
                     }
                 }
             }
         }
     };
-    auto compute = [&](const uint4 (&wr)[NB][CPW][4], int st, int nc) {
-        if constexpr (NB == 2) {
-            if (mt == 1) compute_mt(wr, st, nc, std::integral_constant<int, 1>{});
-            else compute_mt(wr, st, nc, std::integral_constant<int, 2>{});
-        } else {
-            switch (mt) {
-                case 1: compute_mt(wr, st, nc, std::integral_constant<int, 1>{}); break;
-                case 2: compute_mt(wr, st, nc, std::integral_constant<int, 2>{}); break;
-                case 3: compute_mt(wr, st, nc, std::integral_constant<int, 3>{}); break;
-                default: compute_mt(wr, st, nc, std::integral_constant<int, 4>{}); break;
-            }
+    auto compute = [&](const uint4 (&wr)[WT][CPW][2], int st, int nc) {
+        switch (mt) {
+            case 1: compute_mt(wr, st, nc, std::integral_constant<int, 1>{}); break;
+            case 2: compute_mt(wr, st, nc, std::integral_constant<int, 2>{}); break;
+            case 3: compute_mt(wr, st, nc, std::integral_constant<int, 3>{}); break;
+            case 4: compute_mt(wr, st, nc, std::integral_constant<int, 4>{}); break;
+            default:
+                if constexpr (NB == 1) {
+                    switch (mt) {
+                        case 5: compute_mt(wr, st, nc, std::integral_constant<int, 5>{}); break;
+                        case 6: compute_mt(wr, st, nc, std::integral_constant<int, 6>{}); break;
+                        case 7: compute_mt(wr, st, nc, std::integral_constant<int, 7>{}); break;
+                        default: compute_mt(wr, st, nc, std::integral_constant<int, 8>{}); break;
+                    }
+                }
+                break;
         }
     };
 
-    uint4 w[NB][CPW][4], wn[NB][CPW][4];
+    uint4 w[WT][CPW][2], wn[WT][CPW][2];
     float4 xa[RG_F32_ITEMS], xb[RG_F32_ITEMS];                  // (dead in the planes variant)
     load_w(w, c_begin);                                          // the longest latency first
     if constexpr (XMODE == RG_X_PLANES) stage_planes(0, c_begin, min(CPW, c_end - c_begin));
@@ -229,29 +239,29 @@ __global__ __launch_bounds__(64 * WPB) void k_rowsgemm(const RowsGemmArgs a) {
         if (more) {
             if constexpr (XMODE == RG_X_F32) f32_store(st ^ 1, xa, xb);
 #pragma unroll
-            for (int b = 0; b < NB; b++)
+            for (int q = 0; q < WT; q++)
 #pragma unroll
                 for (int c = 0; c < CPW; c++)
 #pragma unroll
-                    for (int s = 0; s < 4; s++) w[b][c][s] = wn[b][c][s];
+                    for (int ks = 0; ks < 2; ks++) w[q][c][ks] = wn[q][c][ks];
         }
     }
-    // ---- raw partial sums: C layout of the 32 x 32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
+    // ---- raw partial sums: C layout of the 16 x 16 MFMA: column = lane & 15, row = 4 (lane >> 4) + r ----
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // (belt and braces for the hazard described at compute_mt)
     if ((a.dbg & 8) && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
-    for (int b = 0; b < NB; b++) {
-        const int col = row0 + b * 32 + li;
+    for (int q = 0; q < WT; q++) {
+        const int col = row0 + q * 16 + li;
         if (col < a.N) {
             float *P0 = a.partial + (size_t)blockIdx.y * a.n * a.N + col;
 #pragma unroll
             for (int t = 0; t < MTMAX; t++) {
                 if (t < mt) {
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int m = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-                        if (m < a.n) P0[(size_t)m * a.N] = acc[b][t][r];
+                    for (int r = 0; r < 4; r++) {
+                        const int m = t * 16 + 4 * kb + r;
+                        if (m < a.n) P0[(size_t)m * a.N] = acc[q][t][r];
                     }
                 }
             }

@@ -72,52 +72,63 @@ __device__ __forceinline__ void sk_planes1(float x, uint16_t &h, uint16_t &m, ui
 // XS: the activation fragments come pre-split (three 16-byte loads per MFMA step, no VALU work): with f32 activations every
 // one of the N / 32 workgroups repeats the same hi / mid / lo split of x, ~7 VALU operations per element and MFMA step, and
 // that - not HBM - bounded the qkv and w1;w3 launches (measured 15 / 22 us for 15.7 / 26.2 MB).
+//
+// Round 3: v_mfma_f32_16x16x32_bf16 instead of the 32x32x16 shape.  Same MFMA time (twice the instructions at half the
+// passes), same register counts - but the operand layout of the smaller shape makes a load instruction take 64 bytes from
+// each of 16 rows instead of 32 bytes from each of 32, for the weights and for the activations alike, and that pattern
+// streams at 5.3 TB/s where the other stops at 3.9 however many loads are in flight (tools/micro/frag_bw.hip).
 template <int EPI, int MT, bool XS>
 __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
-    constexpr int NB = (EPI == SK_SWIGLU) ? 2 : 1;              // W tiles per wave
+    constexpr int NB = (EPI == SK_SWIGLU) ? 2 : 1;              // 32-row W tiles per wave
+    constexpr int MU = 2 * MT;                                   // 16-row activation tiles
     extern __shared__ __attribute__((aligned(16))) float sk_lds[];   // [SK_WPB][NB][MT][1024] accumulators
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lg = lane >> 5;
+    const int li = lane & 15, kb = lane >> 4;
     const int row0 = blockIdx.x * 32;
     const int nchunks = a.K / 64;
     const int kworkers = gridDim.y * SK_WPB, kw = blockIdx.y * SK_WPB + wave;
 
-    f32x16 acc[NB][MT];
+    f32x4 acc[NB][2][MU];
 #pragma unroll
     for (int b = 0; b < NB; b++)
 #pragma unroll
-        for (int t = 0; t < MT; t++)
+        for (int q = 0; q < 2; q++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[b][t][r] = 0.f;
+            for (int u = 0; u < MU; u++) acc[b][q][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const uint16_t *wrow[NB];
-    wrow[0] = a.W + (size_t)(row0 + li) * a.K + lg * 8;
-    if constexpr (NB == 2) wrow[1] = a.W2 + (size_t)(row0 + li) * a.K + lg * 8;
-    const float *xrow[MT];
-    const uint16_t *xprow[MT];
+    const uint16_t *wrow[NB][2];
 #pragma unroll
-    for (int t = 0; t < MT; t++) {
-        xrow[t] = XS ? nullptr : a.X + (size_t)min(t * 32 + li, a.n - 1) * a.ldx + lg * 8;
-        xprow[t] = XS ? a.Xp + (size_t)min(t * 32 + li, a.n - 1) * a.K + lg * 8 : nullptr;
+    for (int q = 0; q < 2; q++) {
+        wrow[0][q] = a.W + (size_t)(row0 + 16 * q + li) * a.K + kb * 8;
+        if constexpr (NB == 2) wrow[1][q] = a.W2 + (size_t)(row0 + 16 * q + li) * a.K + kb * 8;
+    }
+    const float *xrow[MU];
+    const uint16_t *xprow[MU];
+#pragma unroll
+    for (int u = 0; u < MU; u++) {
+        xrow[u] = XS ? nullptr : a.X + (size_t)min(u * 16 + li, a.n - 1) * a.ldx + kb * 8;
+        xprow[u] = XS ? a.Xp + (size_t)min(u * 16 + li, a.n - 1) * a.K + kb * 8 : nullptr;
     }
 
     // A wave owns at most SK_MAXC chunks (the host picks the K split accordingly).  All of its WEIGHT fragments are
     // requested up front (HBM latency paid once, 16 VGPRs per chunk and tile); the activation fragments (L2 hits, 32 VGPRs
     // per chunk) are double buffered.  Register arrays are only ever indexed by compile-time constants.
+    // Fragment index f = 2 * (16-row tile) + (k step of 32): 4 per 32-row tile and 64-wide chunk, as with the 32x32x16 shape.
     uint4 wq[SK_MAXC][NB][4];
     constexpr int XR = XS ? 3 : 2;            // 16-byte registers per fragment: 3 bf16 planes, or 8 f32
     float4 xq0[MT][4][XR], xq1[MT][4][XR];
     auto issue_w = [&](uint4 (&wqc)[NB][4], int c) {
 #pragma unroll
-        for (int s = 0; s < 4; s++)
+        for (int q = 0; q < 2; q++)
 #pragma unroll
-            // plain (L1-allocating) loads on purpose: in fragment layout one instruction takes 32 bytes from each of 32 rows,
-            // and the four instructions of a chunk share their 128-byte lines - a non-temporal load would fetch each line 4 x
-            for (int b = 0; b < NB; b++) {
-                if (a.dbg & 2) wqc[b][s] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-                else wqc[b][s] = *reinterpret_cast<const uint4 *>(wrow[b] + c * 64 + s * 16);
-            }
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                // plain (L1-allocating) loads on purpose: the two k steps of a chunk share their 128-byte lines
+                for (int b = 0; b < NB; b++) {
+                    if (a.dbg & 2) wqc[b][2 * q + ks] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+                    else wqc[b][2 * q + ks] = *reinterpret_cast<const uint4 *>(wrow[b][q] + c * 64 + ks * 32);
+                }
     };
     auto issue_x = [&](float4 (&xq)[MT][4][XR], int c) {
         if (a.dbg & 1) {
@@ -130,15 +141,16 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
             return;
         }
 #pragma unroll
-        for (int s = 0; s < 4; s++)
+        for (int u = 0; u < MU; u++)
 #pragma unroll
-            for (int t = 0; t < MT; t++) {
+            for (int ks = 0; ks < 2; ks++) {
+                const int t = u >> 1, f = 2 * (u & 1) + ks;
                 if constexpr (XS) {
 #pragma unroll
-                    for (int p = 0; p < 3; p++) xq[t][s][p] = *reinterpret_cast<const float4 *>(xprow[t] + p * a.xp_plane + c * 64 + s * 16);
+                    for (int p = 0; p < 3; p++) xq[t][f][p] = *reinterpret_cast<const float4 *>(xprow[u] + p * a.xp_plane + c * 64 + ks * 32);
                 } else {
-                    xq[t][s][0] = *reinterpret_cast<const float4 *>(xrow[t] + c * 64 + s * 16);
-                    xq[t][s][1] = *reinterpret_cast<const float4 *>(xrow[t] + c * 64 + s * 16 + 4);
+                    xq[t][f][0] = *reinterpret_cast<const float4 *>(xrow[u] + c * 64 + ks * 32);
+                    xq[t][f][1] = *reinterpret_cast<const float4 *>(xrow[u] + c * 64 + ks * 32 + 4);
                 }
             }
     };
@@ -147,31 +159,34 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
 #pragma unroll
             for (int b = 0; b < NB; b++)
 #pragma unroll
-                for (int t = 0; t < MT; t++) acc[b][t][0] += __uint_as_float(wqc[b][0].x) + xq[t][0][0].x + __uint_as_float(wqc[b][3].w) + xq[t][3][XR - 1].w;
+                for (int t = 0; t < MT; t++) acc[b][0][t][0] += __uint_as_float(wqc[b][0].x) + xq[t][0][0].x + __uint_as_float(wqc[b][3].w) + xq[t][3][XR - 1].w;
             return;
         }
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            bf16x8_t fa[MT][3];
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8_t fa[MU][3];
 #pragma unroll
-            for (int t = 0; t < MT; t++) {
+            for (int u = 0; u < MU; u++) {
+                const int t = u >> 1, f = 2 * (u & 1) + ks;
                 if constexpr (XS) {
 #pragma unroll
-                    for (int p = 0; p < 3; p++) { union { float4 f; bf16x8_t v; } cv; cv.f = xq[t][s][p]; fa[t][p] = cv.v; }
+                    for (int p = 0; p < 3; p++) { union { float4 f4; bf16x8_t v; } cv; cv.f4 = xq[t][f][p]; fa[u][p] = cv.v; }
                 } else {
-                    sk_split_frag(xq[t][s][0], xq[t][s][1], fa[t][0], fa[t][1], fa[t][2]);
+                    sk_split_frag(xq[t][f][0], xq[t][f][1], fa[u][0], fa[u][1], fa[u][2]);
                 }
             }
 #pragma unroll
-            for (int b = 0; b < NB; b++) {
-                union { uint4 u; bf16x8_t v; } fb;
-                fb.u = wqc[b][s];
+            for (int b = 0; b < NB; b++)
 #pragma unroll
-                for (int p = 2; p >= 0; p--)                   // small terms first
+                for (int q = 0; q < 2; q++) {
+                    union { uint4 u4; bf16x8_t v; } fb;
+                    fb.u4 = wqc[b][2 * q + ks];
 #pragma unroll
-                    for (int t = 0; t < MT; t++)
-                        acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][p], fb.v, acc[b][t], 0, 0, 0);
-            }
+                    for (int p = 2; p >= 0; p--)                   // small terms first
+#pragma unroll
+                        for (int u = 0; u < MU; u++)
+                            acc[b][q][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[u][p], fb.v, acc[b][q][u], 0, 0, 0);
+                }
         }
     };
     static_assert(SK_MAXC == 3, "the chunk schedule below is written out for three chunks");
@@ -189,13 +204,17 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
         }
     }
 
-    // ---- add the K splitters of this workgroup in wave order (element e = r * 64 + lane of each 32 x 32 tile) ------------
+    // ---- add the K splitters of this workgroup in wave order.  Tiles are kept as [32 rows m][32 columns] in LDS: the 16 x 16
+    // MFMA's C layout is column = lane & 15, row = 4 (lane >> 4) + r ----------------------------------------------------------------
 #pragma unroll
     for (int b = 0; b < NB; b++)
 #pragma unroll
-        for (int t = 0; t < MT; t++)
+        for (int q = 0; q < 2; q++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) sk_lds[((wave * NB + b) * MT + t) * 1024 + r * 64 + lane] = acc[b][t][r];
+            for (int u = 0; u < MU; u++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    sk_lds[((wave * NB + b) * MT + (u >> 1)) * 1024 + (16 * (u & 1) + 4 * kb + r) * 32 + 16 * q + li] = acc[b][q][u][r];
     __syncthreads();
     float *red = sk_lds;                                            // reduced tiles overwrite wave 0's slots
     for (int e = tid; e < NB * MT * 1024; e += 64 * SK_WPB) {
@@ -206,12 +225,12 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
     }
     __syncthreads();
 
-    // ---- epilogue over the tile: e -> (tile t, r, lane) -> row m = 32 t + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31
+    // ---- epilogue over the tile: e -> (tile t, row, column) -> row m = 32 t + ((e >> 5) & 31), col = e & 31
     if ((a.dbg & 8) && red[tid] != 12345.678f) return;
     for (int e = tid; e < MT * 1024; e += 64 * SK_WPB) {
-        const int t = e >> 10, r = (e >> 6) & 15, ln = e & 63;
-        const int m = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
-        const int col = row0 + (ln & 31);
+        const int t = e >> 10;
+        const int m = t * 32 + ((e >> 5) & 31);
+        const int col = row0 + (e & 31);
         if (m >= a.n) continue;
         if constexpr (EPI == SK_PARTIAL) {
             a.partial[((size_t)blockIdx.y * a.n + m) * a.N + col] = red[e];
@@ -228,7 +247,7 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
         } else {
             float v = red[e] + (a.bias ? a.bias[col] : 0.f);
             if (col < a.rope_cols) {
-                const float o = red[e ^ 1] + (a.bias ? a.bias[col ^ 1] : 0.f);          // the pair partner: adjacent lane, same row
+                const float o = red[e ^ 1] + (a.bias ? a.bias[col ^ 1] : 0.f);          // the pair partner: adjacent column, same row
                 const int d = (col % a.head_dim) >> 1;
                 const float cs = a.rope_tab[((size_t)m * (a.head_dim / 2) + d) * 2], sn = a.rope_tab[((size_t)m * (a.head_dim / 2) + d) * 2 + 1];
                 v = (col & 1) ? o * sn + v * cs : v * cs - o * sn;                       // (x0 c - x1 s, x0 s + x1 c)

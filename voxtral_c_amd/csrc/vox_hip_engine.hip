@@ -1014,14 +1014,13 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
     uint16_t *xnp = (uint16_t *)e->sgu.p, *hp = xnp + (size_t)3 * n * c.D;
     float *part = (float *)e->ssplitk.p;
     const size_t lds1 = (size_t)SK_WPB * 4096, lds2 = (size_t)SK_WPB * 2 * 4096;
-    static const int sk_dbg = getenv("VOX_HIP_SK_DBG") ? atoi(getenv("VOX_HIP_SK_DBG")) : 0;      // tuning only: wrong results
     if (L > 0)      // attention_norm of layer 0 (no partials, no bias: x is left as it is)
         hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)nullptr, 0, n, c.D, (const float *)nullptr,
                            (const float *)e->enc[0].n1, c.eps, xn, c.D, xnp);
     for (int l = 0; l < L; l++) {
         EncLayer &Ly = e->enc[l];
         {   // attention_norm(x) . [wq; wk; wv]^T + bias, RoPE, K/V into the merged buffer and the rings
-            SkinnyArgs a{}; a.dbg = sk_dbg;
+            SkinnyArgs a{};
             a.Xp = xnp; a.xp_plane = (size_t)n * c.D; a.n = n; a.W = Ly.wqkv; a.N = N3; a.K = c.D; a.bias = Ly.bqkv; a.Y = qkv; a.ldy = N3;
             a.rope_cols = c.QD + c.KVD; a.head_dim = c.hd; a.rope_tab = tab; a.kring = Ly.kring; a.vring = Ly.vring;
             a.ring_cap = e->enc_ring_cap; a.kv_dim = c.KVD; a.pos0 = pos0; a.q_cols = c.QD;
@@ -1029,14 +1028,14 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
         }
         if (enc_attention(e, c, qkv, attn, n, pos0, Ly.kring, Ly.vring, e->enc_ring_cap)) return -1;
         {   // wo as K-split partials, then x += . + bo and ffn_norm in one launch
-            SkinnyArgs a{}; a.dbg = sk_dbg;
+            SkinnyArgs a{};
             a.X = attn; a.ldx = c.QD; a.n = n; a.W = Ly.wo; a.N = c.D; a.K = c.QD; a.partial = part;
             hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, false>), dim3(c.D / 32, so), dim3(64 * SK_WPB), lds1, s, a);
             hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, so, n, c.D, (const float *)Ly.bo,
                                (const float *)Ly.n2, c.eps, xn, c.D, xnp);
         }
         {   // silu(xn w1^T) * (xn w3^T), written as bf16 planes for the w2 launch
-            SkinnyArgs a{}; a.dbg = sk_dbg;
+            SkinnyArgs a{};
             a.Xp = xnp; a.xp_plane = (size_t)n * c.D; a.n = n; a.W = Ly.w13; a.W2 = Ly.w13 + (size_t)c.H * c.D; a.N = c.H; a.K = c.D;
             a.Yp = hp; a.yp_plane = (size_t)n * c.H;
             hipLaunchKernelGGL((k_skinny<SK_SWIGLU, 1, true>), dim3(c.H / 32, 1), dim3(64 * SK_WPB), lds2, s, a);
@@ -1046,7 +1045,7 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
             if (w2_rg) {
                 s2n = launch_rowsgemm(e, hp, (size_t)n * c.H, nullptr, 0, n, Ly.w2, c.D, c.H, part);
             } else {
-                SkinnyArgs a{}; a.dbg = sk_dbg;
+                SkinnyArgs a{};
                 a.Xp = hp; a.xp_plane = (size_t)n * c.H; a.n = n; a.W = Ly.w2; a.N = c.D; a.K = c.H; a.partial = part;
                 hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, true>), dim3(c.D / 32, s2), dim3(64 * SK_WPB), lds1, s, a);
             }
@@ -1083,7 +1082,7 @@ static RgPlan rg_plan(int n, int N, int K, bool f32x = false) {
     if ((force_cpw == 1 || force_cpw == 2) && force_cpw * mt <= 6) p.cpw = force_cpw;
     // register budget of the 512-thread variants (256 VGPRs): two weight register sets of NB x cpw x 4 fragments + 16 NB mt
     // accumulators (+ the f32 rows of the next round) - one chunk per round where two would spill
-    if (p.wpb == 8 && (p.ntile == 2 || f32x)) p.cpw = 1;
+    if (p.wpb == 8 && (p.ntile == 2 || f32x || n > 64)) p.cpw = 1;
     p.lds = (size_t)2 * 3 * 32 * mt * p.cpw * 128;
     // one workgroup per CU (the stages take up to 144 KB of its LDS): as many K splits as fill the chip without a second wave
     // of workgroups - 288 workgroups on 256 CUs ran 75 us where 216 ran 54 (gpurun_out/p6)
@@ -1105,21 +1104,23 @@ static int launch_rowsgemm(vox_hip_engine *e, const uint16_t *Xp, size_t xp_plan
     RowsGemmArgs a{};
     a.Xp = Xp; a.xp_plane = xp_plane; a.X = X; a.ldx = ldx; a.n = n; a.mt = (n + 31) / 32; a.W = W; a.N = N; a.K = K; a.cw = p.cw;
     a.partial = partial;
-    static const int rg_dbg = getenv("VOX_HIP_RG_DBG") ? atoi(getenv("VOX_HIP_RG_DBG")) : 0;       // tuning only: wrong results
-    a.dbg = rg_dbg;
     const dim3 grid(p.nb, p.S), block(64 * p.wpb);
     hipStream_t s = e->stream;
-#define RG_LAUNCH(WPB, CPW, NBT)                                                                                         \
+#define RG_LAUNCH(WPB, CPW, NBT, MTM)                                                                                    \
     do {                                                                                                                 \
-        if (Xp) hipLaunchKernelGGL((k_rowsgemm<WPB, CPW, RG_X_PLANES, NBT>), grid, block, p.lds, s, a);                  \
-        else hipLaunchKernelGGL((k_rowsgemm<WPB, CPW, RG_X_F32, NBT>), grid, block, p.lds, s, a);                        \
+        if (Xp) hipLaunchKernelGGL((k_rowsgemm<WPB, CPW, RG_X_PLANES, NBT, MTM>), grid, block, p.lds, s, a);             \
+        else hipLaunchKernelGGL((k_rowsgemm<WPB, CPW, RG_X_F32, NBT, MTM>), grid, block, p.lds, s, a);                   \
     } while (0)
+    const bool small = n <= 64;                                  // accumulator budget of 4 (instead of 8) 16-row tiles
     if (p.ntile == 2) {
-        if (p.wpb == 8) { if (p.cpw == 2) RG_LAUNCH(8, 2, 2); else RG_LAUNCH(8, 1, 2); }
-        else { if (p.cpw == 2) RG_LAUNCH(4, 2, 2); else RG_LAUNCH(4, 1, 2); }
+        if (p.wpb == 8) { if (p.cpw == 2) RG_LAUNCH(8, 2, 2, 4); else RG_LAUNCH(8, 1, 2, 4); }
+        else { if (p.cpw == 2) RG_LAUNCH(4, 2, 2, 4); else RG_LAUNCH(4, 1, 2, 4); }
+    } else if (small) {
+        if (p.wpb == 8) { if (p.cpw == 2) RG_LAUNCH(8, 2, 1, 4); else RG_LAUNCH(8, 1, 1, 4); }
+        else { if (p.cpw == 2) RG_LAUNCH(4, 2, 1, 4); else RG_LAUNCH(4, 1, 1, 4); }
     } else {
-        if (p.wpb == 8) { if (p.cpw == 2) RG_LAUNCH(8, 2, 1); else RG_LAUNCH(8, 1, 1); }
-        else { if (p.cpw == 2) RG_LAUNCH(4, 2, 1); else RG_LAUNCH(4, 1, 1); }
+        if (p.wpb == 8) { if (p.cpw == 2) RG_LAUNCH(8, 2, 1, 8); else RG_LAUNCH(8, 1, 1, 8); }
+        else { if (p.cpw == 2) RG_LAUNCH(4, 2, 1, 8); else RG_LAUNCH(4, 1, 1, 8); }
     }
 #undef RG_LAUNCH
     return p.S;
@@ -2630,8 +2631,9 @@ static int self_test(vox_hip_engine *e) {
     }
     {   // k_rowsgemm: up to 3 planes x 128 rows x 2 chunks (or 96 rows x 4 chunks) of activations in LDS
         const int rg_lds = 2 * 3 * 32 * 6 * 128;        // the largest request the launcher can make (mt * cpw <= 6)
-#define RG_FN(WPB, CPW) (const void *)k_rowsgemm<WPB, CPW, RG_X_PLANES, 1>, (const void *)k_rowsgemm<WPB, CPW, RG_X_F32, 1>, \
-                        (const void *)k_rowsgemm<WPB, CPW, RG_X_PLANES, 2>, (const void *)k_rowsgemm<WPB, CPW, RG_X_F32, 2>
+#define RG_FN(WPB, CPW) (const void *)k_rowsgemm<WPB, CPW, RG_X_PLANES, 1, 4>, (const void *)k_rowsgemm<WPB, CPW, RG_X_F32, 1, 4>, \
+                        (const void *)k_rowsgemm<WPB, CPW, RG_X_PLANES, 1, 8>, (const void *)k_rowsgemm<WPB, CPW, RG_X_F32, 1, 8>, \
+                        (const void *)k_rowsgemm<WPB, CPW, RG_X_PLANES, 2, 4>, (const void *)k_rowsgemm<WPB, CPW, RG_X_F32, 2, 4>
         const void *fns[] = {RG_FN(8, 2), RG_FN(8, 1), RG_FN(4, 2), RG_FN(4, 1)};
 #undef RG_FN
         for (const void *f : fns)

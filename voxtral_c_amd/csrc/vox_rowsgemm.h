@@ -40,7 +40,6 @@ struct RowsGemmArgs {
     const uint16_t *W; int N, K;              // [N][K] bf16
     int cw;                                   // 64-wide K chunks per workgroup (blockIdx.y owns chunks [y cw, (y + 1) cw)), walked CPW at a time
     float *partial;                           // [gridDim.y][n][N] raw partial sums
-    int dbg;                                  // tuning only (VOX_HIP_RG_DBG, results are WRONG): 1 no activation staging, 2 no weight loads, 4 no MFMAs, 8 no stores
 };
 
 // 16-byte slot swizzle of an LDS row of P slots: 16 consecutive rows reading the same logical slot hit 16 distinct slots of the
@@ -68,13 +67,16 @@ __device__ __forceinline__ int rg_sw(int r) { return (P % 16 == 0) ? (r & 15) : 
 // the DMA path moves ~15 B/clk/CU, vox_gemm_planes.h - or f32 rows held in registers until after the MFMAs) and its weights
 // (second register set) are requested before the MFMAs of round r.  (Deeper: a third LDS stage, and later three weight
 // register sets, were measured and bought nothing - gpurun_out/p8, rg3.)
-template <int WPB, int CPW, int XMODE, int NB>
+// MTM = accumulator budget in 16-row activation tiles (4: n <= 64, 8: n <= 128; NB = 2 goes with 4 only): accumulators of tiles
+// that hold no rows still occupy registers through the whole loop.
+template <int WPB, int CPW, int XMODE, int NB, int MTM>
 __global__ __launch_bounds__(64 * WPB) void k_rowsgemm(const RowsGemmArgs a) {
+    static_assert(MTM == 4 || (MTM == 8 && NB == 1), "accumulator budget");
     extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds[];
     constexpr int P = 8 * CPW;                                   // 16-byte slots per activation row and plane
     constexpr int NT = 64 * WPB;
     constexpr int WT = 2 * NB;                                   // 16-row weight tiles per wave
-    constexpr int MTMAX = NB == 2 ? 4 : 8;                       // 16-row activation tiles
+    constexpr int MTMAX = MTM;                                   // 16-row activation tiles
     // (row, slot) items of an f32 activation stage per thread, at most: rows * P / threads
     constexpr int RG_F32_ITEMS = WPB == 8 ? 3 : 6;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -91,6 +93,9 @@ __global__ __launch_bounds__(64 * WPB) void k_rowsgemm(const RowsGemmArgs a) {
 
     // Weight fragments of a round: plain (L1-allocating) loads, 64 bytes from each of 16 rows per instruction, the two k steps of
     // a chunk share their 128-byte lines.  Chunks past the range re-read the last valid one and are never multiplied.
+    // (No run-time switches in here: a debug branch around these loads - "load, or write a constant into the same register" - made
+    // the compiler wait for vmcnt(0) in front of every round's MFMAs, i.e. for the NEXT round's loads; rounds 1 and 2 of this
+    // kernel's life ran without any overlap of loads and MFMAs because of it.)
     auto load_w = [&](uint4 (&wr)[WT][CPW][2], int cb) {
 #pragma unroll
         for (int c = 0; c < CPW; c++)
@@ -98,8 +103,7 @@ __global__ __launch_bounds__(64 * WPB) void k_rowsgemm(const RowsGemmArgs a) {
             for (int q = 0; q < WT; q++)
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) {
-                    if (a.dbg & 2) wr[q][c][ks] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-                    else wr[q][c][ks] = *reinterpret_cast<const uint4 *>(wrow[q] + (size_t)min(cb + c, nchunks - 1) * 64 + ks * 32);
+                    wr[q][c][ks] = *reinterpret_cast<const uint4 *>(wrow[q] + (size_t)min(cb + c, nchunks - 1) * 64 + ks * 32);
                 }
     };
     // Activations of chunks [cb, cb + nc) into LDS stage `st`: [plane][row][slot], slot s of row r at physical slot s ^ rg_sw(r).
@@ -107,7 +111,6 @@ __global__ __launch_bounds__(64 * WPB) void k_rowsgemm(const RowsGemmArgs a) {
     // is free.  Row groups past the last real row are not fetched: their LDS rows hold whatever they held, and an MFMA's output
     // row depends on its own input row only.
     auto stage_planes = [&](int st, int cb, int nc) {
-        if (a.dbg & 1) return;
         const int ipp = (rows * P) / 64;                         // instructions per plane
         const int ninstr = 3 * ipp;
         for (int q = wave; q < ninstr; q += WPB) {
@@ -172,7 +175,6 @@ __global__ __launch_bounds__(64 * WPB) void k_rowsgemm(const RowsGemmArgs a) {
         const unsigned char *stage = rg_lds + (size_t)st * stage_bytes;
 #pragma unroll
         for (int c = 0; c < CPW; c++) {
-            if (a.dbg & 4) { acc[0][0][c] += __uint_as_float(wr[0][c][0].x) + __uint_as_float(wr[WT - 1][c][1].w); continue; }
             if (c < nc) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) {
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(64 * WPB) void k_rowsgemm(const RowsGemmArgs a) {
             case 3: compute_mt(wr, st, nc, std::integral_constant<int, 3>{}); break;
             case 4: compute_mt(wr, st, nc, std::integral_constant<int, 4>{}); break;
             default:
-                if constexpr (NB == 1) {
+                if constexpr (MTM == 8) {
                     switch (mt) {
                         case 5: compute_mt(wr, st, nc, std::integral_constant<int, 5>{}); break;
                         case 6: compute_mt(wr, st, nc, std::integral_constant<int, 6>{}); break;
@@ -216,40 +218,41 @@ __global__ __launch_bounds__(64 * WPB) void k_rowsgemm(const RowsGemmArgs a) {
         }
     };
 
-    uint4 w[WT][CPW][2], wn[WT][CPW][2];
+    // Two weight register sets, used alternately (no copies between them: a copy "w = wn" is a read of registers with loads in
+    // flight, and wherever the compiler schedules it, it waits for them there - it put those waits in front of the MFMAs).
+    uint4 wA[WT][CPW][2], wB[WT][CPW][2];
     float4 xa[RG_F32_ITEMS], xb[RG_F32_ITEMS];                  // (dead in the planes variant)
-    load_w(w, c_begin);                                          // the longest latency first
+    load_w(wA, c_begin);                                         // the longest latency first
     if constexpr (XMODE == RG_X_PLANES) stage_planes(0, c_begin, min(CPW, c_end - c_begin));
     else { f32_load(xa, xb, c_begin, min(CPW, c_end - c_begin)); f32_store(0, xa, xb); }
-    int st = 0;
-    for (int cb = c_begin; cb < c_end; cb += CPW, st ^= 1) {
+    int st = 0, cb = c_begin;
+    auto round = [&](const uint4 (&wcur)[WT][CPW][2], uint4 (&wnext)[WT][CPW][2]) {
         const int nc = min(CPW, c_end - cb);                     // chunks of this round
         const bool more = cb + CPW < c_end;
-        // this round's activations are in LDS stage st (DMAs landed / stores done) and its weights in w; everybody is past the
+        // this round's activations are in LDS stage st (DMAs landed / stores done) and its weights in wcur; everybody is past the
         // MFMAs of the previous round, so the other stage may be overwritten
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (more) {                                              // round r + 1 streams under the MFMAs of round r
             const int ncn = min(CPW, c_end - cb - CPW);
-            load_w(wn, cb + CPW);
+            load_w(wnext, cb + CPW);
             if constexpr (XMODE == RG_X_PLANES) stage_planes(st ^ 1, cb + CPW, ncn);
             else f32_load(xa, xb, cb + CPW, ncn);
         }
-        compute(w, st, nc);
+        compute(wcur, st, nc);
         if (more) {
             if constexpr (XMODE == RG_X_F32) f32_store(st ^ 1, xa, xb);
-#pragma unroll
-            for (int q = 0; q < WT; q++)
-#pragma unroll
-                for (int c = 0; c < CPW; c++)
-#pragma unroll
-                    for (int ks = 0; ks < 2; ks++) w[q][c][ks] = wn[q][c][ks];
         }
+        cb += CPW; st ^= 1;
+    };
+    while (cb < c_end) {
+        round(wA, wB);
+        if (cb >= c_end) break;
+        round(wB, wA);
     }
     // ---- raw partial sums: C layout of the 16 x 16 MFMA: column = lane & 15, row = 4 (lane >> 4) + r ----
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // (belt and braces for the hazard described at compute_mt)
-    if ((a.dbg & 8) && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
     for (int q = 0; q < WT; q++) {
         const int col = row0 + q * 16 + li;

@@ -42,7 +42,6 @@ struct SkinnyArgs {
     int rope_cols, head_dim;              // SK_QKV: columns [0, rope_cols) are rotated (q then k), pairs (2c, 2c+1)
     const float *rope_tab;                // [n][head_dim/2][2] cos, sin of this chunk's positions
     float *kring, *vring; int ring_cap, kv_dim, pos0, q_cols;   // k columns start at q_cols, v columns at q_cols + kv_dim
-    int dbg;                              // tuning only (VOX_HIP_SK_DBG, results are WRONG): 1 no X loads, 2 no W loads, 4 no MFMAs, 8 no epilogue
 };
 
 // x[m][k..k+7] (f32) -> three bf16x8 fragments (hi, mid, lo): exact split, vox_gemm.h split3
@@ -126,20 +125,10 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
 #pragma unroll
                 // plain (L1-allocating) loads on purpose: the two k steps of a chunk share their 128-byte lines
                 for (int b = 0; b < NB; b++) {
-                    if (a.dbg & 2) wqc[b][2 * q + ks] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-                    else wqc[b][2 * q + ks] = *reinterpret_cast<const uint4 *>(wrow[b][q] + c * 64 + ks * 32);
+                    wqc[b][2 * q + ks] = *reinterpret_cast<const uint4 *>(wrow[b][q] + c * 64 + ks * 32);
                 }
     };
     auto issue_x = [&](float4 (&xq)[MT][4][XR], int c) {
-        if (a.dbg & 1) {
-#pragma unroll
-            for (int s = 0; s < 4; s++)
-#pragma unroll
-                for (int t = 0; t < MT; t++)
-#pragma unroll
-                    for (int p = 0; p < XR; p++) xq[t][s][p] = make_float4(1.f, 1.f, 1.f, 1.f);
-            return;
-        }
 #pragma unroll
         for (int u = 0; u < MU; u++)
 #pragma unroll
@@ -155,13 +144,6 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
             }
     };
     auto compute = [&](const uint4 (&wqc)[NB][4], const float4 (&xq)[MT][4][XR]) {
-        if (a.dbg & 4) {
-#pragma unroll
-            for (int b = 0; b < NB; b++)
-#pragma unroll
-                for (int t = 0; t < MT; t++) acc[b][0][t][0] += __uint_as_float(wqc[b][0].x) + xq[t][0][0].x + __uint_as_float(wqc[b][3].w) + xq[t][3][XR - 1].w;
-            return;
-        }
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             bf16x8_t fa[MU][3];
@@ -226,7 +208,6 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
     __syncthreads();
 
     // ---- epilogue over the tile: e -> (tile t, row, column) -> row m = 32 t + ((e >> 5) & 31), col = e & 31
-    if ((a.dbg & 8) && red[tid] != 12345.678f) return;
     for (int e = tid; e < MT * 1024; e += 64 * SK_WPB) {
         const int t = e >> 10;
         const int m = t * 32 + ((e >> 5) & 31);

@@ -418,6 +418,18 @@ def test_stream_full_size_continuous_restart_matches_reference_golden(vox):
     assert res["ref_steps"] > 2050, res          # i.e. the run did cross kv_cache_len > 2000 and decoded on after it
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "stream_full_batch300.npz")), reason="fixture not generated")
+def test_stream_full_size_300s_one_feed_matches_reference_golden(vox):
+    """The 300 s line of bench.py at the real 4B geometry: the 30 s night1968 clip tiled to 300 s, ONE feed - a 16 946-position
+    encoder pass (sliding window 750 over 20+ window lengths), 3761 decoder steps with the KV length growing to 3799 (the
+    in-kernel merge of more than 8 key slices, split sizes of 64 and 128 keys).  Every id against the reference's own run."""
+    g = gold("stream_full_batch300.npz")
+    with vox.Model(model_dir("full")) as m:
+        res = check_stream("full_batch300", g, run_case(m, g, None, None, False))
+    assert res["ok"], res
+    assert res["ref_steps"] > 3700, res
+
+
 def test_in_library_eight_shards_at_full_geometry_match_reference_golden(vox):
     """BASELINE config 4's encoder split at the real width: VOX_DEVICES = eight engines (all on this box's one GPU), the
     30 s golden clip -> shards of 212 rows (the planes GEMM with split-K, 128-query attention tiles with a 749-row halo

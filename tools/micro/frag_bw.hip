@@ -50,6 +50,50 @@ __global__ __launch_bounds__(512) void k_frag(const unsigned char *W, unsigned *
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[blockIdx.x] = 1;
 }
+// the round structure of k_rowsgemm: two register sets used alternately; per round "everything requested has landed", a workgroup
+// barrier, the next round's request, then this round's data is consumed
+template <int PAT>
+__global__ __launch_bounds__(512) void k_frag_rounds(const unsigned char *W, unsigned *sink) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = (blockIdx.x * 8 + wave) * 64;
+    const size_t kb0 = (size_t)blockIdx.y * ROUNDS * 128;
+    u32x4 acc = {0, 0, 0, 0};
+    u32x4 ra[8], rb[8];
+    auto issue = [&](int rd, u32x4 (&dst)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            size_t off;
+            if (PAT == FRAG) off = (size_t)(row0 + (i & 1) * 32 + (lane & 31)) * K2 + kb0 + rd * 128 + (i >> 1) * 32 + (lane >> 5) * 16;
+            else if (PAT == HALF) off = (size_t)(row0 + (i >> 1) * 16 + (lane & 15)) * K2 + kb0 + rd * 128 + (i & 1) * 64 + (lane >> 4) * 16;
+            else off = (size_t)(row0 + i * 8 + (lane >> 3)) * K2 + kb0 + rd * 128 + (lane & 7) * 16;
+            dst[i] = *reinterpret_cast<const u32x4 *>(W + off);
+        }
+    };
+    issue(0, ra);
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (rd & 1) { if (rd + 1 < ROUNDS) issue(rd + 1, ra); for (int i = 0; i < 8; i++) acc ^= rb[i]; }
+        else { if (rd + 1 < ROUNDS) issue(rd + 1, rb); for (int i = 0; i < 8; i++) acc ^= ra[i]; }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[blockIdx.x] = 1;
+}
+template <int PAT>
+static void run_rounds(const char *name, const unsigned char *buf, size_t bufbytes, unsigned *sink) {
+    const size_t per_launch = (size_t)18432 * K2;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int reps = 40; size_t ofs = 0;
+    for (int i = 0; i < reps + 3; i++) {
+        if (i == 3) hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((k_frag_rounds<PAT>), dim3(36, 7), dim3(512), 0, 0, buf + ofs, sink);
+        ofs = (ofs + per_launch + 4096) % (bufbytes - per_launch - 8192); ofs &= ~(size_t)4095;
+    }
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / reps;
+    printf("%-44s %6.2f us/launch  %5.2f TB/s  (%s)\n", name, us, per_launch / us / 1e6, hipGetErrorString(hipGetLastError()));
+}
 template <int PAT, int DEPTH, bool NT>
 static void run(const char *name, const unsigned char *buf, size_t bufbytes, unsigned *sink) {
     const size_t per_launch = (size_t)18432 * K2;
@@ -84,6 +128,8 @@ int main() {
     run<LINE, 2, true>("LINE non-temporal, 2 rounds ahead", buf, bufbytes, sink);
     run<LINE, 3, true>("LINE non-temporal, 3 rounds ahead", buf, bufbytes, sink);
     run<LINE, 7, true>("LINE non-temporal, all up front", buf, bufbytes, sink);
+    run_rounds<HALF>("HALF, rounds with wait + barrier (k_rowsgemm)", buf, bufbytes, sink);
+    run_rounds<LINE>("LINE, rounds with wait + barrier", buf, bufbytes, sink);
     run<DMA, 1, false>("DMA (LINE -> LDS), 1 round ahead", buf, bufbytes, sink);
     run<DMA, 2, false>("DMA (LINE -> LDS), 2 rounds ahead", buf, bufbytes, sink);
     return 0;

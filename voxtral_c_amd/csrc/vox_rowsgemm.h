@@ -11,7 +11,7 @@
 //     fragments straight from L2: every one of the N / 32 workgroups re-reads all of x (3 planes x n x K x 2 B: 2.3 x the
 //     weight bytes at n = 25, 6 x at n = 64), and its register budget (all weight fragments up front + double-buffered
 //     activation fragments) stops at one 32-row activation tile.  Measured with the loads removed one by one
-//     (gpurun_out/p2, VOX_HIP_SK_DBG): the x loads cost as much as the weight loads (4 - 5 us of a 12 - 16 us launch).
+//     (a debug build with the loads switched off one by one): the x loads cost as much as the weight loads (4 - 5 us of a 12 - 16 us launch).
 //
 // Here the roles are turned around: the waves of a workgroup own DIFFERENT weight tiles (8 x 32 = 256 rows of W, or 4 x 32)
 // and the SAME K range (CPW chunks of 64), K is split over blockIdx.y.  The activation K range (3 bf16 planes x n rows x
@@ -19,10 +19,10 @@
 // - and every wave reads its MFMA A fragments from there; a wave's weight fragments (B operand, 16 bytes per lane in
 // fragment layout straight from global memory, CPW x 4 registers) are all requested up front.  x traffic drops by the
 // number of waves per workgroup (8 x), no wave waits for another except at the one barrier, the accumulators go straight
-// from registers to the partial-sum buffer [split][n][N] (no LDS reduction), and up to four 32-row activation tiles cost
-// 16 accumulator registers each.  The K splits are added in split order by whoever consumes them (k_rows_finish for the
+// from registers to the partial-sum buffer [split][n][N] (no LDS reduction), and up to eight 16-row activation tiles cost
+// 4 accumulator registers each per weight tile.  The K splits are added in split order by whoever consumes them (k_rows_finish for the
 // residual + next RMSNorm, k_qkv_finish for bias + RoPE + KV append, k_swiglu_finish for the gate): deterministic, no atomics.
-// Arithmetic: exact bf16 weights x the exact 3-term bf16 split of the f32 activations on v_mfma_f32_32x32x16_bf16, f32
+// Arithmetic: exact bf16 weights x the exact 3-term bf16 split of the f32 activations on v_mfma_f32_16x16x32_bf16, f32
 // accumulation = the reference's cblas_sgemm / bf16_matvec up to summation order (vox_gemm.h).
 #pragma once
 #include "vox_common.h"

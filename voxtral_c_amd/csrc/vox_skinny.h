@@ -5,11 +5,11 @@
 // padding at n = 25, split-K reduce launches, separate RoPE / ring-append / SiLU / RMSNorm kernels).  Measured in round 1
 // (gpurun_out/prof_stream/r1_kernel_stats.csv): ~130 us per layer for a 25-row chunk against 60.3 MB / 6.3 TB/s = 9.6 us.
 // Reference: vox_encoder_forward_incremental, voxtral_encoder.c:452-636 (same arithmetic: exact bf16 weights x f32
-// activations, f32 accumulation; here through the exact 3-term bf16 split of the activations on v_mfma_f32_32x32x16_bf16).
+// activations, f32 accumulation; here through the exact 3-term bf16 split of the activations on v_mfma_f32_16x16x32_bf16).
 //
-// One wave = one 32-row tile of W (the MFMA's B operand, 16 bytes per lane straight from global memory in fragment
-// layout: lane (li, lg) reads W[row0 + li][k + 8 lg .. +7]) x all n activation rows (A operand: x[m][k + 8 lg .. +7] as
-// f32 from L2, split into hi / mid / lo bf16 in registers) x a set of 64-wide K chunks.  No LDS staging and no barrier
+// One wave = one 32-row tile of W (two 16-row MFMA B operands, 16 bytes per lane straight from global memory in fragment
+// layout: lane (li, kb) reads W[row0 + 16 q + li][k + 8 kb .. +7]) x all n activation rows (A operands: x[m][k + 8 kb .. +7] as
+// f32 from L2, split into hi / mid / lo bf16 in registers, or pre-split planes) x a set of 64-wide K chunks.  No LDS staging and no barrier
 // in the main loop: every wave streams independently with the next chunk's loads in flight under the current chunk's
 // MFMAs.  The waves of a workgroup (WPB = 8) share a W tile and split K; their accumulators are added in wave order
 // through LDS (deterministic), then the epilogue runs on the 32 x 32 (or 64 x 32) tile:

@@ -72,12 +72,14 @@ def headline_audio(seconds):
     reps = -(-n // len(base))
     tiled = np.tile(base, reps)[:n].copy()
     # the 300 s line has its own golden: the reference's run on exactly this tiling, one feed (tools/make_golden.py LONG_CASES)
-    long_path = os.path.join(ROOT, "tests", "golden", "stream_full_batch300.npz")
-    if os.path.exists(long_path):
+    for long_name in ("stream_full_batch300.npz", "stream_full_batch600.npz"):
+        long_path = os.path.join(ROOT, "tests", "golden", long_name)
+        if not os.path.exists(long_path):
+            continue
         try:
             gl = np.load(long_path, allow_pickle=True)
             if int(gl["audio_total_samples"]) == n and np.array_equal(gl["audio_i16"], g["audio_i16"]):
-                return tiled, gl, f"the 30 s night1968 clip tiled to {seconds:g} s (the input of tests/golden/stream_full_batch300.npz)"
+                return tiled, gl, f"the 30 s night1968 clip tiled to {seconds:g} s (the input of tests/golden/{long_name})"
         except Exception:
             pass
     return tiled, None, f"the 30 s night1968 clip of tests/golden/stream_full_batch.npz tiled to {seconds:g} s"
@@ -94,7 +96,8 @@ def parity_block(tokens, g):
     first = next((int(i) for i in range(n) if t[i] != ref[i]), None)
     return {"checked": True, "steps": int(len(ref)), "mismatches": mism, "first_mismatch": first,
             "distinct_ref_tokens": int(len(set(ref.tolist()))), "min_ref_margin": float(g["margin"].min()),
-            "golden": ("tests/golden/stream_full_batch300.npz" if len(ref) > 1000 else "tests/golden/stream_full_batch.npz") +
+            "golden": ("tests/golden/stream_full_batch600.npz" if len(ref) > 5000 else "tests/golden/stream_full_batch300.npz" if len(ref) > 1000
+                       else "tests/golden/stream_full_batch.npz") +
                       " (reference CPU path, oracle/_ref, same checkpoint + audio)"}
 
 

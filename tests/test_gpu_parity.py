@@ -430,6 +430,20 @@ def test_stream_full_size_300s_one_feed_matches_reference_golden(vox):
     assert res["ref_steps"] > 3700, res
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "stream_full_batch600.npz")), reason="fixture not generated")
+def test_stream_full_size_600s_one_feed_ids_match_reference_golden(vox):
+    """BASELINE config 4's audio length on one GPU at the real geometry: 600 s in ONE feed - a 30 196-position encoder pass and
+    7511 decoder steps on the production path (steps enqueued back to back, ids read at the end), KV length to 7549.  Ids
+    only (the per-step logit comparison of the other goldens would hold 4 GB of logits rows on the host)."""
+    g = gold("stream_full_batch600.npz")
+    with vox.Model(model_dir("full")) as m:
+        got = np.asarray(m.transcribe(golden_audio(g))["tokens"])
+    ref = g["tokens"]
+    assert len(got) == len(ref) and len(ref) > 7400, (len(got), len(ref))
+    bad = np.nonzero(got != ref)[0]
+    assert len(bad) == 0, (int(len(bad)), int(bad[0]), float(g["margin"][bad[0]]))
+
+
 def test_in_library_eight_shards_at_full_geometry_match_reference_golden(vox):
     """BASELINE config 4's encoder split at the real width: VOX_DEVICES = eight engines (all on this box's one GPU), the
     30 s golden clip -> shards of 212 rows (the planes GEMM with split-K, 128-query attention tiles with a 749-row halo

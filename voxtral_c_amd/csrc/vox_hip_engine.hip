@@ -1789,8 +1789,13 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.err = e->d_fuse_err; a.spin_limit = 500000ull;         // 5 ms at the 100 MHz wall clock (a hand-off takes microseconds)
                 a.trace = (l == 13) ? e->d_fuse_trace : nullptr;          // tuning: phase stamps of one mid-stack launch
                 a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl : nullptr;
-                static const int spread = getenv("VOX_HIP_FUSE_SPREAD") ? 1 : 0;    // test: group members on all XCDs
-                a.spread_groups = spread;
+                // Group members on all XCDs (group = blockIdx / 32) instead of one XCD per group (blockIdx % 8): the hand-offs then
+                // cross XCDs (+0.3 us each, timeline), but a group's K/V tiles and Wo rows come through all eight L2s - measured on
+                // one box, alternating runs: 232 keys 1.382 -> 1.392 ms per step, 600: 1.485 -> 1.478, 1900: 1.593 -> 1.562,
+                // 3800: 1.724 -> 1.679, 8000: 1.896 -> 1.860.  So: spread beyond 8 key slices (KV > 512).
+                // VOX_HIP_FUSE_SPREAD=1 / =0 forces it on / off.
+                static const int spread_env = getenv("VOX_HIP_FUSE_SPREAD") ? atoi(getenv("VOX_HIP_FUSE_SPREAD")) : -1;
+                a.spread_groups = spread_env >= 0 ? (spread_env != 0) : (f_ns > 8);
                 static const int serial_wo = getenv("VOX_HIP_FUSE_SERIAL_WO") ? 1 : 0;
                 a.wo_serial_reduce = serial_wo;
                 static const int merge3 = getenv("VOX_HIP_FUSE_MERGE3") ? 1 : 0;

@@ -41,6 +41,7 @@ struct AttnArgs {
     int window;
     const DecState *st;             // decoder step: qpos0 = st->pos (when non-null)
     // split-K (decoder)
+    int xcd_map;                    // k_attn_enc_mfma: remap (tile, head) so that a head's query tiles share an XCD (see there)
     int split_keys;                 // keys per blockIdx.y
     float *part_o, *part_ml;        // [n_q][n_heads][nsplit][HD], [..][2]
     int force_partials;             // write partials even when nsplit == 1 (merged by the Wo GEMV prologue)
@@ -194,8 +195,16 @@ __global__ __launch_bounds__(256) void k_attn_enc_mfma(const AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lg = lane >> 5;
-    const int h = blockIdx.y;
-    const int q_first = blockIdx.x * 128;
+    // (head, query tile) from the launch-order index so that all query tiles of a head run on ONE XCD (workgroups go to the XCDs
+    // round robin in launch order, x fastest): neighbouring tiles of a head read almost the same 750-key window of its K / V, and
+    // with blockIdx = (tile, head) a head's 13 tiles were spread over all eight L2s, each of which fetched the head's K / V for itself.
+    int h = blockIdx.y, qtile = blockIdx.x;
+    if (a.xcd_map && (gridDim.y & 7) == 0) {
+        const int lid = blockIdx.x + gridDim.x * blockIdx.y, k = lid >> 3, hpx = gridDim.y >> 3;
+        h = (lid & 7) + 8 * (k % hpx);
+        qtile = k / hpx;
+    }
+    const int q_first = qtile * 128;
     const int qi = q_first + wave * 32 + li;            // this lane's query
     const bool qvalid = qi < a.n_q;
     const int P = a.qpos0 + qi;

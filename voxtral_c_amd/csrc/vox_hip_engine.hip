@@ -860,6 +860,8 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
                 if (ensure(e, e->spart_ml, (size_t)n * c.heads * ks * 2 * 4)) return -1;
                 a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
             }
+            static const int attn_xcd = getenv("VOX_HIP_ATTN_NO_XCD") ? 0 : 1;
+            a.xcd_map = attn_xcd;
             if (e->use_attn_mfma && c.hd == 64 && c.heads == c.kv_heads)
                 hipLaunchKernelGGL(k_attn_enc_mfma, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
             else
@@ -975,6 +977,8 @@ static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float 
         if (ensure(e, e->spart_ml, (size_t)n * c.heads * ks * 2 * 4)) return -1;
         a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
     }
+    static const int attn_xcd = getenv("VOX_HIP_ATTN_NO_XCD") ? 0 : 1;
+    a.xcd_map = attn_xcd;
     if (e->use_attn_mfma && c.hd == 64 && c.heads == c.kv_heads)
         hipLaunchKernelGGL(k_attn_enc_mfma, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
     else

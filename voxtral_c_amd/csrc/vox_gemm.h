@@ -50,6 +50,8 @@ struct GemmArgs {
     // GP_EPI_ROPE applies the interleaved-pair RoPE (table [M][head_dim / 2][cos, sin]) to the first rope_cols columns
     uint16_t *Yp; size_t yp_plane;
     const float *rope_tab; int rope_cols, head_dim;
+    // k_gemm_planes, split-K launches: 1-D grid in XCD-aware order (xcd_tn = N tiles, xcd_tm = M tiles; 0 = plain 3-D grid)
+    int xcd_tn, xcd_tm;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -62,11 +64,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
 template <int TN = 2>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[2][TN], int bm0, int bn0, int wm, int wn,
-                                              int li, int lg) {
+                                              int li, int lg, int zslice = -1) {
     const int M = a.M, N = a.N;
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
     if (a.ksplit > 1) {
-        float *P = a.partial + (size_t)blockIdx.z * M * N;
+        float *P = a.partial + (size_t)(zslice >= 0 ? zslice : (int)blockIdx.z) * M * N;
 #pragma unroll
         for (int tm = 0; tm < 2; tm++)
 #pragma unroll

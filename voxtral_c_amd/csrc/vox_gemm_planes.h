@@ -56,7 +56,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int bm0 = blockIdx.y * GB_M, bn0 = blockIdx.x * BN;
+    // Tile of this workgroup.  Split-K launches (wo, w2: 10 N tiles x 13 M tiles x 3 K slices at the 30 s clip) come as a 1-D grid in
+    // XCD-aware order: workgroups go to the eight XCDs round robin in launch order, and the (M tile, K slice) groups - the 10 workgroups
+    // that read the same 3 x 128 x K/3 slab of activation planes - are dealt to the XCDs whole, so that a slab is fetched into ONE L2
+    // instead of up to eight (with the plain 3-D grid, whose x extent is not a multiple of 8, every L2 ended up reading most of A).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (a.xcd_tn > 0) {
+        const int lid = blockIdx.x, k = lid >> 3, gi = (lid & 7) + 8 * (k / a.xcd_tn);
+        if (gi >= a.xcd_tm * a.ksplit) return;                       // padding workgroups of the last round of groups
+        bx = k % a.xcd_tn; by = gi % a.xcd_tm; bz = gi / a.xcd_tm;
+    }
+    const int bm0 = by * GB_M, bn0 = bx * BN;
     const int M = a.M, N = a.N, K = a.K;
 
     f32x16 acc[2][TN];
@@ -85,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
                 // a workgroup covers 64 hidden columns; tile row r = 64 wn + 32 tn + li holds gate (tn = 0: w1) or up (tn = 1: w3)
                 // of column 64 blockIdx.x + 32 wn + li, so that a lane's two accumulator tiles are the pair the gate needs
                 static_assert(EPI != GP_EPI_SWIGLU || TN == 2, "the SwiGLU epilogue pairs the two N tiles of a wave");
-                wrow = ((row >> 5) & 1) * N + min((int)blockIdx.x * 64 + (row >> 6) * 32 + (row & 31), N - 1);
+                wrow = ((row >> 5) & 1) * N + min(bx * 64 + (row >> 6) * 32 + (row & 31), N - 1);
             }
             src[i] = reinterpret_cast<const unsigned char *>(a.W + (size_t)wrow * K) + dchunk * 16;
         }
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
     }
 
     const int nk_total = K / GP_K;
-    const int kt0 = (a.ksplit > 1) ? blockIdx.z * a.kper : 0;
+    const int kt0 = (a.ksplit > 1) ? bz * a.kper : 0;
     const int kt1 = (a.ksplit > 1) ? min(nk_total, kt0 + a.kper) : nk_total;
     const int nk = kt1 - kt0;
 
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
     for (int tt = 0; tt < TN; tt++) {
         const int row = wn * (32 * TN) + tt * 32 + li;               // row of the workgroup's B tile
         int wrow = min(bn0 + row, N - 1);
-        if constexpr (EPI == GP_EPI_SWIGLU) wrow = ((row >> 5) & 1) * N + min((int)blockIdx.x * 64 + (row >> 6) * 32 + (row & 31), N - 1);
+        if constexpr (EPI == GP_EPI_SWIGLU) wrow = ((row >> 5) & 1) * N + min(bx * 64 + (row >> 6) * 32 + (row & 31), N - 1);
         bsrc[tt] = a.W + (size_t)wrow * K + lg * 8;
     }
     uint4 bcur[TN][2], bnxt[TN][2];
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
     }
     if constexpr (EPI == GP_EPI_SWIGLU) {
         // h = silu(gate) * up (voxtral_encoder.c:598-606), written as the bf16 planes the W2 launch consumes
-        const int col = (int)blockIdx.x * 64 + wn * 32 + li;
+        const int col = bx * 64 + wn * 32 + li;
         if (col < N) {
 #pragma unroll
             for (int tm = 0; tm < 2; tm++)
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
                 }
             }
     } else {
-        gemm_epilogue<TN>(a, acc, bm0, bn0, wm, wn, li, lg);
+        gemm_epilogue<TN>(a, acc, bm0, bn0, wm, wn, li, lg, bz);
     }
 }
 

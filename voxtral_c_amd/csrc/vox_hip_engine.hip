@@ -422,8 +422,16 @@ static int launch_gemm_planes(vox_hip_engine *e, const uint16_t *Xp, size_t plan
         if (ensure(e, e->ssplitk, (size_t)ksplit * M * N * 4)) return -1;
         a.ksplit = ksplit; a.kper = (nk + ksplit - 1) / ksplit; a.partial = (float *)e->ssplitk.p;
         a.ksplit = (nk + a.kper - 1) / a.kper;
-        dim3 grid(tn, tm, a.ksplit);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, e->stream, a);
+        static const int gp_xcd = getenv("VOX_HIP_GP_NO_XCD") ? 0 : 1;
+        if (gp_xcd) {           // 1-D grid in XCD-aware order (vox_gemm_planes.h): groups of tn workgroups sharing an A slab stay on one XCD
+            a.xcd_tn = tn; a.xcd_tm = tm;
+            const int groups = tm * a.ksplit;
+            hipLaunchKernelGGL(kern, dim3(8 * ((groups + 7) / 8) * tn), dim3(256), lds, e->stream, a);
+            a.xcd_tn = 0;
+        } else {
+            dim3 grid(tn, tm, a.ksplit);
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, e->stream, a);
+        }
         hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((size_t)M * N)), dim3(256), 0, e->stream, a);
     } else {
         hipLaunchKernelGGL(kern, dim3(tn, tm), dim3(256), lds, e->stream, a);

@@ -156,3 +156,27 @@ def test_public_api_tolerates_null_and_missing_inputs():
     n = C.c_int(0)
     assert not lib.vox_load_wav(b"/nonexistent.wav", C.byref(n))
     assert not lib.vox_tokenizer_load(b"/nonexistent.json")
+
+
+def test_bench_picks_the_golden_that_belongs_to_the_audio_length():
+    """bench.py's parity block compares the timed run's ids with the reference's run on EXACTLY the timed input: the 30 s golden for
+    the headline, the tiled-clip goldens for --seconds 300 / 600 (when generated), nothing for other lengths."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    a30, g30, _ = bench.headline_audio(30.0)
+    assert g30 is not None and len(a30) == 480000 and len(g30["tokens"]) == 386
+    par = bench.parity_block(g30["tokens"], g30)
+    assert par["checked"] and par["mismatches"] == 0 and "stream_full_batch.npz" in par["golden"]
+    bad = np.array(g30["tokens"]).copy(); bad[100] += 1
+    par = bench.parity_block(bad, g30)
+    assert par["mismatches"] == 1 and par["first_mismatch"] == 100
+    a300, g300, desc = bench.headline_audio(300.0)
+    assert len(a300) == 300 * 16000 and np.array_equal(a300[:480000], a30) and np.array_equal(a300[480000:960000], a30)
+    if os.path.exists(os.path.join(ROOT, "tests", "golden", "stream_full_batch300.npz")):
+        assert g300 is not None and len(g300["tokens"]) == 3761 and "batch300" in desc
+        assert "stream_full_batch300.npz" in bench.parity_block(g300["tokens"], g300)["golden"]
+    a45, g45, _ = bench.headline_audio(45.0)
+    assert g45 is None and len(a45) == 45 * 16000
+    assert bench.parity_block([1, 2, 3], None) == {"checked": False, "reason": "no golden for this length / preset"}

@@ -177,6 +177,10 @@ def test_bench_picks_the_golden_that_belongs_to_the_audio_length():
     if os.path.exists(os.path.join(ROOT, "tests", "golden", "stream_full_batch300.npz")):
         assert g300 is not None and len(g300["tokens"]) == 3761 and "batch300" in desc
         assert "stream_full_batch300.npz" in bench.parity_block(g300["tokens"], g300)["golden"]
+    if os.path.exists(os.path.join(ROOT, "tests", "golden", "stream_full_batch600.npz")):
+        a600, g600, desc = bench.headline_audio(600.0)
+        assert len(a600) == 600 * 16000 and g600 is not None and len(g600["tokens"]) == 7511 and "batch600" in desc
+        assert "stream_full_batch600.npz" in bench.parity_block(g600["tokens"], g600)["golden"]
     a45, g45, _ = bench.headline_audio(45.0)
     assert g45 is None and len(a45) == 45 * 16000
     assert bench.parity_block([1, 2, 3], None) == {"checked": False, "reason": "no golden for this length / preset"}

@@ -57,38 +57,46 @@ def decode_bytes(d, kv_len):
     return w, kv, kern
 
 
-def headline_audio(seconds):
-    """(samples, golden or None): the SURVEY 8(d) 30 s input from the golden fixture, tiled for longer runs."""
+# goldens generated from oracle/_ref (tools/make_golden.py) by feed pattern: one feed of the whole clip / BASELINE config 3's feeds
+# (0.5 s pieces, -I 0.5, continuous mode)
+GOLDENS = {"batch": ("stream_full_batch300.npz", "stream_full_batch600.npz"),
+           "stream": ("stream_full_stream300.npz", "stream_full_continuous.npz", "stream_full_stream.npz")}
+
+
+def headline_audio(seconds, mode="batch"):
+    """(samples, golden or None, golden file name or None, description): the SURVEY 8(d) 30 s input from the golden
+    fixture, tiled for longer runs; the golden is the reference's own run on exactly these samples and this feed pattern."""
     path = os.path.join(ROOT, "tests", "golden", "stream_full_batch.npz")
     try:
         g = np.load(path, allow_pickle=True)
         base = g["audio_i16"].astype(np.float32) / 32768.0
     except Exception:
         from audio_util import synth_speech
-        return synth_speech(seconds, 1234), None, "synthetic speech-like signal (tests/audio_util.py); golden fixture missing"
+        return synth_speech(seconds, 1234), None, None, "synthetic speech-like signal (tests/audio_util.py); golden fixture missing"
     n = int(round(seconds * 16000))
-    if n == len(base):
-        return base, g, "first 480000 samples of night1968/45s_right_through_the_billboard.wav (SURVEY 8(d)), from tests/golden/stream_full_batch.npz"
+    if n == len(base) and mode == "batch":
+        return base, g, "stream_full_batch.npz", \
+            "first 480000 samples of night1968/45s_right_through_the_billboard.wav (SURVEY 8(d)), from tests/golden/stream_full_batch.npz"
     reps = -(-n // len(base))
     tiled = np.tile(base, reps)[:n].copy()
-    # the 300 s line has its own golden: the reference's run on exactly this tiling, one feed (tools/make_golden.py LONG_CASES)
-    for long_name in ("stream_full_batch300.npz", "stream_full_batch600.npz"):
+    for long_name in GOLDENS[mode]:
         long_path = os.path.join(ROOT, "tests", "golden", long_name)
         if not os.path.exists(long_path):
             continue
         try:
             gl = np.load(long_path, allow_pickle=True)
-            if int(gl["audio_total_samples"]) == n and np.array_equal(gl["audio_i16"], g["audio_i16"]):
-                return tiled, gl, f"the 30 s night1968 clip tiled to {seconds:g} s (the input of tests/golden/{long_name})"
+            total = int(gl["audio_total_samples"]) if "audio_total_samples" in gl.files else len(gl["audio_i16"])
+            if total == n and np.array_equal(gl["audio_i16"][:min(n, len(base))], g["audio_i16"][:min(n, len(base))]):
+                return tiled, gl, long_name, f"the 30 s night1968 clip tiled / cut to {seconds:g} s (the input of tests/golden/{long_name})"
         except Exception:
             pass
-    return tiled, None, f"the 30 s night1968 clip of tests/golden/stream_full_batch.npz tiled to {seconds:g} s"
+    return tiled, None, None, f"the 30 s night1968 clip of tests/golden/stream_full_batch.npz tiled / cut to {seconds:g} s"
 
 
-def parity_block(tokens, g):
+def parity_block(tokens, g, golden_name=None):
     """Token ids of the timed pass against the reference's own run (golden generated from oracle/_ref)."""
     if g is None:
-        return {"checked": False, "reason": "no golden for this length / preset"}
+        return {"checked": False, "reason": "no golden for this length / feed pattern / preset"}
     ref = g["tokens"]
     t = np.asarray(tokens)
     n = min(len(t), len(ref))
@@ -96,9 +104,7 @@ def parity_block(tokens, g):
     first = next((int(i) for i in range(n) if t[i] != ref[i]), None)
     return {"checked": True, "steps": int(len(ref)), "mismatches": mism, "first_mismatch": first,
             "distinct_ref_tokens": int(len(set(ref.tolist()))), "min_ref_margin": float(g["margin"].min()),
-            "golden": ("tests/golden/stream_full_batch600.npz" if len(ref) > 5000 else "tests/golden/stream_full_batch300.npz" if len(ref) > 1000
-                       else "tests/golden/stream_full_batch.npz") +
-                      " (reference CPU path, oracle/_ref, same checkpoint + audio)"}
+            "golden": f"tests/golden/{golden_name} (reference CPU path, oracle/_ref, same checkpoint + audio + feed pattern)"}
 
 
 def live_pmc_traffic(kernel_substr, timeout_s=240):
@@ -164,7 +170,7 @@ def cpu_baseline(model_dir_full, preset_dims):
         est = t_enc * 1696 / 100 + t_pre + 386 * t_step
         measured = None
         try:       # the unmodified reference CLI run end to end on a GPU-box host (tools/cpu_baseline_cli.py), committed per round
-            for prof in ("r03_cpu_baseline_cli.json", "r02_cpu_baseline_cli.json"):
+            for prof in ("r04_cpu_baseline_cli.json", "r03_cpu_baseline_cli.json", "r02_cpu_baseline_cli.json"):
                 fp = os.path.join(ROOT, "profiles", prof)
                 if os.path.exists(fp):
                     with open(fp) as fh:
@@ -173,7 +179,7 @@ def cpu_baseline(model_dir_full, preset_dims):
         except Exception:
             pass
         return {"value": round(est / 30.0, 2), "unit": "wall s / audio s (RTF), 30 s clip, extrapolated from the sample",
-                "measured_end_to_end": measured,
+                "builder_run_end_to_end": measured,
                 "cores": os.cpu_count(), "kind": "reference",
                 "threads_note": "decode GEMV is single-threaded in the reference; OpenBLAS threads only in the M>1 GEMMs",
                 "decode_tok_s": round(1.0 / t_step, 3), "ms_per_decode_step": round(t_step * 1e3, 1),
@@ -242,7 +248,7 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True):
         traffic, traffic_source = live_pmc_traffic(DOM_KERNEL_SUBSTR)
     if traffic is None:
         why = traffic_source
-        for prof in ("r03_pmc_decode_summary.json", "r02_pmc_decode_summary.json", "r01_pmc_decode_summary.json"):
+        for prof in ("r04_pmc_decode_summary.json", "r03_pmc_decode_summary.json", "r02_pmc_decode_summary.json", "r01_pmc_decode_summary.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", prof)) as fh:
                     pm = json.load(fh)["kernels"]
@@ -285,13 +291,57 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True):
     return roofline
 
 
-def stream_mode(args, model, audio, v):
+def enc_layer_bytes(d):
+    """bf16 weight bytes of one encoder layer (wq;wk;wv, wo, w1;w3, w2): 60.3 MB at the 4B geometry."""
+    qd = d.enc_heads * d.enc_head_dim
+    return 2 * (3 * qd * d.enc_dim + d.enc_dim * qd + 3 * d.enc_hidden * d.enc_dim)
+
+
+def cpu_baseline_stream(model_dir_full, d, feed_s=0.5):
+    """The reference on this host for ONE 0.5 s feed of BASELINE config 3: a 25-row encoder chunk (behind 100 rows of
+    context) and the 6.25 decoder steps that go with it; bounded sample (~15 s of CPU)."""
+    try:
+        from oracle.ref_binding import RefLib, ref_available
+        if not ref_available("full"):
+            return None
+        R = RefLib("full")
+        ctx = R.load(model_dir_full)
+        rng = np.random.default_rng(0)
+        x = rng.standard_normal((125, d.enc_dim)).astype(np.float32)
+        R.encoder_forward_incremental(ctx, x[:100], d.enc_dim)
+        t0 = time.time(); R.encoder_forward_incremental(ctx, x[100:], d.enc_dim); t_enc = time.time() - t0
+        emb = (rng.standard_normal((64, d.dec_dim)) * 0.5).astype(np.float32)
+        R.decoder_prefill(ctx, emb[:38])
+        n_steps = 12
+        t0 = time.time()
+        for i in range(n_steps):
+            R.decoder_forward(ctx, emb[38 + i], d.vocab)
+        t_step = (time.time() - t0) / n_steps
+        R.free(ctx)
+        per_feed = t_enc + feed_s * 12.5 * t_step
+        return {"value": round(per_feed / feed_s, 2), "unit": "wall s / audio s (RTF) of one 0.5 s feed, from the sample",
+                "cores": os.cpu_count(), "kind": "reference",
+                "threads_note": "decode GEMV is single-threaded in the reference; OpenBLAS threads only in the M>1 GEMMs",
+                "encoder_25rows_s": round(t_enc, 3), "ms_per_decode_step": round(t_step * 1e3, 1),
+                "feed_latency_ms": round(per_feed * 1e3, 1),
+                "sample": "oracle/_ref (reference sources, -O3 -ffast-math, OpenBLAS) on the full-size synthetic checkpoint: one 25-row "
+                          "vox_encoder_forward_incremental call behind 100 rows of context (the real window is 750: a lower bound) + "
+                          "12 vox_decoder_forward steps after a 38-row prefill; one feed = the chunk + 6.25 steps"}
+    except Exception as ex:  # the baseline must never take the benchmark down
+        return {"error": str(ex)}
+
+
+def stream_mode(args, model, audio, v, dims, golden, golden_name, audio_desc, mdir):
     """BASELINE config 3: the clip arrives in 0.5 s pieces (vox_stream_feed per piece, -I 0.5,
     continuous mode so the decoder KV rolls over); not paced to real time — the per-chunk latency
-    is what a live feed would see."""
+    is what a live feed would see.  The ids of the last timed pass are compared with the reference's own run of
+    the same feeds (`parity`); the roofline object is the few-rows encoder path that every feed runs (25-row chunk,
+    32 layers), measured live with HIP events, next to the decode step that follows it."""
+    import ctypes as C
     chunk = 8000
     lat = []
     ntok = 0
+    toks = None
     t_all = time.time()
     for rep in range(args.warmup + args.steps):
         s = v.Stream(model)
@@ -309,24 +359,57 @@ def stream_mode(args, model, audio, v):
         t0 = time.time()
         s.finish(); s.get()
         lat.append(time.time() - t0)
-        ntok += len(s.token_ids())
+        toks = s.token_ids()
+        ntok += len(toks)
         s.free()
     v.hip.vox_hip_sync(model.engine)
     wall = time.time() - t_all
     lat = np.asarray(lat) * 1e3
+    # ---- roofline of the chunk path: the 32 encoder layers on a 25-row chunk behind a full K/V window, HIP events ----
+    v.hip.vox_hip_time_encoder_rows.restype = C.c_double
+    v.hip.vox_hip_time_encoder_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    rows = 25
+    t_chunk = v.hip.vox_hip_time_encoder_rows(model.engine, rows, dims.enc_window, 30)
+    lbytes = enc_layer_bytes(dims)
+    us_layer = t_chunk * 1e6 / dims.enc_layers if t_chunk > 0 else None
+    ach = lbytes / (us_layer * 1e-6) / 1e9 if us_layer else 0.0
+    kv_len = int(min(1000, dims.dec_window))          # continuous mode restarts the stream at 2000 positions: the mean is ~1000
+    s_step = model.time_decoder_step(50, kv_len)
+    wbytes, kvbytes, _ = decode_bytes(dims, kv_len)
+    roofline = {
+        "bound": "hbm", "kernel": "few-rows encoder layer of a 25-row streaming chunk (k_skinny x4, k_attn_small, k_attn_combine, "
+                                  "k_rows_finish x2: voxtral_encoder.c:452-636), all launches of one layer together",
+        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+        "bytes_per_launch": lbytes, "avg_us_per_launch": None if us_layer is None else round(us_layer, 2),
+        "launch_unit": "one encoder layer (its launches back to back); a chunk is %d layers = %.3f ms" % (dims.enc_layers, t_chunk * 1e3),
+        "method": "HIP events on the engine stream around 30 passes of all encoder layers on a 25-row chunk behind a full "
+                  "750-position K/V window (vox_hip_time_encoder_rows), resident weights",
+        "traffic": None, "traffic_source": "not collected for this path (the weights are read once per chunk: k_skinny loads every weight "
+                                           "fragment exactly once, profiles/r03_stream_kernel_stats.csv)",
+        "decode_step": {"algorithmic_bytes": wbytes + kvbytes, "ms": round(s_step * 1e3, 4), "kv_len": kv_len,
+                        "GBps": round((wbytes + kvbytes) / s_step / 1e9, 1),
+                        "frac_of_peak": round((wbytes + kvbytes) / s_step / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "6.25 of these follow every chunk: the decoder is ~80 % of a feed's latency"},
+    }
+    mask, path_names = model.active_paths()
     out = {
         "metric": "real-time-factor, Voxtral-4B bf16, streaming (0.5 s feeds, -I 0.5, rolling KV)",
         "value": round(wall / args.steps / args.seconds, 5), "unit": "wall s / audio s (RTF)", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 2),
         "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16 weights, f32 activations/accumulate", "data": "synthetic",
+        "data_note": "weights: seeded synthetic checkpoint of the exact architecture (no real weights offline); audio: " + audio_desc,
+        "parity": parity_block(toks, golden, golden_name), "active_paths": path_names,
         "chunk_latency_ms": {"mean": round(float(lat.mean()), 2), "p50": round(float(np.percentile(lat, 50)), 2),
                              "p99": round(float(np.percentile(lat, 99)), 2), "max": round(float(lat.max()), 2)},
         "tokens_per_pass": ntok / args.steps,
         "config": {"workload": f"Voxtral-4B (full synthetic checkpoint) on 1xMI355X, {args.seconds:g} s 16 kHz mono fed in 0.5 s pieces, "
                                "processing interval 0.5 s, continuous mode (rolling 8192-position KV), greedy decode",
                    "audio_seconds": args.seconds, "preset": args.preset},
+        "roofline": roofline,
     }
+    if not args.no_cpu_baseline and args.preset == "full":
+        out["cpu_baseline"] = cpu_baseline_stream(mdir, dims)
     model.close()
     print(json.dumps(out))
 
@@ -336,7 +419,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--seconds", type=float, default=30.0, help="audio seconds per GPU")
+    ap.add_argument("--seconds", type=float, default=None, help="audio seconds per GPU (default: 30, the headline; 300 with --mode stream)")
     ap.add_argument("--preset", default="full", help="full | small | tiny (full = Voxtral-4B shapes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cold-load", action="store_true",
@@ -348,6 +431,8 @@ def main():
                     help="batch: the headline (one feed of the whole clip); stream: BASELINE config 3, 0.5 s feeds at -I 0.5, "
                          "continuous mode (rolling KV), reports per-chunk latency as well")
     args = ap.parse_args()
+    if args.seconds is None:
+        args.seconds = 300.0 if args.mode == "stream" else 30.0
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -355,10 +440,9 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # Called directly (`python bench.py --gpus N`): become the launcher.  One rank per GPU under torch.distributed.run
         # on 127.0.0.1, same arguments; this process is replaced, the ranks' output (rank 0 prints the JSON line) is ours.
-        import socket
-        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # (--standalone: torch.distributed.run picks the rendezvous port itself - no bind / close / reuse race with another launch)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
         sys.stdout.flush(); sys.stderr.flush()
         os.execv(sys.executable, cmd)
     if world != args.gpus:
@@ -405,12 +489,12 @@ def main():
     model = v.Model(mdir, device=local_rank, weights=args.weights, **win)
     load_s = time.time() - t0
     dims = model.dims            # geometry as read from the checkpoint by vox_load
-    audio, golden, audio_desc = headline_audio(args.seconds)
+    audio, golden, golden_name, audio_desc = headline_audio(args.seconds, args.mode)
     if args.preset != "full" or args.weights != "bf16" or mdir == real_model:
         golden = None
 
     if args.mode == "stream":
-        return stream_mode(args, model, audio, v)
+        return stream_mode(args, model, audio, v, dims, golden, golden_name, audio_desc, mdir)
 
     def one_pass():
         r = model.transcribe(audio)
@@ -435,7 +519,7 @@ def main():
     n_tok = steps_tokens / args.steps
     decode_tok_s = dec_steps / (dec_ms * 1e-3) if dec_ms > 0 else 0.0
 
-    parity = parity_block(r["tokens"], golden)
+    parity = parity_block(r["tokens"], golden, golden_name)
     roofline = roofline_block(v, model, dims, n_tok, args.weights, pmc=not args.no_pmc and args.preset == "full")
     mask, path_names = model.active_paths()
     out = {
@@ -443,7 +527,9 @@ def main():
                   "real-time-factor + decode tokens/sec, Voxtral-4B fp8 decode weights, 30s audio",
         "value": round(rtf, 5), "unit": "wall s / audio s (RTF)", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 weights, f32 activations/accumulate (fp32 FMA GEMV, f32 MFMA GEMM)",
+        "dtype": ("bf16 weights, f32 activations/accumulate (fp32 FMA GEMV, f32 MFMA GEMM)" if args.weights == "bf16" else
+                  "fp8 (e4m3, one f32 scale per output row) decoder weights in the decode GEMVs and the LM head, f32 activations/accumulate; "
+                  "encoder and prefill on the bf16 weights"),
         "data": "real" if mdir == real_model else "synthetic",
         "data_note": ("weights: real checkpoint " + real_model if mdir == real_model else
                       "weights: seeded synthetic checkpoint of the exact architecture (no real weights offline)") + "; audio: " + audio_desc,

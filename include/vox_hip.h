@@ -219,6 +219,11 @@ int vox_hip_causal_attention(vox_hip_engine_t *e, float *out, const float *q, co
  * decoder weights `iters` times; returns average seconds per pass measured with HIP
  * events on the engine stream (used by bench.py's roofline leg). */
 double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int kv_len);
+/* The same for the encoder stack on an n_rows-row chunk (vox_encoder_forward_incremental, voxtral_encoder.c:452-636) that
+ * follows ctx_rows already-encoded positions (the K/V window is full from 750 on): HIP events on the engine stream around
+ * `iters` passes of all layers on resident weights; seconds per pass.  Resets the encoder stream state (call it between
+ * streams only).  bench.py's roofline leg of the streaming configuration. */
+double vox_hip_time_encoder_rows(vox_hip_engine_t *e, int n_rows, int ctx_rows, int iters);
 
 /* Per-kernel breakdown of one decode step: avg_us[9] / launches[9] indexed by
  * {0 step_begin, 1 qkv gemv, 2 attention, 3 split-K combine, 4 wo gemv, 5 swiglu gemv,

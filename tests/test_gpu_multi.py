@@ -91,10 +91,10 @@ def test_in_library_multi_device_encoder_matches_single_gpu(preset, seconds, dev
     assert np.array_equal(got2, want2) and np.array_equal(want2, want)
 
 
-def _bench_json(cmd, env, timeout=1500):
+def _bench_json(cmd, env, timeout=1500, want_rc=0):
     import json
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert (r.returncode == 0) == (want_rc == 0), (r.returncode, r.stderr[-3000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     return json.loads(line)
 
@@ -134,13 +134,14 @@ def test_bench_self_launches_two_ranks_and_matches_the_reference_golden():
     assert out["replica"]["value"] > 0 and out["value"] > 0
 
 
-def test_bench_falls_back_to_the_replica_line_when_the_sharded_pass_fails():
+def test_bench_reports_no_value_when_the_sharded_pass_fails():
     """The RCCL point-to-point path cannot run with more than one rank before the first multi-GPU node does: if it raises (or
-    hangs past its time limit) the job must still end with ONE honest JSON line - the replica figure, and what happened."""
+    hangs past its time limit) the job ends with ONE honest JSON line - value null, the reason, the replica figure only
+    under `replica` - and a non-zero exit code: a broken multi-GPU path must not look like a green run."""
     env = dict(os.environ, VOX_FORCE_DIST="1", VOX_DIST_INJECT_FAIL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--preset", "small", "--seconds", "12"]
-    out = _bench_json(cmd, env)
+    out = _bench_json(cmd, env, want_rc=4)
     assert out["sharded_pass"]["completed"] is False and "injected" in out["sharded_pass"]["reason"]
-    assert out["value"] == out["replica"]["value"] > 0 and out["config"]["parallelism"] == "1 replicas"
+    assert out["value"] is None and out["replica"]["value"] > 0 and "failed" in out["config"]["parallelism"]

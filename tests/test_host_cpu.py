@@ -165,22 +165,28 @@ def test_bench_picks_the_golden_that_belongs_to_the_audio_length():
     import sys
     sys.path.insert(0, ROOT)
     bench = importlib.import_module("bench")
-    a30, g30, _ = bench.headline_audio(30.0)
-    assert g30 is not None and len(a30) == 480000 and len(g30["tokens"]) == 386
-    par = bench.parity_block(g30["tokens"], g30)
+    a30, g30, n30, _ = bench.headline_audio(30.0)
+    assert g30 is not None and len(a30) == 480000 and len(g30["tokens"]) == 386 and n30 == "stream_full_batch.npz"
+    par = bench.parity_block(g30["tokens"], g30, n30)
     assert par["checked"] and par["mismatches"] == 0 and "stream_full_batch.npz" in par["golden"]
     bad = np.array(g30["tokens"]).copy(); bad[100] += 1
-    par = bench.parity_block(bad, g30)
+    par = bench.parity_block(bad, g30, n30)
     assert par["mismatches"] == 1 and par["first_mismatch"] == 100
-    a300, g300, desc = bench.headline_audio(300.0)
+    a300, g300, n300, desc = bench.headline_audio(300.0)
     assert len(a300) == 300 * 16000 and np.array_equal(a300[:480000], a30) and np.array_equal(a300[480000:960000], a30)
     if os.path.exists(os.path.join(ROOT, "tests", "golden", "stream_full_batch300.npz")):
         assert g300 is not None and len(g300["tokens"]) == 3761 and "batch300" in desc
-        assert "stream_full_batch300.npz" in bench.parity_block(g300["tokens"], g300)["golden"]
+        assert "stream_full_batch300.npz" in bench.parity_block(g300["tokens"], g300, n300)["golden"]
     if os.path.exists(os.path.join(ROOT, "tests", "golden", "stream_full_batch600.npz")):
-        a600, g600, desc = bench.headline_audio(600.0)
+        a600, g600, n600, desc = bench.headline_audio(600.0)
         assert len(a600) == 600 * 16000 and g600 is not None and len(g600["tokens"]) == 7511 and "batch600" in desc
-        assert "stream_full_batch600.npz" in bench.parity_block(g600["tokens"], g600)["golden"]
-    a45, g45, _ = bench.headline_audio(45.0)
-    assert g45 is None and len(a45) == 45 * 16000
-    assert bench.parity_block([1, 2, 3], None) == {"checked": False, "reason": "no golden for this length / preset"}
+        assert "stream_full_batch600.npz" in bench.parity_block(g600["tokens"], g600, n600)["golden"]
+    a45, g45, n45, _ = bench.headline_audio(45.0)
+    assert g45 is None and n45 is None and len(a45) == 45 * 16000
+    assert bench.parity_block([1, 2, 3], None)["checked"] is False
+    # BASELINE config 3's feed pattern has its own goldens: the reference's run of the SAME 0.5 s feeds in continuous mode
+    a176, g176, n176, _ = bench.headline_audio(176.0, "stream")
+    assert len(a176) == 176 * 16000 and n176 == "stream_full_continuous.npz" and len(g176["tokens"]) == 2204
+    a20, g20, n20, _ = bench.headline_audio(20.0, "stream")
+    assert len(a20) == 320000 and n20 == "stream_full_stream.npz" and len(g20["tokens"]) == 261
+    assert bench.headline_audio(30.0, "stream")[1] is None          # a one-feed golden is never used for a streamed run

@@ -80,6 +80,10 @@ LONG_CASES = [
     # the 300 s batch line of bench.py (the 30 s clip tiled, ONE feed: a 16 946-position encoder chunk, 3761 decoder steps, KV to 3799)
     ("full_batch300", "full", 30.0, 0, None, None, False, None, "benchmark/night1968/45s_right_through_the_billboard.wav",
      dict(tile_to=300 * 16000, max_logit_rows=3800, stride=256)),
+    # BASELINE config 3 itself: 300 s in 0.5 s feeds, -I 0.5, continuous mode (the full stream reset at ~160 s included); the golden of
+    # `bench.py --mode stream` (3754 decoder steps; ~50 min of reference CPU time on 8 cores)
+    ("full_stream300", "full", 30.0, 0, 8000, 0.5, True, None, "benchmark/night1968/45s_right_through_the_billboard.wav",
+     dict(tile_to=300 * 16000, max_logit_rows=3900, stride=256)),
     # BASELINE config 4's audio length on one GPU: 600 s, one feed (30 196 encoder positions, 7511 decoder steps, KV to 7549)
     ("full_batch600", "full", 30.0, 0, None, None, False, None, "benchmark/night1968/45s_right_through_the_billboard.wav",
      dict(tile_to=600 * 16000, max_logit_rows=7600, stride=512)),

@@ -47,6 +47,38 @@ constexpr int DF_WO_ROWS = DF_D / DF_BPG;     // 96 rows of Wo per workgroup
 
 typedef unsigned long long u64;
 
+// ---------------------------------------------------------------------------------------------------------
+// L2 prefetch across a kernel boundary (round 4).  From ~11 us on k_dec_attn_fused keeps the memory system idle: the projection
+// weights and the Wo rows have landed and what remains is a chain of L2 round trips (partials -> sweep -> Wo product), then the
+// kernel boundary and the next launch's ramp: ~6 us per layer in which no weight byte moves (profiles/r03_fuse_timeline_kv232.txt).
+// The next launch (k_gemv_w13x) is HBM bound from its first microsecond.  Workgroup b of every 256-block launch of the step runs on
+// the same XCD (observed: XCC_ID = (b + 6) % 8 for all three launches, tools/fuse_timeline.py), so this kernel can pull the first
+// 1 KiB pieces of the rows k_gemv_w13x's block b will ask for into THAT XCD's L2: LDS-DMA into a scratch slot (no registers, the
+// data is discarded), default cache policy.  Unit u of target block bt: matrix m = (u % 72) / 36 (w1, w3), row 36 bt + u % 36,
+// piece u / 72 - i.e. piece 0 of all 72 rows first, in the order k_gemv_w13x issues them.  The units of the 32 target blocks of
+// an XCD class (blockIdx % 8) are dealt round-robin over that class's prefetching waves, so that every target block is covered
+// to the same depth whoever does the work: the attention members (done once their partial is out; they take `member_units` of the
+// class's 32 * units) and the others (either right behind their Wo rows, when = 1, or after the partial sweep, when = 2).
+// Nothing depends on it: wrong placement or an evicted line only costs the gain.
+// ---------------------------------------------------------------------------------------------------------
+struct DfPrefetch {
+    const unsigned char *w;    // w1 rows, then w3 rows (row r of w3 = row rows_m + r)
+    int row_bytes;             // 6144 (bf16) / 3072 (fp8)
+    int rows_m;                // 9216
+    int units;                 // 1 KiB units per target block (0 = off)
+    int member_units;          // of the 32 * units of an XCD class, how many the attention members fetch
+    int when;                  // non-members: 1 = behind their Wo rows, 2 = after the partial sweep
+};
+__device__ __forceinline__ void df_prefetch_units(const DfPrefetch &pf, int cls, int v0, int v1, int slot, int nslots, int lane, unsigned lds_dst) {
+    for (int v = v0 + slot; v < v1; v += nslots) {
+        const int bt = 8 * (v & 31) + cls, u = v >> 5;
+        const int piece = u / 72, r72 = u - 72 * piece;
+        const int m = r72 >= 36 ? 1 : 0, r = r72 - 36 * m;
+        const unsigned char *src = pf.w + ((size_t)m * pf.rows_m + 36 * bt + r) * (size_t)pf.row_bytes + piece * 1024 + lane * 16;
+        glds16(src, lds_dst);
+    }
+}
+
 struct DecFuseArgs {
     const uint16_t *wqkv;      // [6144][3072] bf16: q rows, then k rows, then v rows
     const uint16_t *wo;        // [3072][4096] bf16
@@ -72,6 +104,9 @@ struct DecFuseArgs {
     int merge_three_trips;           // A/B switch: long-context merge with the (max, sum) and the value fetches one after the other
     int attn_gqa;                    // round 3: K / V tiles read from LDS once for the 4 heads of a group (0 = once per head, A/B)
     unsigned long long *tl;          // optional (tuning): per-workgroup timeline, see tl_begin / tl_end
+    // Round 4: L2 prefetch of the NEXT launch's (k_gemv_w13x) first weight bytes in this kernel's tail, when the memory system is
+    // idle (DfPrefetch below).  pf.units = 0 switches it off.
+    DfPrefetch pf;
 };
 // stamps stay in registers until the end (no stores in the middle of the memory schedule)
 #define DF_MARK(k) do { if (a.trace || a.tl) df_stamp[k] = wall_clock64(); } while (0)
@@ -374,6 +409,14 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     if (!att_block) {
         DF_LATE_WO(0) DF_LATE_WO(4) DF_LATE_WO(8) DF_LATE_WO(12)
     }
+    // L2 prefetch for the next launch (see DfPrefetch): only in the short-context regime (members without Wo rows, one XCD per group)
+    const bool pf_on = a.pf.units > 0 && wo_light && !a.spread_groups;
+    const int pf_V = 32 * a.pf.units, pf_Vm = min(a.pf.member_units, pf_V);
+    const unsigned pf_lds = lds_addr(tiles) + 65536u + (unsigned)wave * 1024u;      // beyond the Wo reduction scratch; the tiles are dead where this is used
+    if (pf_on && !att_block && a.pf.when == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        df_prefetch_units(a.pf, g, pf_Vm, pf_V, (j - ns) * DF_WAVES + wave, (DF_BPG - ns) * DF_WAVES, lane, pf_lds);
+    }
 
     float *qs = xs;                        // [512] the group's q
     float *kvn = xs + 512;                 // [256] this step's k | v of head g
@@ -535,6 +578,10 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
             df_store_granule(mine + ho * DF_HD + dd, epoch, o_acc);
             if (dd == 0) { df_store_granule(mine + 4 * DF_HD + 2 * ho, epoch, cr[4 + ho]); df_store_granule(mine + 4 * DF_HD + 2 * ho + 1, epoch, cr[8 + ho]); }
         }
+        if (pf_on && pf_Vm > 0) {      // a member is done: its share of the next launch's first bytes (every tile read is behind the barrier above)
+            __builtin_amdgcn_sched_barrier(0);
+            df_prefetch_units(a.pf, g, 0, pf_Vm, j * DF_WAVES + wave, ns * DF_WAVES, lane, pf_lds);
+        }
     }
 #undef DF_LATE_WO
 #undef DF_WO_PTR
@@ -643,6 +690,10 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the Wo slice has landed in its registers
     __syncthreads();
     DF_MARK(9);
+    if (pf_on && !att_block && a.pf.when == 2) {      // in flight under the Wo product; the wave ends when they have landed
+        df_prefetch_units(a.pf, g, pf_Vm, pf_V, (j - ns) * DF_WAVES + wave, (DF_BPG - ns) * DF_WAVES, lane, pf_lds);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     // ---- this wave's rows of  Wo[:, 512 g .. 512 g + 511] . att ------------------------------------------------------------------
     if (wo_n > 0) {
@@ -684,6 +735,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
             if (q == 0 && row < wo_n) a.wo_part[(size_t)g * DF_D + wo_row0 + row] = s;
         }
     }
+    if (pf_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the scratch slot is this workgroup's LDS: no DMA may outlive it
     DF_MARK(10);
     if (a.trace && tid == 0 && (blockIdx.x == 0 || blockIdx.x == DF_BLOCKS - 1)) {
 #pragma unroll
@@ -711,6 +763,9 @@ struct W13xArgs {
     float *h;                  // [9216]
     unsigned long long *trace; // optional (tuning): [2 blocks][16] stamps, written at +32
     unsigned long long *tl;    // optional (tuning): per-workgroup timeline
+    // Round 4 (A/B): a wave that is done EARLY (before pf_gate wall-clock ticks after its entry) pulls the first pf_units KiB of the
+    // row the same wave of the next launch's block (k_gemv_w2x: row 12 b + wave) will stream into this XCD's L2; late waves do not.
+    const unsigned char *pf_w; int pf_row_bytes, pf_units; unsigned pf_gate;
 };
 constexpr int W13X_THREADS = 768;
 constexpr int W13X_LDS_BYTES = (9 + 2 + 1) * DF_D * 4 + 256;
@@ -728,6 +783,7 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
     const unsigned wofs = (unsigned)wave * 1024u;        // 12 waves x 1 KiB = one 12 KB vector per DMA round
     unsigned long long df_stamp[6] = {0, 0, 0, 0, 0, 0};
     const unsigned long long tl0 = tl_begin(a.tl);
+    const unsigned long long pf_t0 = a.pf_units > 0 ? wall_clock64() : 0ull;
     DF_MARK(0);
 
     glds16(a.x + tid * 4, lds_addr(stage) + wofs);
@@ -825,6 +881,13 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
             a.h[pair0 + r] = silu(g) * u;                                               // voxtral_decoder.c:684-687
         }
     }
+    if (a.pf_units > 0) {
+        if ((unsigned)(wall_clock64() - pf_t0) < a.pf_gate) {
+            const unsigned char *src = a.pf_w + (size_t)(blockIdx.x * 12 + wave) * (size_t)a.pf_row_bytes + lane * 16;
+            for (int u = 0; u < a.pf_units; u++) glds16(src + u * 1024, lds_addr(stage) + wofs);      // the prologue vectors are dead
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     DF_MARK(4);
     if (a.trace && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 255)) {
 #pragma unroll
@@ -847,9 +910,12 @@ struct W2xArgs {
     const float *h;            // [9216]
     float *x;                  // [3072] residual stream, updated in place (every row is read and written by its one wave)
     unsigned long long *tl;    // optional (tuning): per-workgroup timeline
+    // Round 4 (A/B): early waves 0..7 pull the first pf_units KiB of the three projection rows wave w of the NEXT layer's
+    // k_dec_attn_fused block b will stream (same row formula, group = b % 8) into this XCD's L2.
+    const unsigned char *pf_w; int pf_units; unsigned pf_gate;
 };
 constexpr int W2X_THREADS = 768, W2X_K = 9216;
-constexpr int W2X_LDS_BYTES = W2X_K * 4 + 64;
+constexpr int W2X_LDS_BYTES = W2X_K * 4 + 64 + 12 * 1024;     // h, pad, one 1 KiB prefetch scratch slot per wave
 
 template <bool W8>
 __global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
@@ -859,6 +925,7 @@ __global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned wofs = (unsigned)wave * 1024u;
     const unsigned long long tl0 = tl_begin(a.tl);
+    const unsigned long long pf_t0 = a.pf_units > 0 ? wall_clock64() : 0ull;
     const int row = blockIdx.x * 12 + wave;
     const float resid = a.x[row];
 #pragma unroll
@@ -900,6 +967,21 @@ __global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
     acc = wave_sum(acc);
     if constexpr (W8) acc *= a.s2[row];
     if (lane == 0) a.x[row] = resid + acc;
+    if (a.pf_units > 0) {
+        if (wave < DF_WAVES && (unsigned)(wall_clock64() - pf_t0) < a.pf_gate) {
+            const int g = blockIdx.x % DF_GROUPS, j = blockIdx.x / DF_GROUPS;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int lr = 3 * wave + i;
+                const int prow = lr < 16 ? DF_NQ * g + 16 * j + lr
+                               : lr < 20 ? DF_DQ + DF_HD * g + 4 * j + (lr - 16)
+                                         : DF_DQ + DF_DKV + DF_HD * g + 4 * j + (lr - 20);
+                const unsigned char *src = a.pf_w + (size_t)prow * (DF_D * 2) + lane * 16;
+                for (int u = 0; u < a.pf_units; u++) glds16(src + u * 1024, lds_addr(smem + W2X_K + 16) + wofs);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     tl_end(a.tl, tl0);
 }
 }  // namespace vox

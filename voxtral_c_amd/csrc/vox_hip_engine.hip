@@ -269,6 +269,10 @@ struct vox_hip_engine {
     // debug taps of the decoder's residual stream (vox_hip_debug_tap_config): at the decode steps whose KV position is listed,
     // x at the start of every layer, x after every attention block and x after the last layer are copied to d_taps in stream order
     std::vector<int> tap_pos; float *d_taps = nullptr;
+    // Round 4: L2 prefetch of the next launch's first weight bytes (vox_decfuse.h, DfPrefetch).  VOX_HIP_PF="units,member_units,when",
+    // VOX_HIP_PF13="units,gate_ticks", VOX_HIP_PF2="units,gate_ticks" override the defaults (A/B).
+    int pf_units = 0, pf_member_units = 0, pf_when = 2;
+    int pf13_units = 0, pf2_units = 0; unsigned pf13_gate = 0, pf2_gate = 0;
 };
 
 // Every host-side wait on the engine stream goes through here and is counted (vox_hip_host_syncs): the multi-GPU
@@ -634,6 +638,9 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
             e->use_fused = ok; e->fused_ok = ok;
             if (ok && getenv("VOX_HIP_FUSE_TRACE") && hipMalloc((void **)&e->d_fuse_trace, 64 * 8) == hipSuccess)
                 hipMemset(e->d_fuse_trace, 0, 64 * 8);
+            if (const char *pf = getenv("VOX_HIP_PF")) sscanf(pf, "%d,%d,%d", &e->pf_units, &e->pf_member_units, &e->pf_when);
+            if (const char *pf = getenv("VOX_HIP_PF13")) sscanf(pf, "%d,%u", &e->pf13_units, &e->pf13_gate);
+            if (const char *pf = getenv("VOX_HIP_PF2")) sscanf(pf, "%d,%u", &e->pf2_units, &e->pf2_gate);
             if (ok && getenv("VOX_HIP_FUSE_TL") && hipMalloc((void **)&e->d_fuse_tl, 3 * 1024 * TL_STRIDE * 8) == hipSuccess)
                 hipMemset(e->d_fuse_tl, 0, 3 * 1024 * TL_STRIDE * 8);
         }
@@ -1816,6 +1823,11 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.merge_three_trips = merge3 || f_split > 64;
                 static const int attn_old = getenv("VOX_HIP_FUSE_ATTN_PER_HEAD") ? 1 : 0;
                 a.attn_gqa = !attn_old;
+                if (e->pf_units > 0) {        // the next launch's (k_gemv_w13x) first bytes, see DfPrefetch
+                    a.pf.w = e->use_fp8 ? reinterpret_cast<const unsigned char *>(L.w138) : reinterpret_cast<const unsigned char *>(L.w13);
+                    a.pf.row_bytes = e->use_fp8 ? DD : 2 * DD; a.pf.rows_m = DH;
+                    a.pf.units = std::min(e->pf_units, 72 * (e->use_fp8 ? 3 : 6)); a.pf.member_units = e->pf_member_units; a.pf.when = e->pf_when;
+                }
                 const bool emb = (l == 0 && build_embed);
                 if (e->use_dpp) {
                     if (emb) hipLaunchKernelGGL((k_dec_attn_fused<true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
@@ -1834,6 +1846,10 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.eps = d.dec_eps; a.x_out = xalt; a.h = e->dh;
                 a.trace = (l == 13) ? e->d_fuse_trace : nullptr;
                 a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + TL_STRIDE * 1024 : nullptr;
+                if (e->pf13_units > 0) {
+                    a.pf_w = e->use_fp8 ? reinterpret_cast<const unsigned char *>(L.w28) : reinterpret_cast<const unsigned char *>(L.w2);
+                    a.pf_row_bytes = e->use_fp8 ? DH : 2 * DH; a.pf_units = std::min(e->pf13_units, e->use_fp8 ? 9 : 18); a.pf_gate = e->pf13_gate;
+                }
                 if (e->use_fp8) {
                     a.w1 = reinterpret_cast<const uint16_t *>(L.w138); a.w3 = reinterpret_cast<const uint16_t *>(L.w138 + (size_t)DH * DD);
                     a.s1 = L.s13; a.s3 = L.s13 + DH;
@@ -1855,6 +1871,9 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                     W2xArgs a{};
                     a.w2 = L.w2; a.h = e->dh; a.x = xalt;                            // x' += h . W2^T, in place (one wave per row)
                     a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + 2 * TL_STRIDE * 1024 : nullptr;
+                    if (e->pf2_units > 0 && l + 1 < d.dec_layers) {
+                        a.pf_w = reinterpret_cast<const unsigned char *>(e->dec[l + 1].wqkv); a.pf_units = std::min(e->pf2_units, 6); a.pf_gate = e->pf2_gate;
+                    }
                     if (e->use_fp8) {
                         a.w2 = reinterpret_cast<const uint16_t *>(L.w28); a.s2 = L.s2;
                         hipLaunchKernelGGL(k_gemv_w2x<true>, dim3(256), dim3(W2X_THREADS), W2X_LDS_BYTES, s, a);
@@ -2365,6 +2384,33 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
         }
         if (f) fclose(f);
     }
+    return (double)ms * 1e-3 / iters;
+}
+
+// Encoder stack on an n-row chunk behind ctx_rows positions, timed with HIP events (see vox_hip.h).  The K/V rings are zeroed
+// first (attention over zero keys: finite values, the same memory traffic), x is a zero chunk (finite through every norm:
+// RMSNorm of 0 is 0 * rsqrt(eps)); only the time matters here, the parity tests check the values.
+extern "C" double vox_hip_time_encoder_rows(vox_hip_engine_t *e, int n_rows, int ctx_rows, int iters) {
+    if (!e || n_rows <= 0 || iters <= 0 || ctx_rows < 0) return -1.0;
+    if (hipSetDevice(e->device) != hipSuccess) return -1.0;
+    vox_hip_reset_encoder(e);
+    const int ED = e->d.enc_dim;
+    if (ensure(e, e->stmp_in, (size_t)n_rows * ED * 4) || ensure(e, e->stmp_out, (size_t)n_rows * ED * 4)) return -1.0;
+    for (auto &L : e->enc) {
+        hipMemsetAsync(L.kring, 0, (size_t)e->enc_ring_cap * e->enc_qd * 4, e->stream);
+        hipMemsetAsync(L.vring, 0, (size_t)e->enc_ring_cap * e->enc_qd * 4, e->stream);
+    }
+    float ms = 0.f;
+    for (int it = -2; it < iters; it++) {
+        if (it == 0) hipEventRecord(e->ev0, e->stream);
+        hipMemsetAsync(e->stmp_in.p, 0, (size_t)n_rows * ED * 4, e->stream);
+        e->enc_pos = ctx_rows;
+        if (encoder_rows_dev(e, (float *)e->stmp_in.p, n_rows, (float *)e->stmp_out.p)) { vox_hip_reset_encoder(e); return -1.0; }
+    }
+    hipEventRecord(e->ev1, e->stream);
+    esync(e);
+    hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    vox_hip_reset_encoder(e);
     return (double)ms * 1e-3 / iters;
 }
 

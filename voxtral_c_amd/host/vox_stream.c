@@ -247,7 +247,13 @@ static void run_encoder(vox_stream_t *s) {
     const int new_tokens = vox_hip_stream_encode(s->eng, new_mel_left, &conv_rows, &residual);
     s->mel_cursor = total_mel;
     s->stem_started = 1;
-    if (new_tokens < 0) { fprintf(stderr, "vox_stream: encoder failed: %s\n", vox_hip_last_error()); return; }
+    if (new_tokens < 0) {
+        /* the device mel queue was the only copy of these frames and the encoder state is undefined now: the stream is dead
+         * (feed / flush / finish return -1 from here on, the reference's error convention, voxtral.c:1237) */
+        fprintf(stderr, "vox_stream: encoder failed: %s\n", vox_hip_last_error());
+        s->failed = 1;
+        return;
+    }
     if (conv_rows <= 0) return;
     vox_enc_mirror_chunk(s->ctx, conv_rows);
     s->total_adapter += new_tokens;
@@ -276,7 +282,7 @@ static void run_decoder(vox_stream_t *s) {
         ctx->kv_cache_len = 0; ctx->kv_pos_offset = 0;
         int tok = vox_hip_decoder_prefill_stream(s->eng, s->adapter_base, prompt_len, TOK_BOS, TOK_STREAMING_PAD,
                                                  want_logits(s) ? s->logits : NULL);
-        if (tok < 0) { fprintf(stderr, "vox_stream: prefill failed: %s\n", vox_hip_last_error()); return; }
+        if (tok < 0) { fprintf(stderr, "vox_stream: prefill failed: %s\n", vox_hip_last_error()); s->failed = 1; return; }
         vox_kv_mirror_prefill(ctx, prompt_len - 1);
         vox_kv_mirror_step(ctx);
         const tok_class_t cls = account_token(s, &tok);
@@ -305,11 +311,15 @@ static void run_decoder(vox_stream_t *s) {
                 free(s->tok_scratch);
                 s->tok_scratch = (int *)malloc((size_t)batch * sizeof(int));
                 s->tok_scratch_cap = s->tok_scratch ? batch : 0;
-                if (!s->tok_scratch) return;
+                if (!s->tok_scratch) { s->failed = 1; return; }
             }
             const int got = vox_hip_decoder_run(s->eng, s->gen_pos, batch, s->prev_token, TOK_EOS, s->tok_scratch,
                                                 want_logits(s) ? s->logits : NULL);
-            if (got <= 0) { fprintf(stderr, "vox_stream: decode failed: %s\n", vox_hip_last_error()); break; }
+            if (got <= 0) {          /* the KV ring and the position counters no longer describe the same sequence */
+                fprintf(stderr, "vox_stream: decode failed: %s\n", vox_hip_last_error());
+                s->failed = 1;
+                return;
+            }
             (void)V;
             for (int i = 0; i < got; i++) {
                 int tok = s->tok_scratch[i];
@@ -410,7 +420,7 @@ int vox_stream_feed(vox_stream_t *s, const float *samples, int n_samples) {
     run_encoder(s);
     if (s->failed) return -1;
     run_decoder(s);
-    return 0;
+    return s->failed ? -1 : 0;
 }
 
 /* right padding: align to a token, then (delay+1) + 10 tokens of silence (voxtral.c:1593-1606) */
@@ -452,7 +462,7 @@ int vox_stream_finish(vox_stream_t *s) {
     run_encoder(s);
     if (s->failed) return -1;
     run_decoder(s);
-    return 0;
+    return s->failed ? -1 : 0;
 }
 
 int vox_stream_get(vox_stream_t *s, const char **out, int max) {
@@ -578,10 +588,15 @@ char *vox_transcribe_audio(vox_ctx_t *ctx, const float *samples, int n_samples) 
     if (!s) return NULL;
     sbuf_t b;
     if (sb_init(&b)) { vox_stream_free(s); return NULL; }
-    vox_stream_feed(s, samples, n_samples);
-    vox_stream_finish(s);
+    const int rc_feed = vox_stream_feed(s, samples, n_samples);
+    const int rc_fin = vox_stream_finish(s);
     sb_drain(&b, s);
     vox_stream_free(s);
+    if (n_samples > 0 && (rc_feed != 0 || rc_fin != 0)) {      /* a device failure: no partial transcript passed off as a whole one */
+        fprintf(stderr, "vox_transcribe: the stream failed on the device\n");
+        free(b.p);
+        return NULL;
+    }
     return sb_finish(&b);
 }
 

@@ -471,13 +471,15 @@ def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
     v.hip.vox_hip_stream_handle.argtypes = [C.c_void_p]
     comm = TorchComm(device=f"cuda:{dev}", engine_stream=v.hip.vox_hip_stream_handle(model.engine))
     session = DistributedSession(model, comm)
-    audio, golden, audio_desc = headline_audio(args.seconds)
-    if args.preset != "full":
-        golden = None
-    # VOX_DIST_MODE=single: one clip of N x seconds, decoder on rank 0 only (BASELINE config 4)
+    audio, golden, golden_name, audio_desc = headline_audio(args.seconds)
+    # VOX_DIST_MODE=single: one clip of N x seconds, decoder on rank 0 only (BASELINE config 4).  With a golden for that length
+    # (8 x 75 s = the 600 s fixture stream_full_batch600.npz) rank 0's ids are checked against the reference's run.
     single = os.environ.get("VOX_DIST_MODE") == "single"
+    golden_all = golden_all_name = None
     if single:
-        audio_all, _, _ = headline_audio(args.seconds * world)
+        audio_all, golden_all, golden_all_name, audio_desc = headline_audio(args.seconds * world)
+    if args.preset != "full":
+        golden = golden_all = None
     dev_t = comm.device if comm.on_gpu else "cpu"
 
     def allmax(x):
@@ -508,7 +510,7 @@ def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
     rep = None
     if not single:
         rwall, rres, rt = timed(lambda: model.transcribe(audio))
-        rpar = parity_block(rres["tokens"], golden)
+        rpar = parity_block(rres["tokens"], golden, golden_name)
         rep = {"value": round(rwall / args.steps / (args.seconds * world), 5), "ms_per_step": round(rwall * 1e3 / args.steps, 2),
                # (vox_stream_init resets the engine's phase timers: these are the LAST pass's)
                "decode_tok_s": round(allsum(rt["decode_steps"]) / (allmax(rt["decode_ms"]) * 1e-3), 1) if rt["decode_ms"] > 0 else 0.0,
@@ -537,18 +539,22 @@ def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
     state = {"done": False}
 
     def fallback(reason):
+        # The sharded pass is what `value` means on this line.  If it raised or hung there is NO value: the line says so
+        # (value null, the reason, the replica figure only under `replica`) and every rank exits non-zero - a broken or
+        # deadlocked multi-GPU path must not look like a green run whose number means something else.
         if state["done"]:
             return
         state["done"] = True
-        if rank == 0 and rep is not None:
+        if rank == 0:
             out = base_line()
-            out.update({"value": rep["value"], "ms_per_step": rep["ms_per_step"], "decode_tok_s": rep["decode_tok_s"],
+            out.update({"value": None, "ms_per_step": None,
                         "sharded_pass": {"completed": False, "reason": reason},
-                        "config": {"workload": f"Voxtral-4B ({args.preset} synthetic checkpoint), {world} clips of {args.seconds:g} s, one per GPU, "
-                                               "every GPU transcribes its own clip (replicas; the sharded-encoder pass did not complete)",
-                                   "audio_seconds": audio_s, "parallelism": f"{world} replicas", "backend": backend}})
+                        "config": {"workload": f"Voxtral-4B ({args.preset} synthetic checkpoint), {world} clips of {args.seconds:g} s, one per GPU; "
+                                               "the sharded-encoder pass did not complete (see sharded_pass.reason); `replica` holds the "
+                                               "no-communication figure measured before it",
+                                   "audio_seconds": audio_s, "parallelism": f"cp{world} encoder (failed)", "backend": backend}})
             print(json.dumps(out), flush=True)
-        os._exit(0 if rep is not None else 3)
+        os._exit(4)
 
     timer = threading.Timer(limit_s, fallback, args=(f"no result after {limit_s:.0f} s (hang in the RCCL point-to-point path?)",))
     timer.daemon = True
@@ -562,7 +568,10 @@ def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
         phase["prefill"] = allmax(t["prefill_ms"] / max(args.steps, 1))
         phase["decode"] = allmax(t["decode_ms"] / max(args.steps, 1))
         dec_steps, dec_ms = allsum(t["decode_steps"]), allmax(t["decode_ms"])
-        par = parity_block(toks, golden) if (toks is not None and not single) else {"checked": False, "reason": "no golden for this length / preset"}
+        if single:      # only rank 0 decodes
+            par = parity_block(toks, golden_all, golden_all_name) if toks is not None else {"checked": False, "reason": "this rank does not decode"}
+        else:
+            par = parity_block(toks, golden, golden_name) if toks is not None else {"checked": False, "reason": "no tokens on this rank"}
         mism = allsum(par.get("mismatches", 0) if par.get("checked") else 0)
         checked = allsum(1 if par.get("checked") else 0)
         wf_syncs = allmax(session.eng.wavefront_syncs)

@@ -246,6 +246,10 @@ int vox_hip_time_decoder_step_without(vox_hip_engine_t *e, int iters, int kv_len
  * vox_hip_weight_format: 0 = bf16, 1 = fp8 decode weights. */
 int vox_hip_quantize_decoder_fp8(vox_hip_engine_t *e);
 int vox_hip_weight_format(vox_hip_engine_t *e);
+/* Agreement study hook (tools/fp8_agreement.py): the decode step streams bf16 copies of the decoder matrices (lm_head != 0:
+ * and of the LM head) holding dequant(quant_e4m3(w)) with one power-of-two scale per `block` weights of a row (0 = per row) -
+ * bit for bit what a block-scaled fp8 GEMV with such scales computes.  block < 0 = off.  4B geometry, bf16 mode only. */
+int vox_hip_simulate_block_fp8(vox_hip_engine_t *e, int block, int lm_head);
 
 /* Which kernel families are live (bit set = the production variant).  The start-up self-tests compare
  * each MFMA / DPP kernel with a plain HIP cross-check; a mismatch makes vox_hip_engine_create (and so

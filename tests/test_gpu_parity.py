@@ -629,6 +629,34 @@ def test_fused_decode_step_matches_the_launch_per_gemv_chain(vox):
     assert same == n, (same, n)
 
 
+def test_fp8_fused_decode_step_matches_the_fp8_chain(vox):
+    """Round 4: in fp8 mode k_dec_attn_fused<W8> streams the row-scaled e4m3 copies of wq;wk;wv and wo (two Wo rows per load,
+    16 weights per lane) - the same bytes the launch-per-GEMV chain reads in fp8 mode (VOX_HIP_NO_FUSED=1).  70 s of audio:
+    the first ~470 steps run with attention members that carry no Wo rows (<= 8 key slices), the rest with every member
+    streaming 12 Wo rows under its first K/V tile.  The chain's ids are teacher-forced so that every step sees the same inputs;
+    logits must agree up to summation order, argmax may differ at numerical near-ties only."""
+    audio = synth_speech(70.0, 321)
+    os.environ["VOX_HIP_NO_FUSED"] = "1"
+    try:
+        with vox.Model(model_dir("full"), weights="fp8") as m2:
+            assert "dec_fused" not in m2.active_paths()[1]
+            c = m2.transcribe(audio, record_logits=900)
+    finally:
+        del os.environ["VOX_HIP_NO_FUSED"]
+    with vox.Model(model_dir("full"), weights="fp8") as m:
+        assert "dec_fused" in m.active_paths()[1]
+        a = m.transcribe(audio, record_logits=900, force_tokens=c["tokens"])
+        assert "dec_fused" in m.active_paths()[1], "a hand-off timed out: the engine fell back to the chain"
+    n = len(c["tokens"])
+    assert n > 800 and len(a["tokens"]) == n
+    k = min(len(a["logits"]), len(c["logits"]))
+    err = float(np.abs(np.asarray(a["logits"])[:k] - np.asarray(c["logits"])[:k]).max())
+    diff = int((np.asarray(a["tokens"]) != np.asarray(c["tokens"])).sum())
+    diag("fp8_fused_vs_fp8_chain", steps=n, logit_rows=k, max_logit_diff=err, differing_argmax=diff)
+    assert err < 5e-4, err
+    assert diff <= 2, (diff, n)
+
+
 def test_fused_decode_step_matches_the_chain_at_long_context(vox):
     """The same comparison where the fused kernel works differently: 200 s of audio = 2500 decoder steps, KV to ~2540 -
     every member of a KV-head group runs attention (up to 32 key slices, two K/V tiles each beyond 2048 keys), Wo rows ride under

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 asks that fp8 tokens "match bf16 greedy".  This tool measures, on the headline clip and checkpoint, how far
+each quantisation variant is from that: free-running first divergence and teacher-forced agreement (the bf16 ids forced, so every
+step sees the same inputs) against the bf16 run, next to the margin-conditioned figure of tests/test_gpu_parity.py.
+Variants: the shipped fp8 mode (one f32 scale per output row, real e4m3 streaming kernels), the same with the LM head kept on
+the bf16 embedding (VOX_HIP_FP8_LMHEAD_BF16), and block-scaled variants simulated exactly on the bf16 kernels with power-of-two
+scales (vox_hip_simulate_block_fp8: per row, per 128, per 32 weights; LM head quantised or not).
+usage: fp8_agreement.py out.json"""
+import ctypes as C, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import voxtral_c_amd as v
+from conftest import model_dir
+
+g = np.load(os.path.join(ROOT, "tests", "golden", "stream_full_batch.npz"), allow_pickle=True)
+audio = g["audio_i16"].astype(np.float32) / 32768.0
+d = model_dir("full")
+v.hip.vox_hip_simulate_block_fp8.argtypes = [C.c_void_p, C.c_int, C.c_int]
+
+with v.Model(d) as m:
+    ref = m.transcribe(audio, record_logits=512)
+    ta, la = np.asarray(ref["tokens"]), np.asarray(ref["logits"])
+    assert np.array_equal(ta, g["tokens"]), "the bf16 run must be the reference's golden run"
+    srt = np.sort(la, axis=1); margin = srt[:, -1] - srt[:, -2]
+
+    def score(run_free, run_forced, ms):
+        tf, tb, lb = np.asarray(run_free["tokens"]), np.asarray(run_forced["tokens"]), np.asarray(run_forced["logits"])
+        n = min(len(ta), len(tb), len(la), len(lb))
+        agree = ta[:n] == tb[:n]
+        rms = np.sqrt(((la[:n] - lb[:n]) ** 2).mean(axis=1))
+        safe3 = margin[:n] > 3 * rms
+        nf = min(len(tf), len(ta))
+        first = next((i for i in range(nf) if tf[i] != ta[i]), nf)
+        return dict(steps=int(n), tokens_match_bf16_greedy=bool(first == len(ta) and len(tf) == len(ta)),
+                    free_run_first_divergence=int(first), free_run_agreement=float((tf[:nf] == ta[:nf]).mean()),
+                    teacher_forced_agreement=float(agree.mean()), median_rms_logit_err=float(np.median(rms)),
+                    steps_with_margin_3rms=int(safe3.sum()), disagreements_at_margin_3rms=int((~agree & safe3).sum()),
+                    ms_per_token=None if ms is None else round(ms * 1e3, 4))
+
+    rows = {}
+    for name, block, lm in (("sim per-row pow2 scales, LM head fp8", 0, 1), ("sim per-row pow2 scales, LM head bf16", 0, 0),
+                            ("sim 128-block pow2 scales, LM head fp8", 128, 1), ("sim 128-block pow2 scales, LM head bf16", 128, 0),
+                            ("sim 32-block pow2 scales (MX granularity), LM head fp8", 32, 1), ("sim 32-block pow2 scales, LM head bf16", 32, 0)):
+        assert v.hip.vox_hip_simulate_block_fp8(m.engine, block, lm) == 0, name
+        rows[name] = score(m.transcribe(audio), m.transcribe(audio, record_logits=512, force_tokens=ta), None)
+        print(name, rows[name], flush=True)
+    v.hip.vox_hip_simulate_block_fp8(m.engine, -1, 0)
+    assert np.array_equal(np.asarray(m.transcribe(audio)["tokens"]), ta)
+
+for name, env in (("fp8 mode as shipped: e4m3 + f32 scale per row, all decode GEMVs + LM head", {}),
+                  ("fp8 mode, LM head on the bf16 embedding", {"VOX_HIP_FP8_LMHEAD_BF16": "1"}),
+                  ("fp8 mode, qkv / wo on the bf16 matrices (round 3)", {"VOX_HIP_FP8_ATTN_BF16": "1"})):
+    os.environ.update(env)
+    with v.Model(d, weights="fp8") as m8:
+        rows[name] = score(m8.transcribe(audio), m8.transcribe(audio, record_logits=512, force_tokens=ta), m8.time_decoder_step(50, 232))
+    for k in env: del os.environ[k]
+    print(name, rows[name], flush=True)
+
+out = {"clip": "tests/golden/stream_full_batch.npz (30 s night1968, 386 steps)", "min_bf16_top2_margin": float(margin.min()),
+       "bf16_margin_quantiles_1_10_50pct": [float(np.quantile(margin, q)) for q in (0.01, 0.1, 0.5)],
+       "criterion": "BASELINE config 5: tokens match bf16 greedy (free run identical); teacher-forced agreement = share of steps with the "
+                    "same argmax when every step sees the bf16 run's inputs",
+       "variants": rows}
+with open(sys.argv[1] if len(sys.argv) > 1 else "/dev/stdout", "w") as f:
+    json.dump(out, f, indent=1)

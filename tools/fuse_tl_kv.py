@@ -5,6 +5,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import voxtral_c_amd as v
 from conftest import model_dir
-with v.Model(model_dir("full")) as m:
+with v.Model(model_dir("full"), weights=os.environ.get("SWEEP_WEIGHTS", "bf16")) as m:
     s = m.time_decoder_step(20, int(sys.argv[1]))
     print("decoder step at kv %d: %.3f ms" % (int(sys.argv[1]), s * 1e3))

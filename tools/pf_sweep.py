@@ -29,7 +29,7 @@ for rep in range(reps):
     for name, env in variants:
         for k in touched: os.environ.pop(k, None)
         os.environ.update(env)
-        with v.Model(d) as m:
+        with v.Model(d, weights=os.environ.get('SWEEP_WEIGHTS', 'bf16')) as m:
             row = []
             for kv in kvs:
                 m.time_decoder_step(5, kv)

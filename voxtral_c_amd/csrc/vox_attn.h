@@ -627,7 +627,12 @@ __global__ __launch_bounds__(64 * NW) void k_attn_small(const AttnArgs a, int ke
 // 16 output values are requested before anything is computed on them; the arithmetic and its order are unchanged.
 template <int HD>
 __global__ __launch_bounds__(HD) void k_attn_combine(float *out, int ldo, const float *part_o,
-                                                     const float *part_ml, int n_heads, int nsplit) {
+                                                     const float *part_ml, int n_heads, int nsplit, int n_q = 1 << 30, const L2Pf pf = L2Pf{}) {
+    __shared__ __attribute__((aligned(16))) unsigned char pf_scratch[(HD / 64) * 1024];
+    if ((int)blockIdx.y >= n_q) {        // appended L2-prefetch workgroups (vox_common.h, L2Pf); gridDim.x is a multiple of 8 when they exist
+        l2pf_run(pf, ((int)blockIdx.y - n_q) * (int)gridDim.x + (int)blockIdx.x, (int)blockIdx.x, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_addr(pf_scratch) + (threadIdx.x >> 6) * 1024u)));
+        return;
+    }
     const int head = blockIdx.x, qi = blockIdx.y, d = threadIdx.x;
     const size_t base = ((size_t)qi * n_heads + head) * nsplit;
     float mm = -1e30f, ll = 0.f, ov = 0.f;

@@ -80,8 +80,9 @@ __device__ __forceinline__ void df_prefetch_units(const DfPrefetch &pf, int cls,
 }
 
 struct DecFuseArgs {
-    const uint16_t *wqkv;      // [6144][3072] bf16: q rows, then k rows, then v rows
-    const uint16_t *wo;        // [3072][4096] bf16
+    const uint16_t *wqkv;      // [6144][3072] bf16: q rows, then k rows, then v rows  (W8: fp8 e4m3 bytes, one f32 scale per row in sqkv)
+    const uint16_t *wo;        // [3072][4096] bf16                                     (W8: fp8 e4m3 bytes, one f32 scale per row in so)
+    const float *sqkv, *so;
     const float *x;            // [3072] residual stream (layers > 0)
     const float *norm_w;       // [3072] attention_norm
     float eps;
@@ -199,7 +200,9 @@ __device__ __forceinline__ void df_tile_dma(const DecFuseArgs &a, int g, int t0,
     for (int k = 0; k < 8; k++) df_tile_op(a, g, t0, last, kt_lds, vt_lds, wave, lane, k, true, slot0);
 }
 
-template <bool EMBED, bool USE_DPP>
+// W8 (round 4, BASELINE config 5): the projection and Wo matrices are the row-scaled fp8 copies (half the bytes: 9 instead of
+// 18 weight loads per lane, 8 instead of 16 Wo loads per wave - a Wo load then covers TWO rows, 32 lanes x 16 weights each).
+template <bool EMBED, bool USE_DPP, bool W8 = false>
 __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *xs = reinterpret_cast<float *>(smem_raw);                           // [3072] x, then [3072] norm weights (contiguous)
@@ -218,14 +221,18 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     DF_MARK(0);
 
     // ---- this workgroup's 24 weight rows: 16 of Wq, 4 of Wk, 4 of Wv; wave w streams rows 3w .. 3w+2 -------------
+    constexpr int NPW = W8 ? 3 : 6;               // 1 KiB pieces per projection row
+    constexpr int NWO = W8 ? 8 : 16;              // Wo loads per wave (16 rows)
     const unsigned char *rp[3];
+    int prow[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const int lr = 3 * wave + i;
         const int row = lr < 16 ? DF_NQ * g + 16 * j + lr
                       : lr < 20 ? DF_DQ + DF_HD * g + 4 * j + (lr - 16)
                                 : DF_DQ + DF_DKV + DF_HD * g + 4 * j + (lr - 20);
-        rp[i] = reinterpret_cast<const unsigned char *>(a.wqkv) + (size_t)row * (DF_D * 2) + lane * 16;
+        prow[i] = row;
+        rp[i] = reinterpret_cast<const unsigned char *>(a.wqkv) + (size_t)row * (W8 ? DF_D : DF_D * 2) + lane * 16;
     }
     // ---- this workgroup's key slice ---------------------------------------------------------------------------------
     const int ns = a.nsplit;
@@ -259,9 +266,9 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     // the ISA: v_mov of the last piece's registers in front of the wait; the sweep's temporaries on top of in-flight Wo rows).
     // What made asm necessary is gone: no LDS-DMA (asm, uncounted) is issued between the weight loads and their use any
     // more, so the compiler's in-order wait counts are exact here, and where asm DMAs are queued in front they only over-wait.
-    uint4 w[3][6];
+    uint4 w[3][NPW];
 #pragma unroll
-    for (int c = 0; c < 6; c++)
+    for (int c = 0; c < NPW; c++)
 #pragma unroll
         for (int i = 0; i < 3; i++) w[i][c] = ld_stream(reinterpret_cast<const uint4 *>(rp[i] + c * 1024));
     __builtin_amdgcn_sched_barrier(0);
@@ -275,7 +282,8 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     // carry none - they are the critical path, everybody waits for their partials - and the other 32 - ns members share the
     // group's 3072 rows (13 .. 16 per wave); beyond that every member takes 96 (12 per wave).  A wave always issues 16 loads
     // (rows past its share re-read its last one) so that the hand-counted waits below hold for every workgroup.
-    uint4 wv[16];        // compiler-visible non-temporal loads (see DF_LATE_WO)
+    uint4 wv[NWO];       // compiler-visible non-temporal loads (see DF_LATE_WO)
+    float wo_sc[W8 ? NWO : 1];      // W8: the dequantisation scale of the row a lane's half of load i belongs to, fetched with the rows
     const bool wo_light = ns <= 8;
     int wo_rpw = 12, wo_row0 = DF_WO_ROWS * j + 12 * wave;
     if (wo_light) {
@@ -285,8 +293,10 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     }
     const int wo_n = max(0, min(wo_rpw, DF_D - wo_row0));
     const int wo_rmax = wo_n > 0 ? wo_row0 + wo_n - 1 : DF_D - 1;
-    const unsigned char *wo_base = reinterpret_cast<const unsigned char *>(a.wo) + (size_t)(DF_NQ * g) * 2 + lane * 16;
-#define DF_WO_PTR(i) (wo_base + (size_t)min(wo_row0 + (i), wo_rmax) * (DF_DQ * 2))
+    // bf16: load i = row wo_row0 + i, 64 lanes x 8 weights; fp8: load i = rows wo_row0 + 2 i (lanes 0-31) and + 2 i + 1 (lanes 32-63), 16 weights per lane
+    const unsigned char *wo_base = reinterpret_cast<const unsigned char *>(a.wo) + (size_t)(DF_NQ * g) * (W8 ? 1 : 2) + (W8 ? (lane & 31) : lane) * 16;
+#define DF_WO_PTR(i) (wo_base + (size_t)min(wo_row0 + (W8 ? 2 * (i) + (lane >> 5) : (i)), wo_rmax) * (W8 ? DF_DQ : DF_DQ * 2))
+#define DF_WO_SCALE(i) a.so[min(wo_row0 + 2 * (i) + (lane >> 5), wo_rmax)]
     const int tile_last = att_block ? s_hi : 0;
     const int tile_slot0 = __builtin_amdgcn_readfirstlane(att_block ? s_lo % a.kv_cap : 0);
     DF_MARK(1);
@@ -308,10 +318,10 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
 #pragma unroll
         for (int k = 0; k < 8; k++) df_tile_op(a, g, s_lo, tile_last, lds_addr(tiles), lds_addr(tiles + DF_TILE_BYTES), wave, lane, k, att_block, tile_slot0);
 #pragma unroll
-        for (int i = 0; i < 16; i++) wv[i] = ld_stream(reinterpret_cast<const uint4 *>(DF_WO_PTR(i)));
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        for (int i = 0; i < NWO; i++) { wv[i] = ld_stream(reinterpret_cast<const uint4 *>(DF_WO_PTR(i))); if constexpr (W8) wo_sc[i] = DF_WO_SCALE(i); }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + (W8 ? 2 * NWO : NWO)) : "memory");
     } else {
-        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");          // only the 18 weight loads are younger than the activation DMAs
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NPW) : "memory");   // only the 18 (fp8: 9) weight loads are younger than the activation DMAs
     }
     __syncthreads();
     DF_MARK(2);
@@ -350,14 +360,24 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     // ---- dot products, piece by piece as the weights land ------------------------------------------------------------
     float acc[3] = {0.f, 0.f, 0.f};
 #define DF_PIECE(C)                                                                                      \
-    {                                                                                                    \
-        const float4 x0 = *reinterpret_cast<const float4 *>(xs + (C * 64 + lane) * 8);                   \
-        const float4 x1 = *reinterpret_cast<const float4 *>(xs + (C * 64 + lane) * 8 + 4);               \
-        _Pragma("unroll") for (int i = 0; i < 3; i++) acc[i] = dot8_bf16(w[i][C], x0, x1, acc[i]);       \
+    if constexpr ((C) < NPW) {                                                                           \
+        constexpr int CC = (C) < NPW ? (C) : 0;                                                          \
+        if constexpr (W8) {                                                                              \
+            const float *xp = xs + (CC * 64 + lane) * 16;                                                \
+            const float4 x0 = *reinterpret_cast<const float4 *>(xp), x1 = *reinterpret_cast<const float4 *>(xp + 4);          \
+            const float4 x2 = *reinterpret_cast<const float4 *>(xp + 8), x3 = *reinterpret_cast<const float4 *>(xp + 12);     \
+            _Pragma("unroll") for (int i = 0; i < 3; i++) acc[i] = dot16_fp8(w[i][CC], x0, x1, x2, x3, acc[i]);               \
+        } else {                                                                                         \
+            const float4 x0 = *reinterpret_cast<const float4 *>(xs + (CC * 64 + lane) * 8);              \
+            const float4 x1 = *reinterpret_cast<const float4 *>(xs + (CC * 64 + lane) * 8 + 4);          \
+            _Pragma("unroll") for (int i = 0; i < 3; i++) acc[i] = dot8_bf16(w[i][CC], x0, x1, acc[i]);  \
+        }                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                               \
     }
+    // the Wo loads come in four batches (I0 = 0, 4, 8, 12 in units of bf16 loads: a quarter of the wave's loads each)
 #define DF_LATE_WO(I0)                                                                                   \
-    if constexpr (!EMBED) { _Pragma("unroll") for (int i = I0; i < I0 + 4; i++) wv[i] = ld_stream(reinterpret_cast<const uint4 *>(DF_WO_PTR(i))); }
+    if constexpr (!EMBED) { _Pragma("unroll") for (int i = (I0) * NWO / 16; i < ((I0) + 4) * NWO / 16; i++) {                \
+        wv[i] = ld_stream(reinterpret_cast<const uint4 *>(DF_WO_PTR(i))); if constexpr (W8) wo_sc[i] = DF_WO_SCALE(i); } }
     // The two kinds of workgroup order their memory queue differently (per-workgroup timeline, tools/fuse_timeline.py).
     // The members that run attention (j < nsplit: 4 of a group's 32 at the 30 s clip's KV length) gate everybody: nobody's
     // sweep completes before the LAST member has published, and all wait for their partials.  With the K/V tile (64 KB) and
@@ -377,7 +397,8 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
 #undef DF_PIECE
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const float sres = df_wave_sum<USE_DPP>(acc[i]);
+        float sres = df_wave_sum<USE_DPP>(acc[i]);
+        if constexpr (W8) sres *= a.sqkv[prow[i]];                  // per-row dequantisation scale
         if (lane == 0) red[16 + 3 * wave + i] = sres;
     }
     DF_MARK(4);
@@ -406,13 +427,17 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     }
     __syncthreads();                       // xs / nw are dead from here on: 24 KB of scratch for the attention stage
     DF_MARK(5);
-    if (!att_block) {
-        DF_LATE_WO(0) DF_LATE_WO(4) DF_LATE_WO(8) DF_LATE_WO(12)
-    }
     // L2 prefetch for the next launch (see DfPrefetch): only in the short-context regime (members without Wo rows, one XCD per group)
     const bool pf_on = a.pf.units > 0 && wo_light && !a.spread_groups;
     const int pf_V = 32 * a.pf.units, pf_Vm = min(a.pf.member_units, pf_V);
     const unsigned pf_lds = lds_addr(tiles) + 65536u + (unsigned)wave * 1024u;      // beyond the Wo reduction scratch; the tiles are dead where this is used
+    if (pf_on && !att_block && a.pf.when == 3) {      // A/B: in front of the Wo rows
+        df_prefetch_units(a.pf, g, pf_Vm, pf_V, (j - ns) * DF_WAVES + wave, (DF_BPG - ns) * DF_WAVES, lane, pf_lds);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!att_block) {
+        DF_LATE_WO(0) DF_LATE_WO(4) DF_LATE_WO(8) DF_LATE_WO(12)
+    }
     if (pf_on && !att_block && a.pf.when == 1) {
         __builtin_amdgcn_sched_barrier(0);
         df_prefetch_units(a.pf, g, pf_Vm, pf_V, (j - ns) * DF_WAVES + wave, (DF_BPG - ns) * DF_WAVES, lane, pf_lds);
@@ -585,6 +610,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     }
 #undef DF_LATE_WO
 #undef DF_WO_PTR
+#undef DF_WO_SCALE
     DF_MARK(7);
 
     // ---- hand-off 2: sweep the group's partials and merge them in slice order (thread -> head, dim) ---------------------
@@ -696,6 +722,25 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     }
 
     // ---- this wave's rows of  Wo[:, 512 g .. 512 g + 511] . att ------------------------------------------------------------------
+    if constexpr (W8) {
+        if (wo_n > 0) {
+            // lane l holds 16 weights of row wo_row0 + 2 i + (l >> 5), columns 16 (l & 31) .. + 15 of the group's 512
+            const float *xp = att + (lane & 31) * 16;
+            const float4 x0 = *reinterpret_cast<const float4 *>(xp), x1 = *reinterpret_cast<const float4 *>(xp + 4);
+            const float4 x2 = *reinterpret_cast<const float4 *>(xp + 8), x3 = *reinterpret_cast<const float4 *>(xp + 12);
+            float sums[NWO];
+#pragma unroll
+            for (int i = 0; i < NWO; i++) sums[i] = row16_sum<USE_DPP>(dot16_fp8(wv[i], x0, x1, x2, x3, 0.f));
+#pragma unroll
+            for (int i = 0; i < NWO; i++) {
+                // the other 16-lane row of this 32-lane half: a DPP row move within the same SIMD row pair is not available, so one
+                // cross-row exchange per load (all 8 issued back to back, one wait)
+                const float o = __shfl_xor(sums[i], 16, 64);
+                const int row = wo_row0 + 2 * i + (lane >> 5);
+                if ((lane & 31) == 0 && row < wo_row0 + wo_n) a.wo_part[(size_t)g * DF_D + row] = (sums[i] + o) * wo_sc[i];
+            }
+        }
+    } else
     if (wo_n > 0) {
         const float4 x0 = *reinterpret_cast<const float4 *>(att + lane * 8);
         const float4 x1 = *reinterpret_cast<const float4 *>(att + lane * 8 + 4);
@@ -770,7 +815,11 @@ struct W13xArgs {
 constexpr int W13X_THREADS = 768;
 constexpr int W13X_LDS_BYTES = (9 + 2 + 1) * DF_D * 4 + 256;
 
-template <bool W8>
+// EARLY (round 4, A/B): when round 1 of the weight stream is issued.  0 = after the prologue's arithmetic (round 3): the timeline
+// shows round 0 (37 MB chip-wide) landed ~0.5 us before that point and round 1's first bytes ~1 us after it - a bubble of more
+// than a microsecond in an otherwise full pipe.  1 = right behind the barrier that releases the prologue (its sum / RMSNorm then
+// run under round 1's latency); 2 = together with round 0, in front of that barrier.
+template <bool W8, int EARLY = 0>
 __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *stage = smem;                 // [9][3072]: x, wo_part[0..7]
@@ -812,11 +861,16 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
     if constexpr ((C) < NP) { _Pragma("unroll") for (int r = 0; r < 3; r++) w[0][r][(C) < NP ? (C) : 0] = ld_stream(p1[r] + (C) * 64); \
       _Pragma("unroll") for (int r = 0; r < 3; r++) w[1][r][(C) < NP ? (C) : 0] = ld_stream(p3[r] + (C) * 64); }
     W13_ISSUE(0) W13_ISSUE(1)
+    if constexpr (EARLY == 2) { W13_ISSUE(2) W13_ISSUE(3) }
     __builtin_amdgcn_sched_barrier(0);
     DF_MARK(1);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // the 11 DMAs are in; round 0 of the weights still streams
+    // the 11 DMAs are in; round 0 (EARLY 2: and round 1) of the weights still streams
+    if constexpr (EARLY == 2 && !W8) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if constexpr (EARLY == 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __syncthreads();
     DF_MARK(2);
+    if constexpr (EARLY == 1) { W13_ISSUE(2) W13_ISSUE(3) __builtin_amdgcn_sched_barrier(0); }
     {
         float4 v = *reinterpret_cast<const float4 *>(stage + tid * 4);
 #pragma unroll
@@ -858,7 +912,7 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
                 _Pragma("unroll") for (int r = 0; r < 3; r++) acc[m][r] = dot8_bf16(w[m][r][CC], x0, x1, acc[m][r]); \
         }                                                                               \
     }
-    W13_ISSUE(2) W13_ISSUE(3)
+    if constexpr (EARLY == 0) { W13_ISSUE(2) W13_ISSUE(3) }
     __builtin_amdgcn_sched_barrier(0);
     W13_DOT(0) W13_DOT(1)
     __builtin_amdgcn_sched_barrier(0);

@@ -82,6 +82,8 @@ struct DecLayer {
     // optional fp8 (e4m3) copies of the four matrices with one f32 scale per output row
     uint8_t *wqkv8 = nullptr, *wo8 = nullptr, *w138 = nullptr, *w28 = nullptr;
     float *sqkv = nullptr, *so = nullptr, *s13 = nullptr, *s2 = nullptr;
+    // optional bf16 copies holding dequantised block-scaled fp8 values (vox_hip_simulate_block_fp8: agreement studies)
+    uint16_t *wqkv_s = nullptr, *wo_s = nullptr, *w13_s = nullptr, *w2_s = nullptr;
     float *n1 = nullptr, *n2 = nullptr, *ada = nullptr;
     float *kring = nullptr, *vring = nullptr;
 };
@@ -230,6 +232,9 @@ struct vox_hip_engine {
     unsigned skip_kinds = 0;            // timing experiments only: PK_* launches left out of a step
     bool use_fp8 = false;               // decode GEMVs stream the fp8 copies (vox_hip_quantize_decoder_fp8)
     uint8_t *tok_emb8 = nullptr; float *stok = nullptr;
+    uint16_t *tok_emb_s = nullptr;      // simulated-quantisation copy of the LM head (see DecLayer::wqkv_s)
+    bool sim_on = false, sim_lm = false;
+    bool fp8_attn_bf16 = false, fp8_lmhead_bf16 = false;     // A/B and agreement-study switches of the fp8 mode, read at creation
     // fused attention half of the decode step (vox_decfuse.h)
     bool use_fused = false;
     bool fused_ok = false;        // the fused kernels exist for this geometry / device (use_fused may be suspended after a time-out)
@@ -271,7 +276,8 @@ struct vox_hip_engine {
     std::vector<int> tap_pos; float *d_taps = nullptr;
     // Round 4: L2 prefetch of the next launch's first weight bytes (vox_decfuse.h, DfPrefetch).  VOX_HIP_PF="units,member_units,when",
     // VOX_HIP_PF13="units,gate_ticks", VOX_HIP_PF2="units,gate_ticks" override the defaults (A/B).
-    int pf_units = 0, pf_member_units = 0, pf_when = 2;
+    // Default (measured): 24 KiB per target block (6.3 MB per launch) issued by the non-members in front of their Wo rows.
+    int pf_units = 24, pf_member_units = 0, pf_when = 3;
     int pf13_units = 0, pf2_units = 0; unsigned pf13_gate = 0, pf2_gate = 0;
 };
 
@@ -630,7 +636,11 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  hipFuncSetAttribute((const void *)k_dec_attn_fused<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_dec_attn_fused<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_dec_attn_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_dec_attn_fused<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_dec_attn_fused<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w13x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_gemv_w13x<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_gemv_w13x<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w13x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w2x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w2x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess;
@@ -638,6 +648,8 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
             e->use_fused = ok; e->fused_ok = ok;
             if (ok && getenv("VOX_HIP_FUSE_TRACE") && hipMalloc((void **)&e->d_fuse_trace, 64 * 8) == hipSuccess)
                 hipMemset(e->d_fuse_trace, 0, 64 * 8);
+            e->fp8_attn_bf16 = getenv("VOX_HIP_FP8_ATTN_BF16") != nullptr;
+            e->fp8_lmhead_bf16 = getenv("VOX_HIP_FP8_LMHEAD_BF16") != nullptr;
             if (const char *pf = getenv("VOX_HIP_PF")) sscanf(pf, "%d,%d,%d", &e->pf_units, &e->pf_member_units, &e->pf_when);
             if (const char *pf = getenv("VOX_HIP_PF13")) sscanf(pf, "%d,%u", &e->pf13_units, &e->pf13_gate);
             if (const char *pf = getenv("VOX_HIP_PF2")) sscanf(pf, "%d,%u", &e->pf2_units, &e->pf2_gate);
@@ -669,7 +681,8 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
         F(L.wqkv); F(L.wo); F(L.w13); F(L.w2); F(L.n1); F(L.n2); F(L.ada); F(L.kring); F(L.vring);
         F(L.wqkv8); F(L.wo8); F(L.w138); F(L.w28); F(L.sqkv); F(L.so); F(L.s13); F(L.s2);
     }
-    F(e->tok_emb8); F(e->stok); F(e->d_taps);
+    F(e->tok_emb8); F(e->stok); F(e->d_taps); F(e->tok_emb_s);
+    for (auto &L : e->dec) { F(L.wqkv_s); F(L.wo_s); F(L.w13_s); F(L.w2_s); }
     F(e->hann); F(e->cosT); F(e->sinT); F(e->filtT); F(e->enc_inv_freq); F(e->dec_inv_freq); F(e->dec_rope);
     F(e->d_st); F(e->dx); F(e->dx2); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
     F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_gq); F(e->d_gp); F(e->d_wo_part); F(e->d_fuse_err);
@@ -957,7 +970,8 @@ static RowsCfg dec_cfg(const vox_hip_engine *e) {
 
 // Encoder transformer on device rows x[n, enc_dim] (in place), then final norm into out.
 // Encoder attention of a chunk: window tail in the ring + this chunk's K/V in the merged QKV buffer.
-static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float *attn, int n, int pos0, float *kring, float *vring, int ring_cap) {
+static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float *attn, int n, int pos0, float *kring, float *vring, int ring_cap,
+                         const L2Pf *pf = nullptr) {
     const int N3 = c.QD + 2 * c.KVD;
     hipStream_t s = e->stream;
     AttnArgs a{};
@@ -979,8 +993,12 @@ static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float 
             if (e->use_dpp) hipLaunchKernelGGL((k_attn_small<true, 8>), dim3(c.heads, ks), dim3(512), 0, s, a, lo);
             else hipLaunchKernelGGL((k_attn_small<false, 8>), dim3(c.heads, ks), dim3(512), 0, s, a, lo);
         }
-        hipLaunchKernelGGL((k_attn_combine<64>), dim3(c.heads, n), dim3(64), 0, s, attn, c.QD,
-                           (const float *)a.part_o, (const float *)a.part_ml, c.heads, ks);
+        if (pf && pf->n_blocks > 0 && c.heads % 8 == 0)      // + rows of L2-prefetch workgroups for the GEMM launches that follow (vox_common.h)
+            hipLaunchKernelGGL((k_attn_combine<64>), dim3(c.heads, n + pf->n_blocks / c.heads), dim3(64), 0, s, attn, c.QD,
+                               (const float *)a.part_o, (const float *)a.part_ml, c.heads, ks, n, *pf);
+        else
+            hipLaunchKernelGGL((k_attn_combine<64>), dim3(c.heads, n), dim3(64), 0, s, attn, c.QD,
+                               (const float *)a.part_o, (const float *)a.part_ml, c.heads, ks);
         return 0;
     }
     const int qt = (n + 127) / 128, blocks = qt * c.heads;
@@ -1033,9 +1051,27 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
     uint16_t *xnp = (uint16_t *)e->sgu.p, *hp = xnp + (size_t)3 * n * c.D;
     float *part = (float *)e->ssplitk.p;
     const size_t lds1 = (size_t)SK_WPB * 4096, lds2 = (size_t)SK_WPB * 2 * 4096;
+    // L2 prefetch of the next GEMM launches' weight tiles by workgroups appended to the three latency-bound launches of a layer
+    // (vox_common.h, L2Pf).  VOX_HIP_ENC_PF="finish_blocks,combine_blocks,qkvKB,woKB,w1KB,w3KB,w2KB" (KB per XCD; 0 blocks = off).
+    static int pfc[7] = {-1, 0, 0, 0, 0, 0, 0};
+    if (pfc[0] < 0) {
+        int v[7] = {224, 512, 4096, 4096, 4096, 4096, 4096};
+        if (const char *t = getenv("VOX_HIP_ENC_PF")) sscanf(t, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]);
+        v[0] &= ~7; v[1] = (v[1] / c.heads) * c.heads;
+        for (int i = 6; i >= 0; i--) pfc[i] = v[i];
+    }
+    const bool pf_ok = c.heads % 8 == 0 && (N3 / 32) % 8 == 0 && (c.H / 32) % 8 == 0 && (c.D / 32) % 8 == 0;
+    auto pf_job = [&](const uint16_t *W, int N, int K, int kb) {
+        return L2PfJob{reinterpret_cast<const unsigned char *>(W), 32 * K * 2, N / 32, kb};      // 1 KiB units per XCD = KB
+    };
+    auto pf_qkv = [&](int l) {        // attached to the launch in front of layer l's qkv GEMM
+        L2Pf p{};
+        if (pf_ok && pfc[0] > 0 && pfc[2] > 0 && l < L) { p.n_blocks = pfc[0]; p.job[0] = pf_job(e->enc[l].wqkv, N3, c.D, pfc[2]); }
+        return p;
+    };
     if (L > 0)      // attention_norm of layer 0 (no partials, no bias: x is left as it is)
-        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)nullptr, 0, n, c.D, (const float *)nullptr,
-                           (const float *)e->enc[0].n1, c.eps, xn, c.D, xnp);
+        hipLaunchKernelGGL(k_rows_finish, dim3(n + pf_qkv(0).n_blocks), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)nullptr, 0, n, c.D, (const float *)nullptr,
+                           (const float *)e->enc[0].n1, c.eps, xn, c.D, xnp, (const float *)nullptr, pf_qkv(0));
     for (int l = 0; l < L; l++) {
         EncLayer &Ly = e->enc[l];
         {   // attention_norm(x) . [wq; wk; wv]^T + bias, RoPE, K/V into the merged buffer and the rings
@@ -1045,13 +1081,25 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
             a.ring_cap = e->enc_ring_cap; a.kv_dim = c.KVD; a.pos0 = pos0; a.q_cols = c.QD;
             hipLaunchKernelGGL((k_skinny<SK_QKV, 1, true>), dim3(N3 / 32, 1), dim3(64 * SK_WPB), lds1, s, a);
         }
-        if (enc_attention(e, c, qkv, attn, n, pos0, Ly.kring, Ly.vring, e->enc_ring_cap)) return -1;
+        L2Pf pfa{}, pfb{};      // under the partial merge: wo and the gate rows; under the first finish: the up rows and w2
+        if (pf_ok && pfc[1] > 0) {
+            pfa.n_blocks = pfc[1];
+            if (pfc[3] > 0) pfa.job[0] = pf_job(Ly.wo, c.D, c.QD, pfc[3]);
+            if (pfc[4] > 0) pfa.job[1] = pf_job(Ly.w13, c.H, c.D, pfc[4]);
+        }
+        if (pf_ok && pfc[0] > 0) {
+            pfb.n_blocks = pfc[0];
+            if (pfc[5] > 0) pfb.job[0] = pf_job(Ly.w13 + (size_t)c.H * c.D, c.H, c.D, pfc[5]);
+            if (pfc[6] > 0) pfb.job[1] = pf_job(Ly.w2, c.D, c.H, pfc[6]);
+            if (!pfb.job[0].base && !pfb.job[1].base) pfb.n_blocks = 0;
+        }
+        if (enc_attention(e, c, qkv, attn, n, pos0, Ly.kring, Ly.vring, e->enc_ring_cap, &pfa)) return -1;
         {   // wo as K-split partials, then x += . + bo and ffn_norm in one launch
             SkinnyArgs a{};
             a.X = attn; a.ldx = c.QD; a.n = n; a.W = Ly.wo; a.N = c.D; a.K = c.QD; a.partial = part;
             hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, false>), dim3(c.D / 32, so), dim3(64 * SK_WPB), lds1, s, a);
-            hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, so, n, c.D, (const float *)Ly.bo,
-                               (const float *)Ly.n2, c.eps, xn, c.D, xnp);
+            hipLaunchKernelGGL(k_rows_finish, dim3(n + pfb.n_blocks), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, so, n, c.D, (const float *)Ly.bo,
+                               (const float *)Ly.n2, c.eps, xn, c.D, xnp, (const float *)nullptr, pfb);
         }
         {   // silu(xn w1^T) * (xn w3^T), written as bf16 planes for the w2 launch
             SkinnyArgs a{};
@@ -1069,9 +1117,10 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
                 hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, true>), dim3(c.D / 32, s2), dim3(64 * SK_WPB), lds1, s, a);
             }
             const bool last = l + 1 == L;
-            hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, s2n, n, c.D, (const float *)Ly.b2,
+            const L2Pf pfn = pf_qkv(l + 1);
+            hipLaunchKernelGGL(k_rows_finish, dim3(n + pfn.n_blocks), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, s2n, n, c.D, (const float *)Ly.b2,
                                (const float *)(last ? e->enc_final_norm : e->enc[l + 1].n1), c.eps, last ? out : xn, c.D,
-                               last ? (uint16_t *)nullptr : xnp);
+                               last ? (uint16_t *)nullptr : xnp, (const float *)nullptr, pfn);
         }
     }
     if (L == 0)
@@ -1799,7 +1848,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             if (!(e->skip_kinds & (1u << PK_QKV))) {
                 // attention_norm -> wq/wk/wv -> RoPE -> KV append -> attention -> wo (K-split partials): one launch
                 DecFuseArgs a{};
-                a.wqkv = L.wqkv; a.wo = L.wo; a.x = xin; a.norm_w = L.n1; a.eps = d.dec_eps; a.inv_freq = e->dec_inv_freq;
+                a.wqkv = e->sim_on ? L.wqkv_s : L.wqkv; a.wo = e->sim_on ? L.wo_s : L.wo; a.x = xin; a.norm_w = L.n1; a.eps = d.dec_eps; a.inv_freq = e->dec_inv_freq;
                 a.kring = L.kring; a.vring = L.vring; a.kv_cap = e->dec_ring_cap; a.pos = kv_pos; a.window = d.dec_window; a.scale = scale;
                 a.adapter = e->adapter; a.tok_emb = e->tok_emb; a.st = e->d_st; a.x_out = xin;
                 a.gq = e->d_gq; a.gp = e->d_gp; a.wo_part = e->d_wo_part;
@@ -1829,7 +1878,14 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                     a.pf.units = std::min(e->pf_units, 72 * (e->use_fp8 ? 3 : 6)); a.pf.member_units = e->pf_member_units; a.pf.when = e->pf_when;
                 }
                 const bool emb = (l == 0 && build_embed);
-                if (e->use_dpp) {
+                // VOX_HIP_FP8_ATTN_BF16 (A/B): the round-3 state, qkv / wo on the bf16 matrices
+                if (e->use_fp8 && e->use_dpp && !e->fp8_attn_bf16) {
+                    // fp8 mode (BASELINE config 5): the projection and Wo matrices stream their row-scaled e4m3 copies too
+                    a.wqkv = reinterpret_cast<const uint16_t *>(L.wqkv8); a.wo = reinterpret_cast<const uint16_t *>(L.wo8);
+                    a.sqkv = L.sqkv; a.so = L.so;
+                    if (emb) hipLaunchKernelGGL((k_dec_attn_fused<true, true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
+                    else hipLaunchKernelGGL((k_dec_attn_fused<false, true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
+                } else if (e->use_dpp) {
                     if (emb) hipLaunchKernelGGL((k_dec_attn_fused<true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
                     else hipLaunchKernelGGL((k_dec_attn_fused<false, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
                 } else {
@@ -1842,7 +1898,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             if (!(e->skip_kinds & (1u << PK_SWIGLU))) {
                 // x += sum of the wo partials -> ffn_norm * (1 + ada) -> silu(W1 x) * (W3 x)
                 W13xArgs a{};
-                a.w1 = L.w13; a.w3 = L.w13 + (size_t)DH * DD; a.x = xin; a.wo_part = e->d_wo_part; a.norm_w = L.n2; a.ada = L.ada;
+                a.w1 = e->sim_on ? L.w13_s : L.w13; a.w3 = a.w1 + (size_t)DH * DD; a.x = xin; a.wo_part = e->d_wo_part; a.norm_w = L.n2; a.ada = L.ada;
                 a.eps = d.dec_eps; a.x_out = xalt; a.h = e->dh;
                 a.trace = (l == 13) ? e->d_fuse_trace : nullptr;
                 a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + TL_STRIDE * 1024 : nullptr;
@@ -1855,7 +1911,10 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                     a.s1 = L.s13; a.s3 = L.s13 + DH;
                     hipLaunchKernelGGL(k_gemv_w13x<true>, dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
                 } else {
-                    hipLaunchKernelGGL(k_gemv_w13x<false>, dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
+                    static const int early = getenv("VOX_HIP_W13_EARLY") ? atoi(getenv("VOX_HIP_W13_EARLY")) : 0;      // A/B, see k_gemv_w13x
+                    if (early == 1) hipLaunchKernelGGL((k_gemv_w13x<false, 1>), dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
+                    else if (early == 2) hipLaunchKernelGGL((k_gemv_w13x<false, 2>), dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
+                    else hipLaunchKernelGGL((k_gemv_w13x<false, 0>), dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
                 }
                 prof_mark(e, PK_SWIGLU);
             }
@@ -1869,7 +1928,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                     launch_gemv3<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
                 } else {
                     W2xArgs a{};
-                    a.w2 = L.w2; a.h = e->dh; a.x = xalt;                            // x' += h . W2^T, in place (one wave per row)
+                    a.w2 = e->sim_on ? L.w2_s : L.w2; a.h = e->dh; a.x = xalt;        // x' += h . W2^T, in place (one wave per row)
                     a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + 2 * TL_STRIDE * 1024 : nullptr;
                     if (e->pf2_units > 0 && l + 1 < d.dec_layers) {
                         a.pf_w = reinterpret_cast<const unsigned char *>(e->dec[l + 1].wqkv); a.pf_units = std::min(e->pf2_units, 6); a.pf_gate = e->pf2_gate;
@@ -1976,9 +2035,10 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     tap(2 * d.dec_layers, xin);
     {   // final norm -> tied-embedding logits -> per-block argmax (voxtral_decoder.c:694-704)
         GemvArgs a{};
-        a.W = e->tok_emb; a.x = xin; a.norm_w = e->dec_final_norm; a.eps = d.dec_eps; a.y = logits_dst;
+        a.W = (e->sim_on && e->sim_lm) ? e->tok_emb_s : e->tok_emb; a.x = xin; a.norm_w = e->dec_final_norm; a.eps = d.dec_eps; a.y = logits_dst;
         a.N = d.vocab; a.K = DD; a.blk_val = e->blk_val; a.blk_idx = e->blk_idx;
-        if (fast && e->use_fp8) {
+        // VOX_HIP_FP8_LMHEAD_BF16 (agreement study): fp8 mode with the LM head on the bf16 embedding
+        if (fast && e->use_fp8 && !e->fp8_lmhead_bf16) {
             a.W = reinterpret_cast<const uint16_t *>(e->tok_emb8); a.wscale = e->stok;
             hipLaunchKernelGGL((k_gemv<PRO_RMS, EPI_LOGITS, 4, true>), dim3(e->logits_grid), dim3(256),
                                ((size_t)DD + 16) * sizeof(float), s, a);
@@ -2538,6 +2598,65 @@ extern "C" int vox_hip_quantize_decoder_fp8(vox_hip_engine_t *e) {
     return 0;
 }
 extern "C" int vox_hip_weight_format(vox_hip_engine_t *e) { return e ? (e->use_fp8 ? 1 : 0) : -1; }
+
+// Agreement study for BASELINE config 5 (tools/fp8_agreement.py): what would block-scaled fp8 weights do to the greedy ids?
+// An e4m3 value times a POWER-OF-TWO scale is exactly a bf16 value, so a block-scaled fp8 GEMV with such scales is
+// bit-for-bit the bf16 GEMV on the dequantised weights: copies of the decoder matrices (and optionally of the LM head) are
+// rewritten as dequant(quant(w)) with one 2^k scale per `block` weights of a row (block 0 = per row, 32 = the MX granularity,
+// 128 = SURVEY 7 step 9) and the decode step - fused path, bf16 kernels - streams those.  Prefill and encoder keep the
+// originals, as in the real fp8 mode.  block < 0 switches the simulation off.  4B fused geometry only; not with fp8 mode.
+__global__ __launch_bounds__(256) void k_sim_fp8_blocks(const uint16_t *W, uint16_t *Q, int K, int block) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const uint16_t *w = W + (size_t)row * K;
+    uint16_t *q = Q + (size_t)row * K;
+    const int B = block > 0 ? block : K;
+    for (int b0 = 0; b0 < K; b0 += B) {
+        float amax = 0.f;
+        for (int k = tid; k < B; k += 256) amax = fmaxf(amax, fabsf(bf16_to_f32(w[b0 + k])));
+        amax = wave_max(amax);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = amax;
+        __syncthreads();
+        amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        // smallest power of two with amax / scale <= 448 (the largest finite e4m3 value)
+        float sc = 1.0f;
+        if (amax > 0.f) { int ex; (void)frexpf(amax / 448.0f, &ex); sc = ldexpf(1.0f, ex); if (amax / ldexpf(1.0f, ex - 1) <= 448.0f) sc = ldexpf(1.0f, ex - 1); }
+        const float inv = 1.0f / sc;
+        for (int k2 = tid; k2 < B / 2; k2 += 256) {
+            const float v0 = bf16_to_f32(w[b0 + 2 * k2]) * inv, v1 = bf16_to_f32(w[b0 + 2 * k2 + 1]) * inv;
+            const int word = __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, 0, false);
+            const f32x2 d = __builtin_amdgcn_cvt_pk_f32_fp8(word, false);
+            q[b0 + 2 * k2] = (uint16_t)(__float_as_uint(d.x * sc) >> 16);          // exact: 4 significant bits x 2^k
+            q[b0 + 2 * k2 + 1] = (uint16_t)(__float_as_uint(d.y * sc) >> 16);
+        }
+    }
+}
+extern "C" int vox_hip_simulate_block_fp8(vox_hip_engine_t *e, int block, int lm_head) {
+    if (!e) return -1;
+    HC(hipSetDevice(e->device));
+    if (block < 0) { HC(esync(e)); e->sim_on = false; return 0; }
+    const vox_hip_dims_t &d = e->d;
+    const int DD = d.dec_dim, DQ = e->dec_qd, DKV = e->dec_kvd, DH = d.dec_hidden;
+    if (!e->fused_ok || e->use_fp8) { g_err = "simulate_block_fp8: needs the fused bf16 decode path"; return -1; }
+    if (block != 0 && (block % 2 || DD % block || DQ % block || DH % block)) { g_err = "simulate_block_fp8: bad block size"; return -1; }
+    if (e->up && e->up->flush()) return -1;
+    HC(esync(e));
+    auto sim = [&](const uint16_t *W, int N, int K, uint16_t **Q) -> int {
+        if (!*Q && dalloc(e, Q, (size_t)N * K)) return -1;
+        hipLaunchKernelGGL(k_sim_fp8_blocks, dim3(N), dim3(256), 0, e->stream, W, *Q, K, block);
+        return 0;
+    };
+    for (int l = 0; l < d.dec_layers; l++) {
+        DecLayer &L = e->dec[l];
+        if (sim(L.wqkv, DQ + 2 * DKV, DD, &L.wqkv_s) || sim(L.wo, DD, DQ, &L.wo_s) || sim(L.w13, 2 * DH, DD, &L.w13_s) || sim(L.w2, DD, DH, &L.w2_s)) return -1;
+    }
+    if (lm_head && sim(e->tok_emb, d.vocab, DD, &e->tok_emb_s)) return -1;
+    HC(esync(e));
+    HC(hipGetLastError());
+    e->sim_on = true; e->sim_lm = lm_head != 0;
+    return 0;
+}
 
 // Experiment hook: time `iters` passes over the five decode kernels of ONE layer (233 MB of
 // weights, which fit the 256 MB Infinity Cache) to see what the same launches cost when the

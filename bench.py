@@ -36,7 +36,7 @@ PK_NAMES = ["step_begin", "gemv_qkv_rope_kv", "attn_dec", "attn_combine", "gemv_
             "gemv_w2_resid", "gemv_logits_argmax", "argmax_finish"]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (≈6.3 TB/s achievable)
 # the W1;W3 + SwiGLU decode GEMV as rocprofv3 prints it: fused chain / launch-per-GEMV chain
-DOM_KERNEL_FUSED, DOM_KERNEL_CHAIN = "k_gemv_w13x", "k_gemv3<1, 3, 3, 6, 1, 3"
+DOM_KERNEL_FFN, DOM_KERNEL_FUSED, DOM_KERNEL_CHAIN = "k_ffn_fused", "k_gemv_w13x", "k_gemv3<1, 3, 3, 6, 1, 3"
 PK_NAMES_FUSED = {"gemv_qkv_rope_kv": "fused_qkv_attn_wo"}
 
 
@@ -195,7 +195,8 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True):
     """roofline object of the JSON line: dominant decode kernel (w1;w3 GEMV) measured live with HIP
     events on the engine stream, plus the per-kernel table and the whole-step figure."""
     fused = "dec_fused" in model.active_paths()[1]
-    DOM_KERNEL_SUBSTR = DOM_KERNEL_FUSED if fused else DOM_KERNEL_CHAIN
+    ffn = fused and "ffn_fused" in model.active_paths()[1]       # round 4: the FFN block (w1;w3 and w2) is ONE launch, k_ffn_fused
+    DOM_KERNEL_SUBSTR = DOM_KERNEL_FFN if ffn else DOM_KERNEL_FUSED if fused else DOM_KERNEL_CHAIN
     # ---- roofline of the dominant kernel, measured live with HIP events --------------------
     import ctypes as C
     v.hip.vox_hip_profile_decode.restype = C.c_double
@@ -214,16 +215,20 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True):
     if fused:      # one launch covers attention_norm .. wo: 37.7 MB of qkv rows + 25.2 MB of wo + the KV window
         kern_bytes = dict(kern_bytes)
         kern_bytes["fused_qkv_attn_wo"] = kern_bytes["gemv_qkv_rope_kv"] + kern_bytes["gemv_wo_resid"] + kern_bytes["attn_dec"]
+    if ffn:        # one launch streams W1;W3 and W2: 169.9 MB
+        kern_bytes["fused_ffn"] = kern_bytes["gemv_swiglu"] + kern_bytes["gemv_w2_resid"]
     for i, name in enumerate(PK_NAMES):
         if fused:
             name = PK_NAMES_FUSED.get(name, name)
+        if ffn and name == "gemv_swiglu":
+            name = "fused_ffn"
         if cnt[i]:
             ent = {"launches_per_token": cnt[i], "avg_us": round(avg[i], 2)}
             if name in kern_bytes:
                 ent["bytes"] = kern_bytes[name]
                 ent["GBps"] = round(kern_bytes[name] / (avg[i] * 1e-6) / 1e9, 1) if avg[i] > 0 else 0.0
             kernels[name] = ent
-    dom = "gemv_swiglu"
+    dom = "fused_ffn" if ffn else "gemv_swiglu"
     # Launch duration of the dominant kernel inside the chain: HIP events around N whole decode
     # steps with and without the 26 w1;w3 launches, on the engine stream; the difference / 26 is
     # what one launch costs in situ (boundary included, no event packets between kernels).  The
@@ -267,12 +272,13 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True):
     floor_us = {f"eager_{g}": round(v.hip.vox_hip_time_empty_launches(model.engine, 2000, g) * 1e6, 2) for g in (256, 768)}
     floor_us.update({f"graph_{g}": round(v.hip.vox_hip_time_empty_launches_graph(model.engine, 2000, g) * 1e6, 2) for g in (256, 768)})
     roofline = {
-        "bound": "hbm", "kernel": ("k_gemv_w13x" if fused else "k_gemv3<PRO_RMS,EPI_SWIGLU,3,6,1,3>") +
-                                  " (decoder W1;W3 GEMV, 43% of the weight bytes of a token)",
+        "bound": "hbm", "kernel": ("k_ffn_fused (decoder FFN block: W1;W3 GEMV, in-kernel hand-off of h, W2 GEMV; 64% of the weight bytes of a token)" if ffn else
+                                  ("k_gemv_w13x" if fused else "k_gemv3<PRO_RMS,EPI_SWIGLU,3,6,1,3>") +
+                                  " (decoder W1;W3 GEMV, 43% of the weight bytes of a token)"),
         "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_ach / HBM_PEAK_GBS, 4),
         "bytes_per_launch": kern_bytes[dom] // (2 if weights == "fp8" else 1), "avg_us_per_launch": round(dom_us, 2),
         "method": "HIP events on the engine stream around 50 decode steps with and without the 26 launches of this kernel; "
-                  "(full - skipped) / 26",
+                  "(full - skipped) / 26" + (" (the skipped runs leave out the whole FFN launch)" if ffn else ""),
         "traffic": traffic, "traffic_source": traffic_source,
         "decode_step": {"algorithmic_bytes": wbytes + kvbytes, "ms": round(s_per_step * 1e3, 4),
                         "GBps": round((wbytes + kvbytes) / s_per_step / 1e9, 1),

@@ -47,7 +47,13 @@ if r.shape[1] >= 19:
         for i in np.nonzero(m & (st[:, 7] - st[:, 6] > 0.3))[0]:
             print(f"   g{g} j{blk[i] // 8}: {st[i, 4]:6.2f} {st[i, 5]:6.2f} {st[i, 6]:6.2f} [{st[i, 11]:6.2f} {st[i, 12]:6.2f}] {st[i, 7]:6.2f} | {st[m, 5].max():6.2f}")
 r = rows[rows[:, 0] == 1]
-if r.shape[1] >= 11:
+if r.shape[1] >= 14 and (r[:, 13] > 0).any():        # k_ffn_fused (round 4): 8 stamps of wave 0
+    st = r[:, 6:14]
+    print("k_ffn_fused phase stamps, wave 0 of every workgroup (us): min / p50 / max")
+    for i, n in enumerate(["entry", "round 0 issued", "prologue in", "normed", "h published (W2 row queued)", "all waves there", "h swept", "done"]):
+        c = st[:, i]
+        print(f"   {i:2d} {n:28s} {c.min():6.2f} {np.median(c):6.2f} {c.max():6.2f}")
+elif r.shape[1] >= 11:
     st = r[:, 6:11]
     print("k_gemv_w13x phase stamps (us): min / p50 / max")
     for i, n in enumerate(["entry", "round 0 issued", "prologue in", "normed", "done (wave 0)"]):

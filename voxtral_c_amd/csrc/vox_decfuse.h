@@ -618,6 +618,10 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     if (!(wo_light && att_block)) {
         const int h = tid >> 7, d = tid & 127;
         float M = -1e30f, L = 0.f, O = 0.f;
+        // (Round 4, built, measured and removed: the sweep queued ONCE behind the Wo rows / prefetch units, so that it is back when
+        //  they have landed - about when the partials exist - and the poll, its barrier and the second trip to L2 can be skipped:
+        //  +22 .. +50 us per step at every prefetch depth, gpurun_out/r4l.  224 workgroups x 512 threads x 12 granule loads in
+        //  flight while the members run their attention delay the members: attention end 11.2 -> 12.1 us, everybody's sweep 13.4 -> 15.4.)
         // 28 of a group's 32 workgroups arrive here long before the partials exist.  ONE thread per workgroup polls (one granule
         // of the last slice); the other 511 sleep at the barrier: with every thread re-reading its granules the pollers took so
         // much of the fabric that the attention members - whom they are waiting for - finished 2 us later (measured).
@@ -1038,4 +1042,251 @@ __global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
     }
     tl_end(a.tl, tl0);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// k_ffn_fused (round 4) - the whole FFN block of a decoder step as ONE launch:
+//     x' = x + sum_g wo_part[g] -> ffn_norm, ada -> h = silu(W1 x) * (W3 x)   |hand-off|   x'' = x' + W2 h
+// (voxtral_decoder.c:676-690; replaces k_gemv_w13x + k_gemv_w2x: 20.7 + 10.7 us per layer, of which one kernel boundary, one
+// start-up ramp and one drain - ~3 us - move no weight byte).
+//
+// Why this hand-off can be free where the others were not (a hand-off under a full-rate stream costs what a kernel
+// boundary costs, because a load issued into a saturated memory system returns behind everything queued before it): here that
+// property is used, not fought.  A wave that has finished its three row pairs of W1 / W3 publishes its three h values as
+// {epoch, value} granules (one write-through store each) and AT ONCE queues its whole row of W2 (18 KB, registers: the W1 / W3
+// registers are dead) - the weight stream never stops at the phase edge.  Once all 12 waves of the workgroup are there, every
+// thread queues its 12 granule loads of the h sweep BEHIND the W2 rows.  They come back when the W2 rows have landed, ~9 us
+// later, and every producer on the chip published its h long before that (the workgroups of a launch finish their first phase
+// within ~3 us of each other): the sweep normally needs no retry, and its round trip is hidden behind bytes that had to be
+// streamed anyway.  What remains exposed is the tail: tags checked, h to LDS, one barrier, 18 x 8 FMAs per lane, wave
+// reduction, 12 stores per workgroup.
+//
+// Needs its 256 workgroups co-resident (one per CU) like k_dec_attn_fused: every wait is bounded, a time-out sets *err and the
+// host re-runs the batch on the launch-per-GEMV chain.  The epoch is the launch counter of the layer's attention launch.
+// ---------------------------------------------------------------------------------------------------------
+struct FfnArgs {
+    const uint16_t *w1, *w3;   // [9216][3072] each (W8: fp8 e4m3 bytes, one f32 scale per row in s1 / s3)
+    const float *s1, *s3;
+    const uint16_t *w2;        // [3072][9216] (W8: fp8 bytes, scales s2)
+    const float *s2;
+    const float *x;            // [3072] residual stream before the attention block's output is added
+    const float *wo_part;      // [8][3072]
+    const float *norm_w, *ada; // [3072]
+    float eps;
+    float *x_out;              // [3072] x'' (the other residual buffer: nobody reads it during this launch)
+    float *xprime_out;         // optional [3072]: x' (debug taps), written by block 0
+    u64 *gh;                   // [9216] hand-off granules
+    unsigned epoch;
+    unsigned *err;
+    unsigned long long spin_limit;
+    unsigned long long *tl;    // optional (tuning): per-workgroup timeline
+};
+constexpr int FFN_THREADS = 768, FFN_H = 9216;
+constexpr int FFN_LDS_BYTES = W13X_LDS_BYTES;       // phase 2 reuses the prologue's staging area: x' (12 KB) + h (36 KB)
+
+// SCHED = the hand-off schedule (compile time: a run-time branch around register loads made the compiler spill).  Measured on one box,
+// alternating runs, ms per step at 232 / 1900 keys (gpurun_out/r4j; two launches: 1.3872 / 1.5689):
+//   2 (B, the default)  nothing of phase 2 is queued before the whole workgroup has finished phase 1; then the W2 rows, then the sweep
+//          behind them: 1.3662 / 1.5539.  Timeline: workgroup barrier at +18.0 us, sweep back at +25.2 (the 216 KB of W2 rows per CU
+//          landed in 7.2 us), done at +27.0: the 72 KB sweep costs nothing, the dot products at the end cost 1.8 us.
+//   1 (A)  early waves queue their W2 row at once (the stream never drains), workgroup barrier, sweep: 1.4436 / 1.6373 - the early
+//          W2 rows delay the late waves' last W1 / W3 pieces (barrier at +23.7 us), and the sweep behind the barrier has nothing
+//          left to hide behind: 5.6 us, which is what a 72 KB all-to-all granule sweep costs on this chip.
+// Built, measured and removed: C - no barrier, wave w sweeps the granules of the waves w of all workgroups right behind its own W2
+// row (1.82 / 2.01: early sweeps find stale tags, every retry queues behind the CU's whole stream and 3072 polling waves take
+// bandwidth from it); E - the sweep IN FRONT of the W2 rows so that the dot products run piece by piece under the stream
+// (1.3988 / 1.5908: the sweep still takes its ~6 us, now in front of everything, and slows the rows it shares the queue with);
+// D+E - E with a third of the W2 row queued before the barrier (1.4165 / 1.6006).
+template <bool W8, int SCHED = 1>
+__global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *stage = smem;                 // [9][3072]: x, wo_part[0..7]; after the prologue: row 0 = x', rows 1..3 = h
+    float *nws = smem + 9 * DF_D;        // [3072] norm weights
+    float *ads = nws + DF_D;             // [3072] ada
+    float *xs = ads + DF_D;              // [3072]
+    float *red = xs + DF_D;              // [16]
+    float *hs = stage + DF_D;            // [9216] h (phase 2)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wofs = (unsigned)wave * 1024u;
+    unsigned long long df_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tl0 = tl_begin(a.tl);
+#define FFN_MARK(k) do { if (a.tl) df_stamp[k] = wall_clock64(); } while (0)
+    FFN_MARK(0);
+
+    // ---- phase 1: exactly k_gemv_w13x (same memory-queue order, same arithmetic) ------------------------------------------
+    glds16(a.x + tid * 4, lds_addr(stage) + wofs);
+#pragma unroll
+    for (int gi = 0; gi < 8; gi++) glds16(a.wo_part + (size_t)gi * DF_D + tid * 4, lds_addr(stage + (gi + 1) * DF_D) + wofs);
+    glds16(a.norm_w + tid * 4, lds_addr(nws) + wofs);
+    glds16(a.ada + tid * 4, lds_addr(ads) + wofs);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NP = W8 ? 3 : 6, EPP = W8 ? 16 : 8;
+    uint4 w[2][3][NP];
+    const int pair0 = blockIdx.x * 36 + wave * 3;
+    const uint4 *p1[3], *p3[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        constexpr size_t ROWB = W8 ? DF_D : 2 * DF_D;
+        p1[r] = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.w1) + (size_t)(pair0 + r) * ROWB) + lane;
+        p3[r] = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.w3) + (size_t)(pair0 + r) * ROWB) + lane;
+    }
+#define FFN_ISSUE(C)                                                                    \
+    if constexpr ((C) < NP) { _Pragma("unroll") for (int r = 0; r < 3; r++) w[0][r][(C) < NP ? (C) : 0] = ld_stream(p1[r] + (C) * 64); \
+      _Pragma("unroll") for (int r = 0; r < 3; r++) w[1][r][(C) < NP ? (C) : 0] = ld_stream(p3[r] + (C) * 64); }
+    FFN_ISSUE(0) FFN_ISSUE(1)
+    __builtin_amdgcn_sched_barrier(0);
+    FFN_MARK(1);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // the 11 DMAs are in; round 0 of the weights still streams
+    __syncthreads();
+    FFN_MARK(2);
+    {
+        float4 v = *reinterpret_cast<const float4 *>(stage + tid * 4);
+#pragma unroll
+        for (int gi = 1; gi <= 8; gi++) {
+            const float4 p = *reinterpret_cast<const float4 *>(stage + gi * DF_D + tid * 4);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        *reinterpret_cast<float4 *>(stage + tid * 4) = v;          // x' stays in LDS for phase 2 (own elements: no hazard)
+        if (blockIdx.x == 0 && a.xprime_out) *reinterpret_cast<float4 *>(a.xprime_out + tid * 4) = v;
+        float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; i++) tot += red[i];
+        const float inv = 1.0f / sqrtf(tot / (float)DF_D + a.eps);
+        const float4 gw = *reinterpret_cast<const float4 *>(nws + tid * 4);
+        const float4 sc = *reinterpret_cast<const float4 *>(ads + tid * 4);
+        v.x = v.x * inv * gw.x * (1.0f + sc.x); v.y = v.y * inv * gw.y * (1.0f + sc.y);
+        v.z = v.z * inv * gw.z * (1.0f + sc.z); v.w = v.w * inv * gw.w * (1.0f + sc.w);
+        *reinterpret_cast<float4 *>(xs + tid * 4) = v;
+        __syncthreads();
+    }
+    FFN_MARK(3);
+    float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#define FFN_DOT(C)                                                                      \
+    if constexpr ((C) < NP) {                                                           \
+        constexpr int CC = (C) < NP ? (C) : 0;                                          \
+        const float *xp = xs + (CC * 64 + lane) * EPP;                                  \
+        const float4 x0 = *reinterpret_cast<const float4 *>(xp);                        \
+        const float4 x1 = *reinterpret_cast<const float4 *>(xp + 4);                    \
+        if constexpr (W8) {                                                             \
+            const float4 x2 = *reinterpret_cast<const float4 *>(xp + 8);                \
+            const float4 x3 = *reinterpret_cast<const float4 *>(xp + 12);               \
+            _Pragma("unroll") for (int m = 0; m < 2; m++)                               \
+                _Pragma("unroll") for (int r = 0; r < 3; r++) acc[m][r] = dot16_fp8(w[m][r][CC], x0, x1, x2, x3, acc[m][r]); \
+        } else {                                                                        \
+            _Pragma("unroll") for (int m = 0; m < 2; m++)                               \
+                _Pragma("unroll") for (int r = 0; r < 3; r++) acc[m][r] = dot8_bf16(w[m][r][CC], x0, x1, acc[m][r]); \
+        }                                                                               \
+    }
+    FFN_ISSUE(2) FFN_ISSUE(3)
+    __builtin_amdgcn_sched_barrier(0);
+    FFN_DOT(0) FFN_DOT(1)
+    __builtin_amdgcn_sched_barrier(0);
+    FFN_ISSUE(4) FFN_ISSUE(5)
+    __builtin_amdgcn_sched_barrier(0);
+    FFN_DOT(2) FFN_DOT(3)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the phase edge: this wave's row of W2 goes into the queue before its last dot products, so the stream never drains -----
+    constexpr int NP2 = W8 ? 9 : 18;
+    uint4 w2r[NP2];
+    const int row = blockIdx.x * 12 + wave;
+    const uint4 *wp = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.w2) + (size_t)row * (W8 ? FFN_H : 2 * FFN_H)) + lane;
+    constexpr int NEARLY = SCHED == 1 ? NP2 : 0;     // W2 pieces queued before the workgroup barrier
+#pragma unroll
+    for (int c = 0; c < NEARLY; c++) w2r[c] = ld_stream(wp + c * 64);
+    __builtin_amdgcn_sched_barrier(0);
+    FFN_DOT(4) FFN_DOT(5)
+#undef FFN_ISSUE
+#undef FFN_DOT
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) acc[m][r] = wave_sum(acc[m][r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            float g = acc[0][r], u = acc[1][r];
+            if constexpr (W8) { g *= a.s1[pair0 + r]; u *= a.s3[pair0 + r]; }
+            df_store_granule(a.gh + pair0 + r, a.epoch, silu(g) * u);                   // voxtral_decoder.c:684-687
+        }
+    }
+    FFN_MARK(4);
+    // ---- hand-off: workgroup barrier (stage rows 1..8 are dead from here), W2 rows, then every thread's 12 granules behind them ----
+    __syncthreads();
+    // SCHED 3 = B with the sweep behind the first two thirds of the W2 row instead of all of it: h is in LDS while the last third
+    // is still landing, and only that third's dot products remain when the stream ends
+    constexpr int NBEFORE = SCHED == 3 ? (NP2 * 2) / 3 : NP2;
+    if constexpr (SCHED >= 2) {      // schedule B: nothing of phase 2 is queued before the whole workgroup has finished phase 1
+#pragma unroll
+        for (int c = 0; c < NBEFORE; c++) w2r[c] = ld_stream(wp + c * 64);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    FFN_MARK(5);
+    {
+        u64 gv[12];
+        int gi[12];
+#pragma unroll
+        for (int u = 0; u < 12; u++) gi[u] = u * FFN_THREADS + tid;
+        // First attempt in straight-line code (inside a loop the compiler merges the wait counts of "W2 rows queued" and "not queued" and
+        // waits for the whole W2 row before it looks at the first tag); the retry loop is entered only if a tag was stale.
+#pragma unroll
+        for (int u = 0; u < 12; u++) gv[u] = df_load_granule(a.gh + gi[u]);
+        if constexpr (SCHED == 3) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = NBEFORE; c < NP2; c++) w2r[c] = ld_stream(wp + c * 64);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < 12; u++) ok = ok && (unsigned)(gv[u] >> 32) == a.epoch;
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
+            const unsigned long long t0 = wall_clock64();
+            for (unsigned it = 0;; it++) {
+                if ((it & 15u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(8);
+                ok = true;
+#pragma unroll
+                for (int u = 0; u < 12; u++) gv[u] = df_load_granule(a.gh + gi[u]);
+#pragma unroll
+                for (int u = 0; u < 12; u++) ok = ok && (unsigned)(gv[u] >> 32) == a.epoch;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;           // the wave moves as one: its loads go out together
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 12; u++) hs[gi[u]] = __uint_as_float((unsigned)gv[u]);
+    }
+    __syncthreads();
+    FFN_MARK(6);
+
+    // ---- phase 2: x''[row] = x'[row] + W2[row] . h  (k_gemv_w2x's arithmetic) -----------------------------------------------------
+    {
+        constexpr int EPP2 = W8 ? 16 : 8;
+        float acc2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NP2; c++) {
+            const float *xp = hs + (c * 64 + lane) * EPP2;
+            const float4 x0 = *reinterpret_cast<const float4 *>(xp);
+            const float4 x1 = *reinterpret_cast<const float4 *>(xp + 4);
+            if constexpr (W8) {
+                const float4 x2 = *reinterpret_cast<const float4 *>(xp + 8);
+                const float4 x3 = *reinterpret_cast<const float4 *>(xp + 12);
+                acc2 = dot16_fp8(w2r[c], x0, x1, x2, x3, acc2);
+            } else {
+                acc2 = dot8_bf16(w2r[c], x0, x1, acc2);
+            }
+        }
+        acc2 = wave_sum(acc2);
+        if constexpr (W8) acc2 *= a.s2[row];
+        if (lane == 0) a.x_out[row] = stage[row] + acc2;
+    }
+    FFN_MARK(7);
+#undef FFN_MARK
+    tl_end(a.tl, tl0, df_stamp, 8);
+}
+
 }  // namespace vox

@@ -239,7 +239,10 @@ struct vox_hip_engine {
     bool use_fused = false;
     bool fused_ok = false;        // the fused kernels exist for this geometry / device (use_fused may be suspended after a time-out)
     long fuse_rearm = 0;          // clean decode steps on the chain before the fused kernel is tried again (0 = not suspended)
-    u64 *d_gq = nullptr, *d_gp = nullptr;
+    u64 *d_gq = nullptr, *d_gp = nullptr, *d_gh = nullptr;
+    float *d_xprime = nullptr;    // x' of the fused FFN launch, written only for the debug taps
+    bool use_ffn = false;         // FFN block as one launch (k_ffn_fused) instead of k_gemv_w13x + k_gemv_w2x
+    int ffn_sweep = 2;            // hand-off schedule of k_ffn_fused (VOX_HIP_FFN_SWEEP=1: schedule A, see the kernel)
     float *d_wo_part = nullptr;
     unsigned *d_fuse_err = nullptr;
     unsigned fuse_epoch = 0;
@@ -254,6 +257,7 @@ struct vox_hip_engine {
     bool gp_bd = false;
     Buf splanes;                  // [3][n][max(D, QD, H)] bf16
     Uploader *up = nullptr;       // staged weight ingest: lives until vox_hip_upload_done (vox_load calls it) or the engine's end
+    unsigned long long *d_enc_tl = nullptr;       // VOX_HIP_ENC_TL: [4 GEMM launches][1024 workgroups][16] timeline of one few-rows encoder layer
     unsigned long long *d_fuse_tl = nullptr;      // VOX_HIP_FUSE_TL: [3 kernels][1024 workgroups][3] timeline of the layer-13 launches
     int fuse_failures = 0;
     int *d_tokens = nullptr;
@@ -628,7 +632,9 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
         if (geom && !getenv("VOX_HIP_NO_FUSED") && !getenv("VOX_HIP_NO_GEMV3") && !getenv("VOX_HIP_NO_GEMV2") && !getenv("VOX_HIP_CUMASK") &&
             hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount == DF_BLOCKS) {
             bool ok = dalloc(e, &e->d_gq, (size_t)DF_GROUPS * DF_GQ) == 0 && dalloc(e, &e->d_gp, (size_t)DF_GROUPS * DF_BPG * DF_GP) == 0 &&
-                      dalloc(e, &e->d_wo_part, (size_t)DF_GROUPS * DF_D) == 0 && dalloc(e, &e->d_fuse_err, 64) == 0;
+                      dalloc(e, &e->d_wo_part, (size_t)DF_GROUPS * DF_D) == 0 && dalloc(e, &e->d_fuse_err, 64) == 0 &&
+                      dalloc(e, &e->d_gh, (size_t)FFN_H) == 0 && dalloc(e, &e->d_xprime, (size_t)DF_D) == 0 &&
+                      hipMemset(e->d_gh, 0, (size_t)FFN_H * 8) == hipSuccess;
             ok = ok && hipMemset(e->d_gq, 0, (size_t)DF_GROUPS * DF_GQ * 8) == hipSuccess &&
                  hipMemset(e->d_gp, 0, (size_t)DF_GROUPS * DF_BPG * DF_GP * 8) == hipSuccess &&
                  hipMemset(e->d_fuse_err, 0, 64 * 4) == hipSuccess;
@@ -643,9 +649,15 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  hipFuncSetAttribute((const void *)k_gemv_w13x<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w13x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w2x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_gemv_w2x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess;
+                 hipFuncSetAttribute((const void *)k_gemv_w2x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_ffn_fused<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_ffn_fused<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_ffn_fused<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_ffn_fused<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess;
             if (!ok) { (void)hipGetLastError(); fprintf(stderr, "vox_hip: fused decode kernels unavailable; launch-per-GEMV chain\n"); }
             e->use_fused = ok; e->fused_ok = ok;
+            e->use_ffn = ok && !getenv("VOX_HIP_NO_FFN_FUSED");        // A/B: k_gemv_w13x + k_gemv_w2x instead of k_ffn_fused
+            if (getenv("VOX_HIP_FFN_SWEEP")) e->ffn_sweep = atoi(getenv("VOX_HIP_FFN_SWEEP"));
             if (ok && getenv("VOX_HIP_FUSE_TRACE") && hipMalloc((void **)&e->d_fuse_trace, 64 * 8) == hipSuccess)
                 hipMemset(e->d_fuse_trace, 0, 64 * 8);
             e->fp8_attn_bf16 = getenv("VOX_HIP_FP8_ATTN_BF16") != nullptr;
@@ -686,6 +698,7 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     F(e->hann); F(e->cosT); F(e->sinT); F(e->filtT); F(e->enc_inv_freq); F(e->dec_inv_freq); F(e->dec_rope);
     F(e->d_st); F(e->dx); F(e->dx2); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
     F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_gq); F(e->d_gp); F(e->d_wo_part); F(e->d_fuse_err);
+    F(e->d_gh); F(e->d_xprime);
     Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
                    &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml, &e->ssplitk};
     for (Buf *b : bufs) F(b->p);
@@ -1051,11 +1064,17 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
     uint16_t *xnp = (uint16_t *)e->sgu.p, *hp = xnp + (size_t)3 * n * c.D;
     float *part = (float *)e->ssplitk.p;
     const size_t lds1 = (size_t)SK_WPB * 4096, lds2 = (size_t)SK_WPB * 2 * 4096;
+    if (getenv("VOX_HIP_ENC_TL") && !e->d_enc_tl && hipMalloc((void **)&e->d_enc_tl, 4 * 1024 * TL_STRIDE * 8) == hipSuccess)
+        hipMemset(e->d_enc_tl, 0, 4 * 1024 * TL_STRIDE * 8);
+    auto tlp = [&](int l, int k) { return (e->d_enc_tl && l == L / 2) ? e->d_enc_tl + (size_t)k * 1024 * TL_STRIDE : nullptr; };
     // L2 prefetch of the next GEMM launches' weight tiles by workgroups appended to the three latency-bound launches of a layer
     // (vox_common.h, L2Pf).  VOX_HIP_ENC_PF="finish_blocks,combine_blocks,qkvKB,woKB,w1KB,w3KB,w2KB" (KB per XCD; 0 blocks = off).
+    // OFF by default - measured (gpurun_out/r4g): with every GEMM launch's tiles in its XCD's L2 the four GEMM
+    // launches of a 25-row layer get 0.0 - 0.6 us shorter each (13.0 -> 12.4, 10.8 -> 10.8, 9.5 -> 9.2, 4.5 -> 4.4 us) while the
+    // launches carrying the prefetch get longer: 67.7 -> 69.9 us per layer.  These launches are not waiting for HBM.
     static int pfc[7] = {-1, 0, 0, 0, 0, 0, 0};
     if (pfc[0] < 0) {
-        int v[7] = {224, 512, 4096, 4096, 4096, 4096, 4096};
+        int v[7] = {0, 0, 4096, 4096, 4096, 4096, 4096};
         if (const char *t = getenv("VOX_HIP_ENC_PF")) sscanf(t, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]);
         v[0] &= ~7; v[1] = (v[1] / c.heads) * c.heads;
         for (int i = 6; i >= 0; i--) pfc[i] = v[i];
@@ -1078,7 +1097,7 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
             SkinnyArgs a{};
             a.Xp = xnp; a.xp_plane = (size_t)n * c.D; a.n = n; a.W = Ly.wqkv; a.N = N3; a.K = c.D; a.bias = Ly.bqkv; a.Y = qkv; a.ldy = N3;
             a.rope_cols = c.QD + c.KVD; a.head_dim = c.hd; a.rope_tab = tab; a.kring = Ly.kring; a.vring = Ly.vring;
-            a.ring_cap = e->enc_ring_cap; a.kv_dim = c.KVD; a.pos0 = pos0; a.q_cols = c.QD;
+            a.ring_cap = e->enc_ring_cap; a.kv_dim = c.KVD; a.pos0 = pos0; a.q_cols = c.QD; a.tl = tlp(l, 0);
             hipLaunchKernelGGL((k_skinny<SK_QKV, 1, true>), dim3(N3 / 32, 1), dim3(64 * SK_WPB), lds1, s, a);
         }
         L2Pf pfa{}, pfb{};      // under the partial merge: wo and the gate rows; under the first finish: the up rows and w2
@@ -1096,7 +1115,7 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
         if (enc_attention(e, c, qkv, attn, n, pos0, Ly.kring, Ly.vring, e->enc_ring_cap, &pfa)) return -1;
         {   // wo as K-split partials, then x += . + bo and ffn_norm in one launch
             SkinnyArgs a{};
-            a.X = attn; a.ldx = c.QD; a.n = n; a.W = Ly.wo; a.N = c.D; a.K = c.QD; a.partial = part;
+            a.X = attn; a.ldx = c.QD; a.n = n; a.W = Ly.wo; a.N = c.D; a.K = c.QD; a.partial = part; a.tl = tlp(l, 1);
             hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, false>), dim3(c.D / 32, so), dim3(64 * SK_WPB), lds1, s, a);
             hipLaunchKernelGGL(k_rows_finish, dim3(n + pfb.n_blocks), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, so, n, c.D, (const float *)Ly.bo,
                                (const float *)Ly.n2, c.eps, xn, c.D, xnp, (const float *)nullptr, pfb);
@@ -1104,7 +1123,7 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
         {   // silu(xn w1^T) * (xn w3^T), written as bf16 planes for the w2 launch
             SkinnyArgs a{};
             a.Xp = xnp; a.xp_plane = (size_t)n * c.D; a.n = n; a.W = Ly.w13; a.W2 = Ly.w13 + (size_t)c.H * c.D; a.N = c.H; a.K = c.D;
-            a.Yp = hp; a.yp_plane = (size_t)n * c.H;
+            a.Yp = hp; a.yp_plane = (size_t)n * c.H; a.tl = tlp(l, 2);
             hipLaunchKernelGGL((k_skinny<SK_SWIGLU, 1, true>), dim3(c.H / 32, 1), dim3(64 * SK_WPB), lds2, s, a);
         }
         {   // w2 partials, then x += . + b2 and the next norm (next layer's attention_norm, or the final norm into `out`)
@@ -1113,7 +1132,7 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
                 s2n = launch_rowsgemm(e, hp, (size_t)n * c.H, nullptr, 0, n, Ly.w2, c.D, c.H, part);
             } else {
                 SkinnyArgs a{};
-                a.Xp = hp; a.xp_plane = (size_t)n * c.H; a.n = n; a.W = Ly.w2; a.N = c.D; a.K = c.H; a.partial = part;
+                a.Xp = hp; a.xp_plane = (size_t)n * c.H; a.n = n; a.W = Ly.w2; a.N = c.D; a.K = c.H; a.partial = part; a.tl = tlp(l, 3);
                 hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, true>), dim3(c.D / 32, s2), dim3(64 * SK_WPB), lds1, s, a);
             }
             const bool last = l + 1 == L;
@@ -1895,6 +1914,32 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 prof_mark(e, PK_QKV);
             }
             tap(2 * l, xin);              // (layer 0 of a stream step builds x inside the launch above and writes it to xin)
+            // (fp8 mode keeps the two launches: with half the W2 bytes the 72 KB sweep and the dot products at the end are no longer
+            //  hidden - measured 1.1055 against 1.0271 ms per step, gpurun_out/r4k)
+            if (e->use_ffn && !e->use_fp8 && !e->sim_on && !(e->skip_kinds & ((1u << PK_SWIGLU) | (1u << PK_W2)))) {
+                // the whole FFN block as one launch (k_ffn_fused): x' -> ffn_norm -> silu(W1 x) * (W3 x) -> in-kernel hand-off of h -> x' + W2 h
+                FfnArgs a{};
+                a.w1 = L.w13; a.w3 = L.w13 + (size_t)DH * DD; a.w2 = L.w2; a.x = xin; a.wo_part = e->d_wo_part; a.norm_w = L.n2; a.ada = L.ada;
+                a.eps = d.dec_eps; a.x_out = xalt; a.xprime_out = tap_i >= 0 ? e->d_xprime : nullptr;
+                a.gh = e->d_gh; a.epoch = e->fuse_epoch; a.err = e->d_fuse_err; a.spin_limit = 500000ull;
+
+                a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + TL_STRIDE * 1024 : nullptr;
+                if (e->use_fp8) {
+                    a.w1 = reinterpret_cast<const uint16_t *>(L.w138); a.w3 = reinterpret_cast<const uint16_t *>(L.w138 + (size_t)DH * DD);
+                    a.w2 = reinterpret_cast<const uint16_t *>(L.w28); a.s1 = L.s13; a.s3 = L.s13 + DH; a.s2 = L.s2;
+                    hipLaunchKernelGGL((k_ffn_fused<true, 2>), dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a);
+                } else if (e->ffn_sweep == 1) {
+                    hipLaunchKernelGGL((k_ffn_fused<false, 1>), dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a);
+                } else if (e->ffn_sweep == 3) {
+                    hipLaunchKernelGGL((k_ffn_fused<false, 3>), dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a);
+                } else {
+                    hipLaunchKernelGGL((k_ffn_fused<false, 2>), dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a);
+                }
+                prof_mark(e, PK_SWIGLU);
+                tap(2 * l + 1, e->d_xprime);
+                std::swap(xin, xalt);
+                continue;
+            }
             if (!(e->skip_kinds & (1u << PK_SWIGLU))) {
                 // x += sum of the wo partials -> ffn_norm * (1 + ada) -> silu(W1 x) * (W3 x)
                 W13xArgs a{};
@@ -2470,6 +2515,24 @@ extern "C" double vox_hip_time_encoder_rows(vox_hip_engine_t *e, int n_rows, int
     hipEventRecord(e->ev1, e->stream);
     esync(e);
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    if (e->d_enc_tl && getenv("VOX_HIP_ENC_TL")) {      // per-workgroup timeline of the last pass's mid-stack GEMM launches -> text file
+        std::vector<unsigned long long> h((size_t)4 * 1024 * TL_STRIDE);
+        FILE *f = fopen(getenv("VOX_HIP_ENC_TL"), "w");
+        if (f && hipMemcpy(h.data(), e->d_enc_tl, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long t0 = ~0ull;
+            for (size_t i = 0; i < (size_t)4 * 1024; i++) if (h[i * TL_STRIDE] && h[i * TL_STRIDE] < t0) t0 = h[i * TL_STRIDE];
+            fprintf(f, "# kernel block start_us end_us xcc hw_id stamps(issued, chunk0 done, compute done, tiles in LDS, reduced)   kernel 0 qkv, 1 wo, 2 w1;w3, 3 w2\n");
+            for (int k = 0; k < 4; k++)
+                for (int b = 0; b < 1024; b++) {
+                    const unsigned long long *r = &h[(size_t)(k * 1024 + b) * TL_STRIDE];
+                    if (!r[0]) continue;
+                    fprintf(f, "%d %d %.2f %.2f %u %u", k, b, (double)(r[0] - t0) / 100.0, (double)(r[1] - t0) / 100.0, (unsigned)(r[2] >> 32), (unsigned)r[2]);
+                    for (int q = 3; q < 8; q++) fprintf(f, " %.2f", r[q] ? (double)(r[q] - t0) / 100.0 : -1.0);
+                    fprintf(f, "\n");
+                }
+        }
+        if (f) fclose(f);
+    }
     vox_hip_reset_encoder(e);
     return (double)ms * 1e-3 / iters;
 }
@@ -2525,6 +2588,7 @@ extern "C" int vox_hip_time_decoder_step_without(vox_hip_engine_t *e, int iters,
     if (!e || kind <= 0 || kind >= PK_LOGITS) return -1;
     const double a = vox_hip_time_decoder_step(e, iters, kv_len);
     e->skip_kinds = 1u << kind;
+    if (kind == PK_SWIGLU && e->use_fused && e->use_ffn && !e->use_fp8) e->skip_kinds |= 1u << PK_W2;      // k_ffn_fused is ONE launch: w1;w3 and w2 go together
     const double b = vox_hip_time_decoder_step(e, iters, kv_len);
     e->skip_kinds = 0;
     if (full_s) *full_s = a;
@@ -2821,6 +2885,7 @@ static int self_test(vox_hip_engine *e) {
         for (const void *f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, rg_lds) != hipSuccess) {
                 (void)hipGetLastError();
+                if (e->use_rowsgemm) fprintf(stderr, "vox_hip: WARNING k_rowsgemm cannot get its LDS (%zu bytes): 33 .. 128-row passes fall back to the planes GEMM / k_skinny\n", (size_t)rg_lds);
                 e->use_rowsgemm = false;
             }
         if (getenv("VOX_HIP_NO_ROWSGEMM")) e->use_rowsgemm = false;
@@ -2858,6 +2923,8 @@ extern "C" unsigned vox_hip_active_paths(const vox_hip_engine_t *e) {
     if (fast_geom && e->use_fused) m |= VOX_PATH_DEC_FUSED;
     if (e->use_skinny && e->use_mfma) m |= VOX_PATH_SKINNY_ENC;
     if (e->use_planes && e->use_mfma && e->use_bf16x3) m |= VOX_PATH_GEMM_PLANES;
+    if (fast_geom && e->use_fused && e->use_ffn && !e->use_fp8) m |= VOX_PATH_FFN_FUSED;
+    if (e->use_rowsgemm && e->use_mfma) m |= VOX_PATH_ROWSGEMM;
     return m;
 }
 

@@ -42,7 +42,9 @@ struct SkinnyArgs {
     int rope_cols, head_dim;              // SK_QKV: columns [0, rope_cols) are rotated (q then k), pairs (2c, 2c+1)
     const float *rope_tab;                // [n][head_dim/2][2] cos, sin of this chunk's positions
     float *kring, *vring; int ring_cap, kv_dim, pos0, q_cols;   // k columns start at q_cols, v columns at q_cols + kv_dim
+    unsigned long long *tl;               // optional (tuning, VOX_HIP_ENC_TL): per-workgroup timeline, see tl_begin / tl_end
 };
+#define SK_MARK(k) do { if (a.tl) sk_stamp[k] = wall_clock64(); } while (0)
 
 // x[m][k..k+7] (f32) -> three bf16x8 fragments (hi, mid, lo): exact split, vox_gemm.h split3
 __device__ __forceinline__ void sk_split_frag(const float4 x0, const float4 x1, bf16x8_t &fh, bf16x8_t &fm, bf16x8_t &fl) {
@@ -87,6 +89,8 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
     const int row0 = blockIdx.x * 32;
     const int nchunks = a.K / 64;
     const int kworkers = gridDim.y * SK_WPB, kw = blockIdx.y * SK_WPB + wave;
+    unsigned long long sk_stamp[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long tl0 = tl_begin(a.tl);
 
     f32x4 acc[NB][2][MU];
 #pragma unroll
@@ -176,15 +180,18 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
     if (c0 < nchunks) { issue_x(xq0, c0); issue_w(wq[0], c0); }
     if (c1 < nchunks) issue_w(wq[1], c1);
     if (c2 < nchunks) issue_w(wq[2], c2);
+    SK_MARK(0);
     if (c0 < nchunks) {
         if (c1 < nchunks) issue_x(xq1, c1);
         compute(wq[0], xq0);
+        SK_MARK(1);
         if (c1 < nchunks) {
             if (c2 < nchunks) issue_x(xq0, c2);
             compute(wq[1], xq1);
             if (c2 < nchunks) compute(wq[2], xq0);
         }
     }
+    SK_MARK(2);
 
     // ---- add the K splitters of this workgroup in wave order.  Tiles are kept as [32 rows m][32 columns] in LDS: the 16 x 16
     // MFMA's C layout is column = lane & 15, row = 4 (lane >> 4) + r ----------------------------------------------------------------
@@ -198,6 +205,7 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
                 for (int r = 0; r < 4; r++)
                     sk_lds[((wave * NB + b) * MT + (u >> 1)) * 1024 + (16 * (u & 1) + 4 * kb + r) * 32 + 16 * q + li] = acc[b][q][u][r];
     __syncthreads();
+    SK_MARK(3);
     float *red = sk_lds;                                            // reduced tiles overwrite wave 0's slots
     for (int e = tid; e < NB * MT * 1024; e += 64 * SK_WPB) {
         float v = sk_lds[e];
@@ -206,6 +214,7 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
         red[e] = v;                                                 // same index as wave 0's own slot e: no hazard
     }
     __syncthreads();
+    SK_MARK(4);
 
     // ---- epilogue over the tile: e -> (tile t, row, column) -> row m = 32 t + ((e >> 5) & 31), col = e & 31
     for (int e = tid; e < MT * 1024; e += 64 * SK_WPB) {
@@ -241,6 +250,7 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
             }
         }
     }
+    tl_end(a.tl, tl0, sk_stamp, 5);
 }
 
 // x[m] += bias + sum_s partial[s][m]  (split order), then out_norm[m] = rmsnorm(x[m]) * w (+ada) — one block per row.

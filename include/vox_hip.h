@@ -196,6 +196,15 @@ int vox_hip_shard_kv_push(vox_hip_engine_t *src, vox_hip_engine_t *dst, int laye
 int64_t vox_hip_adapter_extend(vox_hip_engine_t *e, int n_rows);                           /* first new logical row or -1 */
 int vox_hip_shard_end_push(vox_hip_engine_t *src, vox_hip_engine_t *owner, int64_t first_row);
 int vox_hip_encoder_state_push(vox_hip_engine_t *src, vox_hip_engine_t *dst);
+/* Round 4.  vox_hip_shard_end_push and vox_hip_encoder_state_push no longer make the owner's stream wait for the other engine
+ * at once: the owner's DECODER waits (on its stream) for a shard's adapter rows right in front of the first step that reads
+ * them, its ENCODER side waits for the handed-over state before it touches encoder state again - so decoding starts on the first
+ * shard's rows while later shards still encode.  VOX_MULTI_NO_OVERLAP=1 restores the immediate waits (A/B).
+ * vox_hip_encoder_aligned: 1 if the stream's encoder state sits on a token boundary (a sharded chunk may start from it);
+ * vox_hip_encoder_pos: encoder positions done so far; vox_hip_pending_fences: waits not yet placed (tests). */
+int vox_hip_encoder_aligned(const vox_hip_engine_t *e);
+int vox_hip_encoder_pos(const vox_hip_engine_t *e);
+int vox_hip_pending_fences(const vox_hip_engine_t *e);
 
 /* ---- state ---------------------------------------------------------------------- */
 void vox_hip_reset_encoder(vox_hip_engine_t *e);   /* mel queue, conv tails, encoder KV, 4x residual */

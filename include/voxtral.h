@@ -170,11 +170,14 @@ typedef struct vox_ctx {
     float **ada_down, **ada_up; /* per-layer f32 copies of the ada MLP weights (= decoder.layers[i].ada_norm_*) */
     void *tokenizer;            /* vox_tokenizer_t shared by the streams of this model (parsed once) */
     /* Extra GPUs of a multi-device model (vox_load_opts_t.devices / VOX_DEVICES=0,1,...): encoder-only engines that take
-     * contiguous position ranges of a large first chunk (exact context parallelism, host/vox_multi.c).  engine above is
+     * contiguous position ranges of a large chunk (exact context parallelism, host/vox_multi.c).  engine above is
      * shard_engines[0]'s peer on devices[0] and runs everything else (streaming chunks, prefill, decode). */
     void *shard_engines[VOX_MAX_DEVICES];
     int n_shard_engines;        /* engines taking part in a sharded chunk, including `engine` (1 = single GPU) */
     float **owned_f32; int n_owned_f32, cap_owned_f32;   /* the f32 views this ctx allocated (freed by vox_free) */
+    int n_sharded_chunks;       /* chunks encoded by all shard engines together so far (statistics, tests) */
+    int shard_disabled;         /* set (atomically) when a sharded chunk failed: later streams of this model run on one GPU; the
+                                 * shard engines stay alive until vox_free (another stream may be using them) */
 } vox_ctx_t;
 
 /* Optional load parameters (vox_load uses the defaults; the environment variables

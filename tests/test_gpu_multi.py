@@ -91,6 +91,39 @@ def test_in_library_multi_device_encoder_matches_single_gpu(preset, seconds, dev
     assert np.array_equal(got2, want2) and np.array_equal(want2, want)
 
 
+@pytest.mark.parametrize("preset,seconds,devices", [("small", 90.0, "0,0,0"), ("tiny", 60.0, "0,0")])
+def test_in_library_later_chunks_are_sharded_too_and_decoding_overlaps(preset, seconds, devices):
+    """Round 4: not only a stream's first chunk - every chunk that starts on a token boundary and holds >= 16 tokens per engine goes
+    through all engines (three feeds of a third of the clip each, processing interval 2 s: three sharded chunks, the second and
+    third continuing from the stream engine's K/V rings and conv history), and the stream engine's decoder no longer waits for
+    the whole wavefront: it waits for a shard's adapter rows right in front of the first step that reads them.  Ids = the single
+    engine's; VOX_MULTI_NO_OVERLAP=1 (the round-3 waits) gives the same ids."""
+    import ctypes as C
+    import voxtral_c_amd as v
+    v.hip.vox_hip_pending_fences.argtypes = [C.c_void_p]
+    audio = synth_speech(seconds, 56)
+    third = (len(audio) // 3 // 1280) * 1280
+    feeds = [third, third, len(audio)]
+    win = {} if preset != "tiny" else dict(enc_window=48, dec_window=64)
+    with v.Model(model_dir(preset), **win) as m:
+        want = m.transcribe(audio, feed_sizes=feeds)["tokens"]
+        assert m.ctx.n_sharded_chunks == 0
+    for no_overlap in (False, True):
+        os.environ["VOX_DEVICES"] = devices
+        if no_overlap:
+            os.environ["VOX_MULTI_NO_OVERLAP"] = "1"
+        try:
+            with v.Model(model_dir(preset), **win) as mm:
+                got = mm.transcribe(audio, feed_sizes=feeds)["tokens"]
+                n_sharded = mm.ctx.n_sharded_chunks
+                assert v.hip.vox_hip_pending_fences(mm.engine) == 0
+        finally:
+            del os.environ["VOX_DEVICES"]
+            os.environ.pop("VOX_MULTI_NO_OVERLAP", None)
+        assert len(want) > 300 and np.array_equal(got, want), (no_overlap, len(got), len(want))
+        assert n_sharded == 3, n_sharded
+
+
 def _bench_json(cmd, env, timeout=1500, want_rc=0):
     import json
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)

@@ -168,3 +168,64 @@ def test_shard_plan_and_mel_span():
     assert n == 3392                     # 8 mel frames per adapter token, M = 424
     buf, n = padded_stream(np.zeros(176000, np.float32))
     assert n == 1496                     # jfk.wav: 1496 frames
+
+
+def _pipelined_worker(rank, world, port, mdir, out_dir):
+    """Round 4: pipelined delivery of the adapter rows (deliver_rows_pipelined).  The LAST rank is slowed down (it sleeps before
+    every layer); rank 0 stamps the moment it is handed its first block - in the product that is where the decoder's prefill
+    starts - and every rank stamps the end of its own shard."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import time
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from audio_util import synth_speech
+    from oracle import vox_oracle as vo
+    from voxtral_c_amd.multi_gpu import Staging, TorchComm, encode_sharded, padded_stream
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dims = vo.PRESETS["tiny"]
+    eng = OracleShardEngine(mdir, dims)
+    if rank == world - 1:
+        plain_layer = eng.layer
+        eng.layer = lambda l: (time.sleep(0.4), plain_layer(l))[1]
+    comm = TorchComm()
+    padded, n_frames = padded_stream(synth_speech(12.0, 41))
+    blocks, stamps = [], {}
+
+    def consume(r, rows):
+        stamps.setdefault("first_block", time.time())
+        blocks.append((r, rows.numpy().copy()))
+
+    def staging(shape):
+        return Staging(comm.empty(shape))
+
+    rows, counts = encode_sharded(eng, comm, padded, n_frames, staging, dst=0, on_encoded=lambda: stamps.setdefault("shard_done", time.time()),
+                                  consume=consume)
+    assert rows is None
+    all_stamps = [None] * world
+    dist.all_gather_object(all_stamps, stamps)
+    if rank == 0:
+        assert [r for r, _ in blocks] == list(range(world)) and [b.shape[0] for _, b in blocks] == counts
+        np.save(os.path.join(out_dir, "rows.npy"), np.concatenate([b for _, b in blocks]))
+        # rank 0 had its first block - and, in the product, its decoder running - before the slowed-down last shard was finished
+        assert all_stamps[0]["first_block"] < all_stamps[world - 1]["shard_done"] - 0.3, all_stamps
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rows_are_delivered_block_by_block_and_decoding_starts_before_the_last_shard_is_done(tmp_path):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    from audio_util import synth_speech
+    from oracle import vox_oracle as vo
+    from voxtral_c_amd.multi_gpu import padded_stream
+    mdir = model_dir("tiny")
+    mp.spawn(_pipelined_worker, args=(3, _free_port(), mdir, str(tmp_path)), nprocs=3, join=True)
+    got = np.load(str(tmp_path / "rows.npy"))
+    o = vo.Oracle(mdir, vo.PRESETS["tiny"])
+    padded, n_frames = padded_stream(synth_speech(12.0, 41))
+    ref = o.stream_encode(vo.mel_frames(padded, n_frames))
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-4

@@ -77,7 +77,8 @@ class _Ctx(C.Structure):
                       "dec_ffn_out", "dec_rope_freqs") +
                 [("dims", _Dims), ("device", C.c_int), ("engine", C.c_void_p), ("ada_down", C.c_void_p), ("ada_up", C.c_void_p),
                  ("tokenizer", C.c_void_p), ("shard_engines", C.c_void_p * 8), ("n_shard_engines", C.c_int),
-                 ("owned_f32", C.c_void_p), ("n_owned_f32", C.c_int), ("cap_owned_f32", C.c_int)])
+                 ("owned_f32", C.c_void_p), ("n_owned_f32", C.c_int), ("cap_owned_f32", C.c_int),
+                 ("n_sharded_chunks", C.c_int), ("shard_disabled", C.c_int)])
 
 
 class _LoadOpts(C.Structure):

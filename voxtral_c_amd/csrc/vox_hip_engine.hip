@@ -268,6 +268,14 @@ struct vox_hip_engine {
     vox_hip_timing_t timing{};
     // multi-GPU shard in flight (vox_hip_shard_*), events for cross-engine stream ordering
     std::vector<hipEvent_t> xev; size_t xev_next = 0;
+    // Round 4: work other engines still have in flight FOR this engine (a sharded chunk, vox_multi.c).  Instead of making this
+    // engine's one stream wait for all of it at once, the waits are placed where the data is first touched: the decoder waits
+    // for a shard's adapter rows when it reaches them (row_fences, ascending), the encoder side waits for the handed-over stream
+    // state before it touches encoder state again (enc_fence).  So the decoder starts on the first shard's rows while the
+    // later shards are still encoding.
+    struct RowFence { int64_t first_row; hipEvent_t ev; };
+    std::vector<RowFence> row_fences;
+    std::vector<hipEvent_t> enc_fences;
     float *shard_x = nullptr; int shard_n = 0;
     // per-kernel profiling of the decode step (HIP events between launches)
     bool prof_on = false;
@@ -290,6 +298,26 @@ struct vox_hip_engine {
 static hipError_t esync(vox_hip_engine *e) {
     e->n_host_syncs++;
     return hipStreamSynchronize(e->stream);
+}
+
+// Stream-side waits for other engines' pending work (see vox_hip_engine::row_fences).
+static int apply_row_fences(vox_hip_engine *e, int64_t upto_row) {         // rows [.., upto_row] are about to be read on e->stream
+    while (!e->row_fences.empty() && e->row_fences.front().first_row <= upto_row) {
+        HC(hipStreamWaitEvent(e->stream, e->row_fences.front().ev, 0));
+        e->row_fences.erase(e->row_fences.begin());
+    }
+    return 0;
+}
+static int apply_enc_fences(vox_hip_engine *e) {                            // encoder state is about to be touched on e->stream
+    for (hipEvent_t ev : e->enc_fences) HC(hipStreamWaitEvent(e->stream, ev, 0));
+    e->enc_fences.clear();
+    return 0;
+}
+static int drain_fences(vox_hip_engine *e) {                                // host wait: everything anybody still owes this engine
+    for (auto &f : e->row_fences) HC(hipEventSynchronize(f.ev));
+    for (hipEvent_t ev : e->enc_fences) HC(hipEventSynchronize(ev));
+    e->row_fences.clear(); e->enc_fences.clear();
+    return 0;
 }
 
 enum { PK_BEGIN = 0, PK_QKV, PK_ATTN, PK_COMBINE, PK_WO, PK_SWIGLU, PK_W2, PK_LOGITS, PK_ARGMAX, PK_COUNT };
@@ -683,6 +711,7 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     if (!e) return;
     hipSetDevice(e->device);
     if (e->up) { e->up->stop(); delete e->up; e->up = nullptr; }
+    (void)drain_fences(e);
     if (e->stream) esync(e);
     auto F = [](void *p) { if (p) hipFree(p); };
     F(e->splanes.p);
@@ -1394,6 +1423,7 @@ static int conv_stem_dev(vox_hip_engine *e, int n, float **xout) {
     hipStream_t s = e->stream;
     *xout = nullptr;
     if (n <= 0) return 0;
+    if (apply_enc_fences(e)) return -1;
     float *in0 = (float *)e->conv_in0.p;
     if (ensure_keep(e, e->conv_in1, (size_t)(2 + n + 1) * ED * 4, (size_t)2 * ED * 4)) return -1;
     float *in1 = (float *)e->conv_in1.p;
@@ -1495,6 +1525,7 @@ extern "C" int vox_hip_conv_stem_pad_odd(vox_hip_engine_t *e, float *out_row) {
 extern "C" int vox_hip_encoder_chunk(vox_hip_engine_t *e, const float *x_new, int new_len, float *out) {
     if (!e || new_len <= 0) return -1;
     HC(hipSetDevice(e->device));
+    if (apply_enc_fences(e)) return -1;
     const int ED = e->d.enc_dim;
     if (ensure(e, e->stmp_in, (size_t)new_len * ED * 4)) return -1;
     if (ensure(e, e->stmp_out, (size_t)new_len * ED * 4)) return -1;
@@ -1527,6 +1558,7 @@ static int adapter_reserve(vox_hip_engine *e, int64_t extra_rows) {
     const int DD = e->d.dec_dim;
     int64_t phys = e->adapter_total - e->adapter_row0;
     if (phys + extra_rows <= e->adapter_cap) return 0;
+    if (drain_fences(e)) return -1;          // rows are about to move: nobody may still be writing into the old buffer
     // drop rows the decoder has already consumed (stream_adapter_compact, voxtral.c:718-731)
     const int64_t dead = std::min(e->adapter_consumed - e->adapter_row0, phys);
     if (dead > 0) {
@@ -1563,6 +1595,7 @@ extern "C" int vox_hip_adapter_read(vox_hip_engine_t *e, int64_t first_row, int 
     if (!e || n_rows <= 0) return -1;
     HC(hipSetDevice(e->device));
     if (first_row < e->adapter_row0 || first_row + n_rows > e->adapter_total) { g_err = "vox_hip_adapter_read: rows not resident"; return -1; }
+    if (apply_row_fences(e, first_row + n_rows - 1)) return -1;
     HC(esync(e));
     HC(hipMemcpy(out, e->adapter + (size_t)(first_row - e->adapter_row0) * e->d.dec_dim,
                  (size_t)n_rows * e->d.dec_dim * 4, hipMemcpyDeviceToHost));
@@ -2205,6 +2238,7 @@ extern "C" int vox_hip_decoder_prefill_stream(vox_hip_engine_t *e, int64_t first
     if (first_row < e->adapter_row0 || first_row + n_prompt > e->adapter_total) { g_err = "prefill_stream: adapter rows not resident"; return -1; }
     const int DD = e->d.dec_dim;
     hipStream_t s = e->stream;
+    if (apply_row_fences(e, first_row + n_prompt - 1)) return -1;
     HC(hipEventRecord(e->ev0, s));
     if (ensure(e, e->sx, (size_t)n_prompt * DD * 4)) return -1;
     float *x = (float *)e->sx.p;
@@ -2248,8 +2282,11 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
             if (ensure(e, e->stmp_out, (size_t)batch * V * 4)) return -1;
             lg = (float *)e->stmp_out.p;
         }
-        for (int i = 0; i < batch; i++)
+        for (int i = 0; i < batch; i++) {
+            // a shard's adapter rows are waited for (on the stream) right in front of the first step that reads them
+            if (!e->row_fences.empty() && apply_row_fences(e, first_row + done + i)) return -1;
             if (enqueue_step(e, e->dec_pos + i, true, logits_out ? lg + (size_t)i * V : lg, eos_token, 1)) return -1;
+        }
         DecState st{};
         HC(hipMemcpyAsync(&st, e->d_st, sizeof st, hipMemcpyDeviceToHost, s));
         HC(esync(e));
@@ -2279,6 +2316,7 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
 extern "C" void vox_hip_reset_encoder(vox_hip_engine_t *e) {
     if (!e) return;
     hipSetDevice(e->device);
+    (void)drain_fences(e);
     esync(e);
     e->enc_pos = 0; e->mel_q = 0; e->c0_carry = 0; e->enc_res = 0;
     // zero the causal-history rows (start-of-sequence padding)
@@ -2291,6 +2329,7 @@ extern "C" void vox_hip_reset_encoder(vox_hip_engine_t *e) {
 extern "C" void vox_hip_reset_encoder_async(vox_hip_engine_t *e) {
     if (!e) return;
     hipSetDevice(e->device);
+    (void)apply_enc_fences(e);
     e->enc_pos = 0; e->mel_q = 0; e->c0_carry = 0; e->enc_res = 0;
     if (e->conv_in0.p) hipMemsetAsync(e->conv_in0.p, 0, (size_t)2 * e->d.mel_bins * 4, e->stream);
     if (e->conv_in1.p) hipMemsetAsync(e->conv_in1.p, 0, (size_t)2 * e->d.enc_dim * 4, e->stream);
@@ -2303,6 +2342,7 @@ extern "C" unsigned long long vox_hip_host_syncs(const vox_hip_engine_t *e) { re
 extern "C" void vox_hip_reset_decoder(vox_hip_engine_t *e) {
     if (!e) return;
     hipSetDevice(e->device);
+    (void)drain_fences(e);
     esync(e);
     e->dec_pos = 0;
     e->adapter_total = 0; e->adapter_row0 = 0; e->adapter_consumed = 0;
@@ -2315,7 +2355,12 @@ extern "C" void vox_hip_reset_decoder_kv(vox_hip_engine_t *e) {
 }
 extern "C" int vox_hip_decoder_kv_len(const vox_hip_engine_t *e) { return e ? e->dec_pos : 0; }
 extern "C" int vox_hip_mel_queue_len(const vox_hip_engine_t *e) { return e ? e->mel_q : 0; }
-extern "C" void vox_hip_sync(vox_hip_engine_t *e) { if (e) { hipSetDevice(e->device); esync(e); } }
+extern "C" void vox_hip_sync(vox_hip_engine_t *e) { if (e) { hipSetDevice(e->device); (void)drain_fences(e); esync(e); } }
+// 1 if the stream's encoder state sits on a token boundary (no conv0 frame waiting for its stride-2 partner, no encoder rows
+// waiting for 4x alignment): the state a sharded chunk may start from (vox_multi.c)
+extern "C" int vox_hip_encoder_aligned(const vox_hip_engine_t *e) { return e ? (e->c0_carry == 0 && e->enc_res == 0) : 0; }
+extern "C" int vox_hip_encoder_pos(const vox_hip_engine_t *e) { return e ? e->enc_pos : 0; }
+extern "C" int vox_hip_pending_fences(const vox_hip_engine_t *e) { return e ? (int)(e->row_fences.size() + e->enc_fences.size()) : 0; }
 extern "C" void vox_hip_get_timing(const vox_hip_engine_t *e, vox_hip_timing_t *t) { if (e && t) *t = e->timing; }
 extern "C" void vox_hip_reset_timing(vox_hip_engine_t *e) { if (e) e->timing = vox_hip_timing_t{}; }
 // Encoder time spent outside vox_hip_stream_encode (a chunk sharded over several engines, host/vox_multi.c): the host
@@ -3086,16 +3131,24 @@ static int peer_copy_async(vox_hip_engine *dst, void *dptr, vox_hip_engine *src,
     else HC(hipMemcpyPeerAsync(dptr, dst->device, sptr, src->device, bytes, s));
     return 0;
 }
-// consumer's stream waits for everything enqueued so far on the producer's stream
-static int chain_streams(vox_hip_engine *producer, vox_hip_engine *consumer) {
-    if (producer == consumer) return 0;
+// an event behind everything enqueued so far on the producer's stream (from its ring of 64: a sharded chunk records
+// 32 layers + 2 per engine, and every one of them has been waited for before the ring comes round)
+static int record_xev(vox_hip_engine *producer, hipEvent_t *out) {
     HC(hipSetDevice(producer->device));
     if (producer->xev.empty()) {
-        producer->xev.resize(64);
+        producer->xev.resize(96);
         for (auto &ev : producer->xev) HC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     hipEvent_t ev = producer->xev[producer->xev_next++ % producer->xev.size()];
     HC(hipEventRecord(ev, producer->stream));
+    *out = ev;
+    return 0;
+}
+// consumer's stream waits for everything enqueued so far on the producer's stream
+static int chain_streams(vox_hip_engine *producer, vox_hip_engine *consumer) {
+    if (producer == consumer) return 0;
+    hipEvent_t ev;
+    if (record_xev(producer, &ev)) return -1;
     HC(hipStreamWaitEvent(consumer->stream, ev, 0));
     return 0;
 }
@@ -3220,7 +3273,14 @@ extern "C" int vox_hip_shard_end_push(vox_hip_engine_t *src, vox_hip_engine_t *o
         if (ensure(src, src->stmp_in, (size_t)m * DD * 4)) return -1;
         if (adapter_dev(src, (const float *)src->stmp_out.p, m, (float *)src->stmp_in.p)) return -1;
         if (peer_copy_async(owner, dst_rows, src, src->stmp_in.p, (size_t)m * DD * 4, src->stream)) return -1;
-        if (chain_streams(src, owner)) return -1;
+        // the owner's stream does NOT wait here: its decoder waits for these rows when it gets to them (row_fences)
+        static const bool no_overlap = getenv("VOX_MULTI_NO_OVERLAP") != nullptr;       // A/B: the round-3 behaviour
+        if (no_overlap) { if (chain_streams(src, owner)) return -1; }
+        else {
+            hipEvent_t ev;
+            if (record_xev(src, &ev)) return -1;
+            owner->row_fences.push_back({first_row, ev});
+        }
     }
     src->enc_pos += n;                       // like a streaming chunk: the engine now stands behind its shard
     src->shard_x = nullptr; src->shard_n = 0;
@@ -3243,5 +3303,10 @@ extern "C" int vox_hip_encoder_state_push(vox_hip_engine_t *src, vox_hip_engine_
     if (peer_copy_async(dst, dst->conv_in1.p, src, src->conv_in1.p, (size_t)2 * ED * 4, src->stream)) return -1;
     if (peer_copy_async(dst, dst->enc_out.p, src, src->enc_out.p, (size_t)3 * ED * 4, src->stream)) return -1;
     dst->enc_pos = src->enc_pos; dst->c0_carry = src->c0_carry; dst->enc_res = src->enc_res;
-    return chain_streams(src, dst);
+    static const bool no_overlap = getenv("VOX_MULTI_NO_OVERLAP") != nullptr;
+    if (no_overlap) return chain_streams(src, dst);
+    hipEvent_t ev;
+    if (record_xev(src, &ev)) return -1;
+    dst->enc_fences.push_back(ev);           // waited for in front of dst's next encoder-side work, not by its decoder
+    return 0;
 }

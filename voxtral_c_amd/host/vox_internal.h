@@ -24,7 +24,7 @@ int vox_mel_total_frames(vox_mel_ctx_t *ctx);
 /* Engine used by the engine-less public mel API (created on first use). */
 vox_hip_engine_t *vox_default_mel_engine(void);
 
-/* host/vox_multi.c: sharded encoder of a stream's first chunk over ctx->shard_engines; frames consumed / 0 / -1 */
-int vox_multi_encode_first_chunk(vox_ctx_t *ctx, int frames_avail, int *new_tokens);
+/* host/vox_multi.c: sharded encoder of a large chunk over ctx->shard_engines; frames consumed / 0 / -1 */
+int vox_multi_encode_chunk(vox_ctx_t *ctx, int frames_avail, int *new_tokens);
 
 #endif

@@ -54,17 +54,22 @@ static int up_f32(vox_ctx_t *ctx, int slot, int layer, const char *name, float *
     if (!t) return -1;
     float *v = vox_st_to_f32(t);
     if (!v) return -1;
-    const int rc = vox_hip_upload_f32((vox_hip_engine_t *)ctx->engine, slot, layer, v, (size_t)vox_st_numel(t));
-    if (view && own_f32(ctx, v) == 0) *view = v; else free(v);
+    int rc = vox_hip_upload_f32((vox_hip_engine_t *)ctx->engine, slot, layer, v, (size_t)vox_st_numel(t));
+    if (!view) free(v);
+    else if (own_f32(ctx, v) == 0) *view = v;
+    else { free(v); fprintf(stderr, "vox_load: out of memory keeping the f32 view of %s\n", name); rc = -1; }   /* a NULL view in a "loaded" ctx would be a trap */
     return rc;
 }
 
 /* f32 view of a tensor the engine takes as bf16 (the conv weights: the reference converts them at load,
  * voxtral_encoder.c:56-63; identical values). */
-static void view_f32(vox_ctx_t *ctx, const char *name, float **view) {
+static int view_f32(vox_ctx_t *ctx, const char *name, float **view) {
     const vox_st_tensor_t *t = vox_st_find((const vox_st_file_t *)ctx->safetensors, name);
     float *v = t ? vox_st_to_f32(t) : NULL;
-    if (v && own_f32(ctx, v) == 0) *view = v; else free(v);
+    if (v && own_f32(ctx, v) == 0) { *view = v; return 0; }
+    free(v);
+    fprintf(stderr, "vox_load: cannot build the f32 view of %s\n", name);
+    return -1;              /* the header promises these views filled: fail the load rather than leave a hole */
 }
 
 /* ---- time conditioning (reference voxtral.c:31-80) --------------------------------
@@ -239,8 +244,8 @@ vox_ctx_t *vox_load_ex(const char *model_dir, const vox_load_opts_t *opts) {
     rc |= up_f32(ctx, VOXT_CONV0_B, 0, ENC_PFX ".conv_layers.0.conv.bias", &ctx->encoder.conv0_bias);
     rc |= up_bf16(ctx, VOXT_CONV1_W, 0, ENC_PFX ".conv_layers.1.conv.weight", NULL);
     rc |= up_f32(ctx, VOXT_CONV1_B, 0, ENC_PFX ".conv_layers.1.conv.bias", &ctx->encoder.conv1_bias);
-    view_f32(ctx, ENC_PFX ".conv_layers.0.conv.weight", &ctx->encoder.conv0_weight);
-    view_f32(ctx, ENC_PFX ".conv_layers.1.conv.weight", &ctx->encoder.conv1_weight);
+    rc |= view_f32(ctx, ENC_PFX ".conv_layers.0.conv.weight", &ctx->encoder.conv0_weight);
+    rc |= view_f32(ctx, ENC_PFX ".conv_layers.1.conv.weight", &ctx->encoder.conv1_weight);
     for (int i = 0; i < d->enc_layers && !rc; i++) {
         vox_enc_layer_t *Lv = &ctx->encoder.layers[i];
 #define EL(sfx) (snprintf(nm, sizeof nm, ENC_PFX ".transformer.layers.%d." sfx, i), nm)
@@ -344,6 +349,11 @@ vox_ctx_t *vox_load_ex(const char *model_dir, const vox_load_opts_t *opts) {
 
 void vox_free(vox_ctx_t *ctx) {
     if (!ctx) return;
+    /* the stream engine may still hold waits on events of the shard engines (a sharded chunk's adapter rows / handed-over encoder
+     * state that nothing has touched since): resolve them while those engines - and their events - still exist */
+    if (ctx->engine) vox_hip_sync((vox_hip_engine_t *)ctx->engine);
+    for (int i = 1; i < ctx->n_shard_engines; i++)
+        if (ctx->shard_engines[i]) vox_hip_sync((vox_hip_engine_t *)ctx->shard_engines[i]);
     for (int i = 1; i < ctx->n_shard_engines; i++)
         if (ctx->shard_engines[i]) vox_hip_engine_destroy((vox_hip_engine_t *)ctx->shard_engines[i]);
     if (ctx->engine) vox_hip_engine_destroy((vox_hip_engine_t *)ctx->engine);

@@ -212,27 +212,33 @@ static void run_encoder(vox_stream_t *s) {
 
     const double t0 = now_ms();
     int new_mel_left = new_mel;
-    if (s->ctx->n_shard_engines > 1 && !s->stem_started) {
-        /* a multi-device model: the first chunk of a stream, if large, is encoded by all GPUs together (vox_multi.c);
-         * whatever is left (< 8 frames) and every later chunk runs on the stream's own engine as usual */
+    if (s->ctx->n_shard_engines > 1 && !__atomic_load_n(&s->ctx->shard_disabled, __ATOMIC_RELAXED)) {
+        /* a multi-device model: a large chunk - a stream's first one or any later one that starts on a token boundary - is
+         * encoded by all GPUs together (vox_multi.c); whatever is left (< 8 frames) waits for the next chunk, or runs on the
+         * stream's own engine as usual when the stream is being finished.  (main.c -i feeds files in 1 s pieces: after the
+         * first chunk of ~3 s such a stream never has 16 tokens per engine in one chunk - it cannot benefit; one-feed clients,
+         * vox_transcribe_audio and large processing intervals do.) */
         int mt = 0;
-        const int used = vox_multi_encode_first_chunk(s->ctx, new_mel, &mt);
+        const int used = vox_multi_encode_chunk(s->ctx, new_mel, &mt);
         if (used < 0) {
             /* By now the mel queue of the stream engine may be half consumed and adapter rows are accounted for that
              * were never written: there is nothing consistent left to retry on (the device mel queue is the only copy
              * of the frames).  Fail the stream for good - every later feed / flush / finish returns -1, like the
-             * reference's error convention (voxtral.c:1237) - and stop sharding for the streams that follow. */
+             * reference's error convention (voxtral.c:1237).  Later streams of this model do not shard (one flag write,
+             * read at the start of run_encoder: no engine is torn down under a stream that may still use it). */
             fprintf(stderr, "vox_stream: sharded encoder failed (%s); this stream is dead, later streams of this model run on one GPU\n",
                     vox_hip_last_error());
             s->failed = 1;
-            s->ctx->n_shard_engines = 1;
+            __atomic_store_n(&s->ctx->shard_disabled, 1, __ATOMIC_RELAXED);
             return;
         }
         if (used > 0) {
-            /* the shards were only enqueued: wait for the stream engine (every other engine's last work is chained into
-             * its stream) so that the encoder time printed at the end - and parsed by benchmark.py - is the real one */
-            vox_hip_sync(s->eng);
+            /* the shards are only enqueued, and the stream engine does not wait for the others here: its decoder waits for each
+             * shard's adapter rows when it reaches them (vox_hip_shard_end_push).  The encoder time accounted here is the host's
+             * enqueue time; VOX_MULTI_NO_OVERLAP=1 (A/B) waits for the whole wavefront as round 3 did. */
+            if (getenv("VOX_MULTI_NO_OVERLAP")) vox_hip_sync(s->eng);
             vox_hip_add_encode_ms(s->eng, now_ms() - t0);
+            __atomic_fetch_add(&s->ctx->n_sharded_chunks, 1, __ATOMIC_RELAXED);
             s->mel_cursor += used;
             s->stem_started = 1;
             vox_enc_mirror_chunk(s->ctx, used / 2);

@@ -251,9 +251,29 @@ class Staging:
             self._to_dev()
 
 
-def encode_sharded(eng, comm, padded, n_frames, staging, dst=0, self_loop=False, on_encoded=None):
+def deliver_rows_pipelined(comm, local_rows, counts, dst, consume, empty=None):
+    """Round 4 ("GPU 0 starts decoding while later shards still encode"): every rank's adapter rows go to rank `dst`
+    point to point, in rank order, and `consume(r, rows_r)` runs on `dst` as each block arrives - its own block without any
+    communication.  With dst = 0 (one clip, decoder on rank 0) the decoder is already running on the first shard's ~T/N tokens
+    while ranks 1 .. N-1 are still in their wavefront; their sends wait (on their own streams) until rank 0 posts the receive.
+    No collective: N - 1 point-to-point messages of 12 KB per token over one xGMI link each."""
+    rank, world = comm.rank, comm.world
+    if rank == dst:
+        for r in range(world):
+            if r == rank:
+                consume(r, local_rows)
+            else:
+                t = (empty or comm.empty)((counts[r], local_rows.shape[1]))
+                comm.recv(t, r)
+                consume(r, t)
+    else:
+        comm.wait(comm.isend(local_rows, dst))
+
+
+def encode_sharded(eng, comm, padded, n_frames, staging, dst=0, self_loop=False, on_encoded=None, consume=None):
     """Wavefront context-parallel encode. `staging(shape)` returns a Staging buffer.
-    Returns (gathered adapter rows on rank `dst` | None, per-rank row counts).
+    Returns (gathered adapter rows on rank `dst` | None, per-rank row counts); with `consume` the rows are not gathered by a
+    collective but delivered block by block (deliver_rows_pipelined) and the first element of the result is None.
 
     This function never waits on the host itself: with a stream-ordered engine + RCCL every call below only enqueues
     (tests assert vox_hip_host_syncs does not move between begin() and end()); host-staged transports block inside
@@ -299,7 +319,59 @@ def encode_sharded(eng, comm, padded, n_frames, staging, dst=0, self_loop=False,
     counts = [(b - a) // 4 for a, b in plan]
     if on_encoded:
         on_encoded()
+    if consume is not None:
+        deliver_rows_pipelined(comm, s_ad.tensor, counts, dst, consume)
+        return None, counts
     return comm.gather_rows(s_ad.tensor, counts, dst), counts
+
+
+class _IncrementalDecoder:
+    """Greedy decoder fed with adapter rows block by block (deliver_rows_pipelined): prefill as soon as the prompt's rows are there,
+    then one vox_hip_decoder_run per block over the rows that have arrived.  Same calls, same order of steps as decoding after a
+    complete gather, so the ids are those of the single-GPU run."""
+
+    def __init__(self, session, delay_tokens):
+        self.s, self.prompt_len = session, 1 + LEFT_PAD_TOKENS + delay_tokens
+        self.total, self.pos, self.first, self.out, self.stopped = 0, 0, None, [], False
+        session.v.hip.vox_hip_reset_decoder_kv(session.model.engine)
+
+    def append(self, rows):
+        s = self.s
+        v, h, comm, model = s.v, s.v.hip, s.comm, s.model
+        n = int(rows.shape[0])
+        if n == 0:
+            return
+        if comm.on_gpu:
+            s._keep.append(rows)
+            assert h.vox_hip_adapter_append_dev_async(model.engine, C.c_void_p(rows.data_ptr()), n) == 0
+        else:
+            arr = np.ascontiguousarray(rows.numpy())
+            h.vox_hip_adapter_append(model.engine, arr.ctypes.data_as(v.f32p), n)
+        self.total += n
+        if self.stopped:
+            return
+        if self.first is None:
+            if self.total < self.prompt_len:
+                return
+            self.first = h.vox_hip_decoder_prefill_stream(model.engine, 0, self.prompt_len, 1, 32, None)
+            self.pos = self.prompt_len
+            self.out.append(np.array([self.first], np.int32))
+            if self.first == 2:
+                self.stopped = True
+                return
+        n_steps = self.total - self.pos
+        if n_steps > 0:
+            out = np.zeros(n_steps, np.int32)
+            prev = int(self.out[-1][-1])
+            got = h.vox_hip_decoder_run(model.engine, self.pos, n_steps, prev, 2, out.ctypes.data_as(v.i32p), None)
+            assert got >= 0, h.vox_hip_last_error()
+            self.out.append(out[:got])
+            self.pos += got
+            if got < n_steps:
+                self.stopped = True        # eos
+
+    def tokens(self):
+        return np.concatenate(self.out).astype(np.int32) if self.out else np.zeros(0, np.int32)
 
 
 # ---------------------------------------------------------------------------------------
@@ -391,12 +463,21 @@ class DistributedSession:
         padded, n_frames = padded_stream(audio, delay_tokens)
         self.eng.wavefront_syncs = 0
         self.eng.reset()
+        pipelined = os.environ.get("VOX_DIST_NO_PIPELINE") != "1"      # A/B: the round-3 collective gather, decode after it
         with self.comm.ordered():
             self._mark("start")
-            rows, counts = encode_sharded(self.eng, self.comm, padded, n_frames, self.staging, self_loop=self.self_loop,
-                                          on_encoded=lambda: self._mark("encode"))
-            self._mark("gather")
-            toks = self._decode_rows(rows, delay_tokens) if self.comm.rank == 0 else None
+            if pipelined:
+                dec = _IncrementalDecoder(self, delay_tokens) if self.comm.rank == 0 else None
+                encode_sharded(self.eng, self.comm, padded, n_frames, self.staging, self_loop=self.self_loop,
+                               on_encoded=lambda: self._mark("encode"),
+                               consume=(lambda r, rows: dec.append(rows)) if dec else (lambda r, rows: None))
+                self._mark("gather")
+                toks = dec.tokens() if dec else None
+            else:
+                rows, counts = encode_sharded(self.eng, self.comm, padded, n_frames, self.staging, self_loop=self.self_loop,
+                                              on_encoded=lambda: self._mark("encode"))
+                self._mark("gather")
+                toks = self._decode_rows(rows, delay_tokens) if self.comm.rank == 0 else None
         self._finish_pass()
         return toks
 

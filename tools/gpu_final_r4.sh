@@ -15,7 +15,7 @@ echo "== headline bench (live PMC sub-run, live CPU sample, cold load)"
 timeout 900 python bench.py --steps 10 --warmup 3 --cold-load > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 echo "== rocprofv3 kernel stats of the headline command"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$O/prof" -o r4 -- \
-    python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-pmc > /dev/null 2> "$GRAFT_REPO_ROOT/$O/prof.err" )
+    python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-pmc --no-graph-floor > /dev/null 2> "$GRAFT_REPO_ROOT/$O/prof.err" )
 cp $(find $O/prof -name "r4_kernel_stats.csv" | head -1) $O/kernel_stats.csv 2>/dev/null; head -12 $O/kernel_stats.csv | cut -c1-140
 python tools/trace_summary.py $O/prof --layer-of "k_qkv_finish" --out $O/head_trace_summary.txt > /dev/null 2>&1
 echo "== PMC FETCH_SIZE, decode only"

@@ -2933,6 +2933,53 @@ static int self_test(vox_hip_engine *e) {
                 if (e->use_rowsgemm) fprintf(stderr, "vox_hip: WARNING k_rowsgemm cannot get its LDS (%zu bytes): 33 .. 128-row passes fall back to the planes GEMM / k_skinny\n", (size_t)rg_lds);
                 e->use_rowsgemm = false;
             }
+        // (5) k_rowsgemm against the scalar GEMM (round 4): both activation modes, one 16-row tile / five (the 8-tile accumulator
+        // budget) / two weight tiles per wave, K split over workgroups - the variants decoder prefill, the encoder flush pass and the
+        // small conv / adapter GEMMs run.  The kernel has one straight-line MFMA body per tile count because of a read-after-write
+        // hazard the compiler does not track across branches (vox_rowsgemm.h): a miscompiled variant must not pass silently.
+        if (e->use_rowsgemm && e->use_mfma) {
+            struct { int n, N, K, planes; } cases[] = {{13, 256, 256, 0}, {70, 256, 256, 0}, {40, 4096, 128, 0}, {38, 512, 384, 1}};
+            for (const auto &cs : cases) {
+                const int n = cs.n, N2 = cs.N, K2 = cs.K;
+                std::vector<float> x((size_t)n * K2), yref((size_t)n * N2);
+                std::vector<uint16_t> w((size_t)N2 * K2);
+                for (int m = 0; m < n; m++) for (int k = 0; k < K2; k++) x[(size_t)m * K2 + k] = 0.013f * (float)((m * 5 + k * 7) % 31 - 15) + 0.0007f * m;
+                for (int r = 0; r < N2; r++) for (int k = 0; k < K2; k++) {
+                    const float v = 0.017f * (float)((r * 3 + k * 13) % 19 - 9) - 0.0003f * (r % 64);
+                    uint32_t u; memcpy(&u, &v, 4); w[(size_t)r * K2 + k] = (uint16_t)(u >> 16);
+                }
+                const size_t pbytes = rg_partial_bytes(n, N2, K2);
+                float *tx = nullptr, *ty = nullptr, *tp = nullptr; uint16_t *tw = nullptr, *tpl = nullptr;
+                HC(hipMalloc((void **)&tx, x.size() * 4)); HC(hipMalloc((void **)&ty, yref.size() * 4)); HC(hipMalloc((void **)&tp, pbytes));
+                HC(hipMalloc((void **)&tw, w.size() * 2)); HC(hipMalloc((void **)&tpl, x.size() * 3 * 2));
+                HC(hipMemcpy(tx, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+                HC(hipMemcpy(tw, w.data(), w.size() * 2, hipMemcpyHostToDevice));
+                launch_gemm(e, tx, K2, tw, ty, N2, n, N2, K2, nullptr, nullptr, 0, ACT_NONE, 1);          // scalar reference
+                int S = 0;
+                if (cs.planes) {
+                    hipLaunchKernelGGL(k_split_planes, dim3(grid1d((size_t)n * K2 / 4)), dim3(256), 0, e->stream, tpl, (size_t)n * K2, (const float *)tx, K2, n, K2);
+                    S = launch_rowsgemm(e, tpl, (size_t)n * K2, nullptr, 0, n, tw, N2, K2, tp);
+                } else {
+                    S = launch_rowsgemm(e, nullptr, 0, tx, K2, n, tw, N2, K2, tp);
+                }
+                HC(esync(e));
+                std::vector<float> part((size_t)S * n * N2);
+                HC(hipMemcpy(yref.data(), ty, yref.size() * 4, hipMemcpyDeviceToHost));
+                HC(hipMemcpy(part.data(), tp, part.size() * 4, hipMemcpyDeviceToHost));
+                double worst = 0;
+                for (size_t i = 0; i < yref.size(); i++) {
+                    float v = 0.f;
+                    for (int z = 0; z < S; z++) v += part[(size_t)z * n * N2 + i];
+                    worst = std::max(worst, (double)fabsf(v - yref[i]));
+                }
+                hipFree(tx); hipFree(ty); hipFree(tp); hipFree(tw); hipFree(tpl);
+                if (!(worst < 5e-5)) {
+                    fprintf(stderr, "vox_hip: k_rowsgemm self-test FAILED (n %d, N %d, K %d, %s activations: max diff %g)\n", n, N2, K2, cs.planes ? "plane" : "f32", worst);
+                    e->use_rowsgemm = false; failed++;
+                    break;
+                }
+            }
+        }
         if (getenv("VOX_HIP_NO_ROWSGEMM")) e->use_rowsgemm = false;
         e->rg_small = getenv("VOX_HIP_RG_SMALL") ? 1 : 0;
     }

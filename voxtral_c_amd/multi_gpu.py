@@ -467,6 +467,8 @@ class DistributedSession:
         with self.comm.ordered():
             self._mark("start")
             if pipelined:
+                self._pipelined_pass = True
+                self._t_before = self.model.timing()
                 dec = _IncrementalDecoder(self, delay_tokens) if self.comm.rank == 0 else None
                 encode_sharded(self.eng, self.comm, padded, n_frames, self.staging, self_loop=self.self_loop,
                                on_encoded=lambda: self._mark("encode"),
@@ -486,6 +488,13 @@ class DistributedSession:
         self.comm.sync()
         ph = self._phases_done()
         self.phase_ms = {"encode": ph.get("encode", 0.0), "gather": ph.get("gather", 0.0)}
+        if getattr(self, "_pipelined_pass", False):
+            # the rows were delivered block by block and each block was decoded as it arrived: the interval called "gather" holds the
+            # decoder's work of rank 0 as well - report what is left of it beside the engine's own prefill + decode timers
+            t, t0 = self.model.timing(), self._t_before
+            self.phase_ms["gather_and_decode"] = self.phase_ms["gather"]
+            self.phase_ms["gather"] = max(0.0, self.phase_ms["gather"] - (t["prefill_ms"] - t0["prefill_ms"]) - (t["decode_ms"] - t0["decode_ms"]))
+            self._pipelined_pass = False
         self._free_staging()
 
     def _decode_rows(self, rows, delay_tokens):

@@ -418,6 +418,18 @@ def test_stream_full_size_continuous_restart_matches_reference_golden(vox):
     assert res["ref_steps"] > 2050, res          # i.e. the run did cross kv_cache_len > 2000 and decoded on after it
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "stream_full_stream300.npz")), reason="fixture not generated")
+def test_stream_full_size_config3_300s_matches_reference_golden(vox):
+    """BASELINE config 3 ITSELF at the real 4B geometry: the 30 s night1968 clip tiled to 300 s, 600 feeds of 0.5 s, -I 0.5, continuous
+    mode (the full stream reset after ~160 s included): 3754 decoder steps, 318 distinct ids, every step against the reference's own
+    run of the same feeds (round 4; `bench.py --mode stream` checks its timed pass against the same fixture)."""
+    g = gold("stream_full_stream300.npz")
+    with vox.Model(model_dir("full")) as m:
+        res = check_stream("full_stream300", g, run_case(m, g, 8000, 0.5, True))
+    assert res["ok"], res
+    assert res["ref_steps"] == 3754 and res["n_distinct_ref"] > 300, res
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "stream_full_batch300.npz")), reason="fixture not generated")
 def test_stream_full_size_300s_one_feed_matches_reference_golden(vox):
     """The 300 s line of bench.py at the real 4B geometry: the 30 s night1968 clip tiled to 300 s, ONE feed - a 16 946-position

@@ -190,3 +190,6 @@ def test_bench_picks_the_golden_that_belongs_to_the_audio_length():
     a20, g20, n20, _ = bench.headline_audio(20.0, "stream")
     assert len(a20) == 320000 and n20 == "stream_full_stream.npz" and len(g20["tokens"]) == 261
     assert bench.headline_audio(30.0, "stream")[1] is None          # a one-feed golden is never used for a streamed run
+    if os.path.exists(os.path.join(ROOT, "tests", "golden", "stream_full_stream300.npz")):      # BASELINE config 3 itself
+        a300s, g300s, n300s, _ = bench.headline_audio(300.0, "stream")
+        assert n300s == "stream_full_stream300.npz" and len(g300s["tokens"]) == 3754 and len(a300s) == 300 * 16000

@@ -23,6 +23,7 @@
 // exactly "logical positions max(0,P-W+1)..P" here.
 #pragma once
 #include "vox_common.h"
+#include "vox_gemm.h"
 
 namespace vox {
 
@@ -346,6 +347,251 @@ __global__ __launch_bounds__(256) void k_attn_enc_mfma(const AttnArgs a) {
     }
 
     // ---- finish: the two lane halves hold disjoint keys (same m) and disjoint dims ---------
+    l += __shfl_xor(l, 32, 64);
+    if (!qvalid) return;
+    if (nsplit > 1) {
+        const size_t pidx = ((size_t)qi * a.n_heads + h) * nsplit + blockIdx.z;
+        float *po = a.part_o + pidx * HD;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            const int d = 8 * q4 + 4 * lg;
+            *reinterpret_cast<float4 *>(po + d) = make_float4(o0[4 * q4], o0[4 * q4 + 1], o0[4 * q4 + 2], o0[4 * q4 + 3]);
+            *reinterpret_cast<float4 *>(po + 32 + d) = make_float4(o1[4 * q4], o1[4 * q4 + 1], o1[4 * q4 + 2], o1[4 * q4 + 3]);
+        }
+        if (lg == 0) { a.part_ml[pidx * 2] = m; a.part_ml[pidx * 2 + 1] = l; }
+    } else {
+        float *op = a.out + (size_t)qi * a.ldo + h * HD;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            const int d = 8 * q4 + 4 * lg;
+            *reinterpret_cast<float4 *>(op + d) =
+                make_float4(o0[4 * q4] * inv, o0[4 * q4 + 1] * inv, o0[4 * q4 + 2] * inv, o0[4 * q4 + 3] * inv);
+            *reinterpret_cast<float4 *>(op + 32 + d) =
+                make_float4(o1[4 * q4] * inv, o1[4 * q4 + 1] * inv, o1[4 * q4 + 2] * inv, o1[4 * q4 + 3] * inv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_attn_enc_bf16 (round 4) - the same attention on the bf16 matrix pipe.
+// k_attn_enc_mfma above feeds f32 operands to v_mfma_f32_32x32x2_f32: exact, but that instruction runs at the f32 VECTOR rate
+// (1/16 of the bf16 MFMA rate): 64 of them per 32 x 32 (query, key) tile and wave = 4096 cycles, 34.8 % of that pipe's peak in
+// the 30 s clip's big pass (profiles/r03_pmc_encoder_mfma.json) and the largest single item of the encoder pass (5.8 of 21.7 ms).
+// Here every f32 operand is split EXACTLY into three bf16 terms (hi = trunc16(x), mid = trunc16(x - hi), lo = x - hi - mid:
+// 24 = 3 x 8 significand bits, vox_gemm.h) and a product a . b is the six bf16 MFMAs hh + hm + mh + hl + lh + mm; the dropped
+// terms (ml, lm, ll) are below 2^-24 of the product.  Per tile and wave: 4 k-steps x 6 for S^T = K . Q^T and 2 k-steps x 2 halves
+// x 6 for O^T += V^T . P^T = 48 v_mfma_f32_32x32x16_bf16 = 1536 cycles.
+// Same transposed formulation as above (a lane owns one query: column lane & 31 of both results), same online softmax, same
+// staging (next tile in registers under this tile's math), same partial outputs.  Layout differences:
+//   * K is kept as three bf16 planes [plane][key][64 dims] with 144-byte rows (16 lanes of a ds_read_b128 hit 16 distinct
+//     16-byte slots), V as three transposed planes [plane][dim][32 keys] with 72-byte rows; the split happens on the way into LDS;
+//   * the C layout of S^T hands a lane the keys (r & 3) + 8 (r >> 2) + 4 (lane >> 5); the second product contracts over keys, so
+//     any key order will do as long as both operands use the same one: k-step s takes registers 8 s .. 8 s + 7 as they are
+//     (keys 16 s + 4 lg + {0..3} and 16 s + 8 + 4 lg + {0..3}) and reads V^T at exactly those keys (two 8-byte reads per plane).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void ab_split8(const float (&x)[8], bf16x8_t &h, bf16x8_t &m, bf16x8_t &l) {
+    uint32_t hh[8], mm[8], ll[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) split3(x[i], hh[i], mm[i], ll[i]);
+    union { uint32_t u[4]; bf16x8_t v; } ph, pm, pl;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        ph.u[i] = (hh[2 * i] >> 16) | hh[2 * i + 1];
+        pm.u[i] = (mm[2 * i] >> 16) | mm[2 * i + 1];
+        pl.u[i] = (ll[2 * i] >> 16) | (ll[2 * i + 1] & 0xffff0000u);
+    }
+    h = ph.v; m = pm.v; l = pl.v;
+}
+// c += a . b with a = (ah, am, al), b = (bh, bm, bl): the six terms, small ones first
+__device__ __forceinline__ f32x16 ab_mfma6(const bf16x8_t (&a)[3], const bf16x8_t (&b)[3], f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    return c;
+}
+
+__global__ __launch_bounds__(256) void k_attn_enc_bf16(const AttnArgs a) {
+    constexpr int HD = 64, TK = 32;
+    constexpr int KROW = 144, KPL = TK * KROW;          // bytes per K row / plane
+    constexpr int VROW = 72, VPL = HD * VROW;           // bytes per V^T row / plane
+    __shared__ __attribute__((aligned(16))) unsigned char Kp[3 * KPL];
+    __shared__ __attribute__((aligned(16))) unsigned char Vp[3 * VPL];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lg = lane >> 5;
+    int h = blockIdx.y, qtile = blockIdx.x;
+    if (a.xcd_map && (gridDim.y & 7) == 0) {           // all query tiles of a head on one XCD (see k_attn_enc_mfma)
+        const int lid = blockIdx.x + gridDim.x * blockIdx.y, k = lid >> 3, hpx = gridDim.y >> 3;
+        h = (lid & 7) + 8 * (k % hpx);
+        qtile = k / hpx;
+    }
+    const int q_first = qtile * 128;
+    const int qi = q_first + wave * 32 + li;            // this lane's query
+    const bool qvalid = qi < a.n_q;
+    const int P = a.qpos0 + qi;
+    const int last_key = a.last_key;
+    const int q_last = min(q_first + 127, a.n_q - 1);
+    int blo = a.qpos0 + q_first - a.window + 1; if (blo < 0) blo = 0;
+    int bhi = a.qpos0 + q_last; if (bhi > last_key) bhi = last_key;
+    const int nsplit = gridDim.z;
+    if (nsplit > 1) {
+        const int tiles = (bhi - blo + TK) / TK;
+        const int per = (tiles + nsplit - 1) / nsplit;
+        const int lo2 = blo + (int)blockIdx.z * per * TK;
+        const int hi2 = lo2 + per * TK - 1;
+        blo = lo2;
+        if (hi2 < bhi) bhi = hi2;
+    }
+    int lo_i = P - a.window + 1; if (lo_i < blo) lo_i = blo;
+    int hi_i = P < bhi ? P : bhi;
+    if (!qvalid) { lo_i = 1; hi_i = 0; }
+    const int wq0 = a.qpos0 + q_first + wave * 32;
+    const int w_lo = max(wq0 - a.window + 1, blo), w_hi = min(wq0 + 31, bhi);
+
+    // Q planes of this lane's query: k-step t covers dims 16 t + 8 lg .. + 7 (B operand of S^T = K . Q^T)
+    bf16x8_t qp[4][3];
+    {
+        const float *qsrc = a.q + (size_t)(qvalid ? qi : 0) * a.ldq + h * HD;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(qsrc + 16 * t + 8 * lg);
+            const float4 v1 = *reinterpret_cast<const float4 *>(qsrc + 16 * t + 8 * lg + 4);
+            float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (!qvalid) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = 0.f;
+            }
+            ab_split8(x, qp[t][0], qp[t][1], qp[t][2]);
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = -1e30f, l = 0.f;
+
+    // staging: 32 rows x 16 float4 for K and for V -> 2 + 2 per thread (as k_attn_enc_mfma)
+    float4 rk[2], rv[2];
+    auto load_tile = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int idx = tid + i * 256, r = idx >> 4, c = (idx & 15) * 4;
+            const int pos = t0 + r;
+            float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+            if (pos <= bhi) {
+                if (pos >= a.posB0) {
+                    const size_t off = (size_t)(pos - a.posB0) * a.ldB + h * HD + c;
+                    kk = *reinterpret_cast<const float4 *>(a.kB + off);
+                    vv = *reinterpret_cast<const float4 *>(a.vB + off);
+                } else {
+                    const size_t off = (size_t)(pos % a.capA) * a.ldA + h * HD + c;
+                    kk = *reinterpret_cast<const float4 *>(a.kA + off);
+                    vv = *reinterpret_cast<const float4 *>(a.vA + off);
+                }
+            }
+            rk[i] = kk; rv[i] = vv;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int idx = tid + i * 256, r = idx >> 4, c = (idx & 15) * 4;
+            uint32_t h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+            split3(rk[i].x, h0, m0, l0); split3(rk[i].y, h1, m1, l1); split3(rk[i].z, h2, m2, l2); split3(rk[i].w, h3, m3, l3);
+            unsigned char *kd = Kp + r * KROW + c * 2;
+            *reinterpret_cast<uint2 *>(kd) = make_uint2((h0 >> 16) | h1, (h2 >> 16) | h3);
+            *reinterpret_cast<uint2 *>(kd + KPL) = make_uint2((m0 >> 16) | m1, (m2 >> 16) | m3);
+            *reinterpret_cast<uint2 *>(kd + 2 * KPL) = make_uint2((l0 >> 16) | (l1 & 0xffff0000u), (l2 >> 16) | (l3 & 0xffff0000u));
+            const float vx[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {                 // V transposed: [dim c + e][key r]
+                uint32_t vh, vm, vl;
+                split3(vx[e], vh, vm, vl);
+                unsigned char *vd = Vp + (c + e) * VROW + r * 2;
+                *reinterpret_cast<uint16_t *>(vd) = (uint16_t)(vh >> 16);
+                *reinterpret_cast<uint16_t *>(vd + VPL) = (uint16_t)(vm >> 16);
+                *reinterpret_cast<uint16_t *>(vd + 2 * VPL) = (uint16_t)(vl >> 16);
+            }
+        }
+    };
+
+    if (blo <= bhi) {
+        load_tile(blo);
+        store_tile();
+    }
+    __syncthreads();
+    for (int t0 = blo; t0 <= bhi; t0 += TK) {
+        const bool more = t0 + TK <= bhi;
+        if (more) load_tile(t0 + TK);
+        if (t0 + TK - 1 >= w_lo && t0 <= w_hi) {             // wave-uniform
+            // ---- S^T = K . Q^T: A = K planes (row = key li, dims 16 t + 8 lg ..), B = Q planes ------------------------------
+            f32x16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) sc[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                bf16x8_t kf[3];
+#pragma unroll
+                for (int p = 0; p < 3; p++) kf[p] = *reinterpret_cast<const bf16x8_t *>(Kp + p * KPL + li * KROW + (16 * t + 8 * lg) * 2);
+                sc = ab_mfma6(kf, qp[t], sc);
+            }
+            // ---- online softmax for this lane's query (as k_attn_enc_mfma) ---------------------
+            float mt = -1e30f;
+            bool ok[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int kp = t0 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                ok[r] = (kp >= lo_i) && (kp <= hi_i);
+                sc[r] = sc[r] * a.scale;
+                if (ok[r]) mt = fmaxf(mt, sc[r]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float mn = fmaxf(m, mt);
+            const float corr = expf(m - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float pv = ok[r] ? expf(sc[r] - mn) : 0.f;
+                sc[r] = pv;
+                ps += pv;
+            }
+            l = l * corr + ps;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { o0[r] *= corr; o1[r] *= corr; }
+            // ---- O^T += V^T . P^T: k-step s = registers 8 s .. 8 s + 7 = keys 16 s + 4 lg + {0..3}, 16 s + 8 + 4 lg + {0..3} ----
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                float px[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) px[e] = sc[8 * s2 + e];
+                bf16x8_t pf[3];
+                ab_split8(px, pf[0], pf[1], pf[2]);
+                bf16x8_t v0[3], v1[3];
+#pragma unroll
+                for (int p = 0; p < 3; p++) {
+                    const unsigned char *b0 = Vp + p * VPL + li * VROW + (16 * s2 + 4 * lg) * 2;
+                    const unsigned char *b1 = Vp + p * VPL + (32 + li) * VROW + (16 * s2 + 4 * lg) * 2;
+                    union { uint2 u[2]; bf16x8_t v; } c0, c1;
+                    c0.u[0] = *reinterpret_cast<const uint2 *>(b0); c0.u[1] = *reinterpret_cast<const uint2 *>(b0 + 16);
+                    c1.u[0] = *reinterpret_cast<const uint2 *>(b1); c1.u[1] = *reinterpret_cast<const uint2 *>(b1 + 16);
+                    v0[p] = c0.v; v1[p] = c1.v;
+                }
+                o0 = ab_mfma6(v0, pf, o0);
+                o1 = ab_mfma6(v1, pf, o1);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- finish: the two lane halves hold disjoint keys (same m); O^T rows: dim (r & 3) + 8 (r >> 2) + 4 lg of each half ----
     l += __shfl_xor(l, 32, 64);
     if (!qvalid) return;
     if (nsplit > 1) {

@@ -197,6 +197,7 @@ struct vox_hip_engine {
     bool use_rowsgemm = true;     // 33 .. 128-row chunks (decoder prefill, encoder flush pass) on k_rowsgemm (vox_rowsgemm.h)
     int rg_small = 0;             // A/B (VOX_HIP_RG_SMALL): also run <= 32-row encoder chunks on that path instead of k_skinny
     bool use_dpp = true, use_mfma = true, use_gemv2 = true, use_gemv3 = true, use_splitk = true, use_bf16x3 = true, use_attn_mfma = true;
+    bool use_attn_bf16 = true;    // encoder attention on the bf16 matrix pipe (k_attn_enc_bf16, 6-term exact split) instead of the f32-input MFMA
 
     // weights
     uint16_t *tok_emb = nullptr, *conv0_w = nullptr, *conv1_w = nullptr, *adapter0 = nullptr, *adapter1 = nullptr;
@@ -933,7 +934,8 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
             static const int attn_xcd = getenv("VOX_HIP_ATTN_NO_XCD") ? 0 : 1;
             a.xcd_map = attn_xcd;
             if (e->use_attn_mfma && c.hd == 64 && c.heads == c.kv_heads)
-                hipLaunchKernelGGL(k_attn_enc_mfma, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
+                if (e->use_attn_bf16) hipLaunchKernelGGL(k_attn_enc_bf16, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
+                else hipLaunchKernelGGL(k_attn_enc_mfma, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
             else
                 hipLaunchKernelGGL((k_attn_rows<64>), dim3(qt, c.heads, ks), dim3(128), 0, s, a);
             if (ks > 1)
@@ -1055,7 +1057,8 @@ static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float 
     static const int attn_xcd = getenv("VOX_HIP_ATTN_NO_XCD") ? 0 : 1;
     a.xcd_map = attn_xcd;
     if (e->use_attn_mfma && c.hd == 64 && c.heads == c.kv_heads)
-        hipLaunchKernelGGL(k_attn_enc_mfma, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
+        if (e->use_attn_bf16) hipLaunchKernelGGL(k_attn_enc_bf16, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_attn_enc_mfma, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((k_attn_rows<64>), dim3(qt, c.heads, ks), dim3(128), 0, s, a);
     if (ks > 1)
@@ -2423,7 +2426,8 @@ extern "C" int vox_hip_causal_attention(vox_hip_engine_t *e, float *out, const f
     float *po = nullptr, *pml = nullptr;
     int rc = 0;
     if (head_dim == 64 && e->use_attn_mfma && n_heads == n_kv_heads) {
-        hipLaunchKernelGGL(k_attn_enc_mfma, dim3((seq_q + 127) / 128, n_heads), dim3(256), 0, e->stream, a);
+        if (e->use_attn_bf16) hipLaunchKernelGGL(k_attn_enc_bf16, dim3((seq_q + 127) / 128, n_heads), dim3(256), 0, e->stream, a);
+        else hipLaunchKernelGGL(k_attn_enc_mfma, dim3((seq_q + 127) / 128, n_heads), dim3(256), 0, e->stream, a);
     } else if (head_dim == 64 && n_heads == n_kv_heads) {
         hipLaunchKernelGGL((k_attn_rows<64>), dim3((seq_q + 127) / 128, n_heads), dim3(128), 0, e->stream, a);
     } else if (head_dim == 128 && n_heads == 4 * n_kv_heads) {
@@ -2908,6 +2912,17 @@ static int self_test(vox_hip_engine *e) {
             fprintf(stderr, "vox_hip: MFMA attention self-test FAILED (max diff %g)\n", md);
             e->use_attn_mfma = false; failed++;
         }
+        a.out = do1;
+        hipLaunchKernelGGL(k_attn_enc_bf16, dim3((nq + 127) / 128, nh), dim3(256), 0, e->stream, a);
+        HC(esync(e));
+        HC(hipMemcpy(r1.data(), do1, r1.size() * 4, hipMemcpyDeviceToHost));
+        md = 0;
+        for (size_t i = 0; i < r1.size(); i++) md = std::max(md, (double)fabsf(r1[i] - r2[i]));
+        if (!(md < 1e-4)) {
+            fprintf(stderr, "vox_hip: bf16-split MFMA attention self-test FAILED (max diff %g)\n", md);
+            e->use_attn_bf16 = false; failed++;
+        }
+        if (getenv("VOX_HIP_ATTN_F32")) e->use_attn_bf16 = false;          // A/B: the f32-input MFMA kernel of rounds 1 - 3
         hipFree(dq); hipFree(dk); hipFree(dv); hipFree(do1); hipFree(do2);
         if (getenv("VOX_HIP_NO_ATTN_MFMA")) e->use_attn_mfma = false;
     }

@@ -452,16 +452,17 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     float *sc8 = xs + 2560;                // [4 heads][8 dim slices][64 keys] partial scores, then [4 key quarters][4 heads][128] partial outputs
 
     // ---- hand-off 1 (attention members only): sweep the group's 768 granules ------------------------------------------------
+    // The granule loads go out here; their tags are looked at INSIDE the tile loop's first iteration: everything the compiler hoists in
+    // front of that loop (a few hundred address computations - 0.6 us between "sweep done" and "first tile in" in the round-4 timelines)
+    // then runs while the loads are in flight instead of after them, on the path every workgroup of the group waits for.
+    u64 gv1[2] = {0, 0};
     if (att_block) {
-        u64 gv[2];
-        gv[0] = df_load_granule(gq + tid);
-        if (tid < 256) gv[1] = df_load_granule(gq + 512 + tid);
-        qs[tid] = (unsigned)(gv[0] >> 32) == epoch ? __uint_as_float((unsigned)gv[0]) : df_wait_granule(gq + tid, epoch, a, 1u);
-        if (tid < 256)
-            kvn[tid] = (unsigned)(gv[1] >> 32) == epoch ? __uint_as_float((unsigned)gv[1]) : df_wait_granule(gq + 512 + tid, epoch, a, 1u);
+        gv1[0] = df_load_granule(gq + tid);
+        if (tid < 256) gv1[1] = df_load_granule(gq + 512 + tid);
+    } else {
+        __syncthreads();
+        DF_MARK(6);
     }
-    __syncthreads();
-    DF_MARK(6);
 
     // ---- attention over this workgroup's key slice, 64-key tiles through LDS -------------------------------------------
     //   scores: wave -> (head, half of the 128 dims), lane -> key: a 64-term dot per thread, halves added through LDS;
@@ -476,6 +477,12 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
         for (int ti = 0; ti < n_tiles; ti++) {
             unsigned char *kt = tiles + (ti & 1) * 2 * DF_TILE_BYTES, *vt = kt + DF_TILE_BYTES;
             const int t0 = s_lo + ti * DF_TILE;
+            if (ti == 0) {      // hand-off 1 completes here (see above)
+                qs[tid] = (unsigned)(gv1[0] >> 32) == epoch ? __uint_as_float((unsigned)gv1[0]) : df_wait_granule(gq + tid, epoch, a, 1u);
+                if (tid < 256)
+                    kvn[tid] = (unsigned)(gv1[1] >> 32) == epoch ? __uint_as_float((unsigned)gv1[1]) : df_wait_granule(gq + 512 + tid, epoch, a, 1u);
+                DF_MARK(6);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this tile (and everything older) has landed
             __syncthreads();
             if (ti + 1 < n_tiles)                                    // next tile into the other buffer, under this tile's math
@@ -884,7 +891,7 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
         }
         if (blockIdx.x == 0) *reinterpret_cast<float4 *>(a.x_out + tid * 4) = v;
         float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        ss = wave_sum(ss);
+        ss = df_wave_sum<true>(ss);
         if (lane == 0) red[wave] = ss;
         __syncthreads();
         float tot = 0.f;
@@ -930,7 +937,7 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
-        for (int r = 0; r < 3; r++) acc[m][r] = wave_sum(acc[m][r]);
+        for (int r = 0; r < 3; r++) acc[m][r] = df_wave_sum<true>(acc[m][r]);
     if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < 3; r++) {
@@ -1022,7 +1029,7 @@ __global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
     W2_DOT(2)
 #undef W2_ISSUE
 #undef W2_DOT
-    acc = wave_sum(acc);
+    acc = df_wave_sum<true>(acc);
     if constexpr (W8) acc *= a.s2[row];
     if (lane == 0) a.x[row] = resid + acc;
     if (a.pf_units > 0) {
@@ -1149,7 +1156,7 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
         *reinterpret_cast<float4 *>(stage + tid * 4) = v;          // x' stays in LDS for phase 2 (own elements: no hazard)
         if (blockIdx.x == 0 && a.xprime_out) *reinterpret_cast<float4 *>(a.xprime_out + tid * 4) = v;
         float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        ss = wave_sum(ss);
+        ss = df_wave_sum<true>(ss);
         if (lane == 0) red[wave] = ss;
         __syncthreads();
         float tot = 0.f;
@@ -1194,9 +1201,23 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
     uint4 w2r[NP2];
     const int row = blockIdx.x * 12 + wave;
     const uint4 *wp = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.w2) + (size_t)row * (W8 ? FFN_H : 2 * FFN_H)) + lane;
+    // bf16 (round 4, "K-sliced waves"): wave w does not take ONE row of the workgroup's 12 but columns 768 w .. 768 w + 767 of ALL of
+    // them.  Its 12 x 768 weights are 18 loads of 64 lanes x 8: load 3m = row 2m, columns 0..511 of the slice; load 3m+1 = row 2m,
+    // columns 512..767 (lanes 0-31) and row 2m+1, columns 0..255 (lanes 32-63); load 3m+2 = row 2m+1, columns 256..767.  The 768 h
+    // values a wave needs are exactly the 12 granules per lane of its share of the sweep: they go through a 3 KB LDS slice only this
+    // wave touches (no workgroup barrier), and a lane reads 24 of them once for all rows.  With one row per wave every wave read the
+    // whole h vector from LDS - 12 x 36 KB per workgroup, 1.6 of the 1.8 us between "h swept" and "done" in the round-4 timeline.
+    const unsigned char *w2s = reinterpret_cast<const unsigned char *>(a.w2) + ((size_t)blockIdx.x * 12 * FFN_H + 768 * wave) * 2;
+    auto w2ptr = [&](int c) -> const uint4 * {
+        if constexpr (W8) return wp + c * 64;
+        const int m = c / 3, k = c - 3 * m;
+        const int r = k == 0 ? 2 * m : k == 2 ? 2 * m + 1 : 2 * m + (lane >> 5);
+        const int col = k == 0 ? 8 * lane : k == 2 ? 256 + 8 * lane : (lane < 32 ? 512 + 8 * lane : 8 * (lane - 32));
+        return reinterpret_cast<const uint4 *>(w2s + ((size_t)r * FFN_H + col) * 2);
+    };
     constexpr int NEARLY = SCHED == 1 ? NP2 : 0;     // W2 pieces queued before the workgroup barrier
 #pragma unroll
-    for (int c = 0; c < NEARLY; c++) w2r[c] = ld_stream(wp + c * 64);
+    for (int c = 0; c < NEARLY; c++) w2r[c] = ld_stream(w2ptr(c));
     __builtin_amdgcn_sched_barrier(0);
     FFN_DOT(4) FFN_DOT(5)
 #undef FFN_ISSUE
@@ -1204,7 +1225,7 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
-        for (int r = 0; r < 3; r++) acc[m][r] = wave_sum(acc[m][r]);
+        for (int r = 0; r < 3; r++) acc[m][r] = df_wave_sum<true>(acc[m][r]);
     if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < 3; r++) {
@@ -1221,7 +1242,7 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
     constexpr int NBEFORE = SCHED == 3 ? (NP2 * 2) / 3 : NP2;
     if constexpr (SCHED >= 2) {      // schedule B: nothing of phase 2 is queued before the whole workgroup has finished phase 1
 #pragma unroll
-        for (int c = 0; c < NBEFORE; c++) w2r[c] = ld_stream(wp + c * 64);
+        for (int c = 0; c < NBEFORE; c++) w2r[c] = ld_stream(w2ptr(c));
         __builtin_amdgcn_sched_barrier(0);
     }
     FFN_MARK(5);
@@ -1229,7 +1250,7 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
         u64 gv[12];
         int gi[12];
 #pragma unroll
-        for (int u = 0; u < 12; u++) gi[u] = u * FFN_THREADS + tid;
+        for (int u = 0; u < 12; u++) gi[u] = W8 ? u * FFN_THREADS + tid : 768 * wave + 64 * u + lane;      // bf16: this wave's own slice of h
         // First attempt in straight-line code (inside a loop the compiler merges the wait counts of "W2 rows queued" and "not queued" and
         // waits for the whole W2 row before it looks at the first tag); the retry loop is entered only if a tag was stale.
 #pragma unroll
@@ -1237,9 +1258,10 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
         if constexpr (SCHED == 3) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = NBEFORE; c < NP2; c++) w2r[c] = ld_stream(wp + c * 64);
+            for (int c = NBEFORE; c < NP2; c++) w2r[c] = ld_stream(w2ptr(c));
             __builtin_amdgcn_sched_barrier(0);
         }
+
         bool ok = true;
 #pragma unroll
         for (int u = 0; u < 12; u++) ok = ok && (unsigned)(gv[u] >> 32) == a.epoch;
@@ -1260,6 +1282,41 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
 #pragma unroll
         for (int u = 0; u < 12; u++) hs[gi[u]] = __uint_as_float((unsigned)gv[u]);
     }
+    if constexpr (!W8) {
+        // ---- phase 2, K-sliced: partial sums of all 12 rows over this wave's 768 columns --------------------------------------------
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the slice is written and read by this wave only: LDS operations of
+        __builtin_amdgcn_wave_barrier();                            // one wave execute in order, no workgroup barrier
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        FFN_MARK(6);
+        const float *hw = hs + 768 * wave;
+        const int cb = lane < 32 ? 512 + 8 * lane : 8 * (lane - 32);
+        const float4 hA0 = *reinterpret_cast<const float4 *>(hw + 8 * lane), hA1 = *reinterpret_cast<const float4 *>(hw + 8 * lane + 4);
+        const float4 hB0 = *reinterpret_cast<const float4 *>(hw + cb), hB1 = *reinterpret_cast<const float4 *>(hw + cb + 4);
+        const float4 hC0 = *reinterpret_cast<const float4 *>(hw + 256 + 8 * lane), hC1 = *reinterpret_cast<const float4 *>(hw + 256 + 8 * lane + 4);
+        float *part = xs;                    // [12 waves][12 rows] (the normalised x' is dead)
+        float rs[12];
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+            const float p0 = dot8_bf16(w2r[3 * m], hA0, hA1, 0.f);
+            const float p1 = dot8_bf16(w2r[3 * m + 1], hB0, hB1, 0.f);
+            const float p2 = dot8_bf16(w2r[3 * m + 2], hC0, hC1, 0.f);
+            rs[2 * m] = df_wave_sum<true>(p0 + (lane < 32 ? p1 : 0.f));
+            rs[2 * m + 1] = df_wave_sum<true>(p2 + (lane < 32 ? 0.f : p1));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int r4 = 0; r4 < 3; r4++)
+                *reinterpret_cast<float4 *>(part + wave * 12 + 4 * r4) = make_float4(rs[4 * r4], rs[4 * r4 + 1], rs[4 * r4 + 2], rs[4 * r4 + 3]);
+        }
+        __syncthreads();
+        if (tid < 12) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w12 = 0; w12 < 12; w12++) sum += part[w12 * 12 + tid];         // fixed order
+            const int orow = blockIdx.x * 12 + tid;
+            a.x_out[orow] = stage[orow] + sum;
+        }
+    } else {
     __syncthreads();
     FFN_MARK(6);
 
@@ -1280,9 +1337,10 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
                 acc2 = dot8_bf16(w2r[c], x0, x1, acc2);
             }
         }
-        acc2 = wave_sum(acc2);
+        acc2 = df_wave_sum<true>(acc2);
         if constexpr (W8) acc2 *= a.s2[row];
         if (lane == 0) a.x_out[row] = stage[row] + acc2;
+    }
     }
     FFN_MARK(7);
 #undef FFN_MARK

@@ -1879,7 +1879,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     const int nsplit = (kv_len + split_keys - 1) / split_keys;
     const bool fuse_combine = fast && nsplit <= 8;
     const float scale = 1.0f / sqrtf((float)HD);
-    const bool fused = fast && e->use_fused;          // fp8 mode: qkv / wo stay on the bf16 matrices (k_dec_attn_fused), w1;w3 and w2 stream the fp8 copies
+    const bool fused = fast && e->use_fused && e->use_dpp;      // the FFN kernels reduce with DPP row sums (self-tested at start-up).  fp8 mode: qkv / wo stay on the bf16 matrices (k_dec_attn_fused), w1;w3 and w2 stream the fp8 copies
     // fused path: key slices of the attention stage (<= 32 per KV head, multiples of 64 keys)
     int f_split = 64, f_ns = 1;
     if (fused) {
@@ -3027,10 +3027,10 @@ extern "C" unsigned vox_hip_active_paths(const vox_hip_engine_t *e) {
     if (e->use_splitk) m |= VOX_PATH_GEMM_SPLITK;
     if (fast_geom && e->use_gemv2 && e->use_gemv3) m |= VOX_PATH_GEMV3;
     if (e->use_fp8) m |= VOX_PATH_FP8_DECODE;
-    if (fast_geom && e->use_fused) m |= VOX_PATH_DEC_FUSED;
+    if (fast_geom && e->use_fused && e->use_dpp) m |= VOX_PATH_DEC_FUSED;
     if (e->use_skinny && e->use_mfma) m |= VOX_PATH_SKINNY_ENC;
     if (e->use_planes && e->use_mfma && e->use_bf16x3) m |= VOX_PATH_GEMM_PLANES;
-    if (fast_geom && e->use_fused && e->use_ffn && !e->use_fp8) m |= VOX_PATH_FFN_FUSED;
+    if (fast_geom && e->use_fused && e->use_dpp && e->use_ffn && !e->use_fp8) m |= VOX_PATH_FFN_FUSED;
     if (e->use_rowsgemm && e->use_mfma) m |= VOX_PATH_ROWSGEMM;
     return m;
 }

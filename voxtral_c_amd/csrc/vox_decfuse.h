@@ -819,18 +819,13 @@ struct W13xArgs {
     float *h;                  // [9216]
     unsigned long long *trace; // optional (tuning): [2 blocks][16] stamps, written at +32
     unsigned long long *tl;    // optional (tuning): per-workgroup timeline
-    // Round 4 (A/B): a wave that is done EARLY (before pf_gate wall-clock ticks after its entry) pulls the first pf_units KiB of the
-    // row the same wave of the next launch's block (k_gemv_w2x: row 12 b + wave) will stream into this XCD's L2; late waves do not.
-    const unsigned char *pf_w; int pf_row_bytes, pf_units; unsigned pf_gate;
 };
 constexpr int W13X_THREADS = 768;
 constexpr int W13X_LDS_BYTES = (9 + 2 + 1) * DF_D * 4 + 256;
 
-// EARLY (round 4, A/B): when round 1 of the weight stream is issued.  0 = after the prologue's arithmetic (round 3): the timeline
-// shows round 0 (37 MB chip-wide) landed ~0.5 us before that point and round 1's first bytes ~1 us after it - a bubble of more
-// than a microsecond in an otherwise full pipe.  1 = right behind the barrier that releases the prologue (its sum / RMSNorm then
-// run under round 1's latency); 2 = together with round 0, in front of that barrier.
-template <bool W8, int EARLY = 0>
+// (Round 4, measured and removed: issuing round 1 of the weight stream earlier - right behind the prologue barrier or together with
+// round 0 - and an L2 prefetch of the W2 launch's first bytes by waves that finish early: no gain, profiles/NOTES.md.)
+template <bool W8>
 __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *stage = smem;                 // [9][3072]: x, wo_part[0..7]
@@ -843,7 +838,6 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
     const unsigned wofs = (unsigned)wave * 1024u;        // 12 waves x 1 KiB = one 12 KB vector per DMA round
     unsigned long long df_stamp[6] = {0, 0, 0, 0, 0, 0};
     const unsigned long long tl0 = tl_begin(a.tl);
-    const unsigned long long pf_t0 = a.pf_units > 0 ? wall_clock64() : 0ull;
     DF_MARK(0);
 
     glds16(a.x + tid * 4, lds_addr(stage) + wofs);
@@ -872,16 +866,11 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
     if constexpr ((C) < NP) { _Pragma("unroll") for (int r = 0; r < 3; r++) w[0][r][(C) < NP ? (C) : 0] = ld_stream(p1[r] + (C) * 64); \
       _Pragma("unroll") for (int r = 0; r < 3; r++) w[1][r][(C) < NP ? (C) : 0] = ld_stream(p3[r] + (C) * 64); }
     W13_ISSUE(0) W13_ISSUE(1)
-    if constexpr (EARLY == 2) { W13_ISSUE(2) W13_ISSUE(3) }
     __builtin_amdgcn_sched_barrier(0);
     DF_MARK(1);
-    // the 11 DMAs are in; round 0 (EARLY 2: and round 1) of the weights still streams
-    if constexpr (EARLY == 2 && !W8) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if constexpr (EARLY == 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // the 11 DMAs are in; round 0 of the weights still streams
     __syncthreads();
     DF_MARK(2);
-    if constexpr (EARLY == 1) { W13_ISSUE(2) W13_ISSUE(3) __builtin_amdgcn_sched_barrier(0); }
     {
         float4 v = *reinterpret_cast<const float4 *>(stage + tid * 4);
 #pragma unroll
@@ -923,7 +912,7 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
                 _Pragma("unroll") for (int r = 0; r < 3; r++) acc[m][r] = dot8_bf16(w[m][r][CC], x0, x1, acc[m][r]); \
         }                                                                               \
     }
-    if constexpr (EARLY == 0) { W13_ISSUE(2) W13_ISSUE(3) }
+    W13_ISSUE(2) W13_ISSUE(3)
     __builtin_amdgcn_sched_barrier(0);
     W13_DOT(0) W13_DOT(1)
     __builtin_amdgcn_sched_barrier(0);
@@ -945,13 +934,6 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
             if constexpr (W8) { g *= a.s1[pair0 + r]; u *= a.s3[pair0 + r]; }          // per-row dequantisation scale
             a.h[pair0 + r] = silu(g) * u;                                               // voxtral_decoder.c:684-687
         }
-    }
-    if (a.pf_units > 0) {
-        if ((unsigned)(wall_clock64() - pf_t0) < a.pf_gate) {
-            const unsigned char *src = a.pf_w + (size_t)(blockIdx.x * 12 + wave) * (size_t)a.pf_row_bytes + lane * 16;
-            for (int u = 0; u < a.pf_units; u++) glds16(src + u * 1024, lds_addr(stage) + wofs);      // the prologue vectors are dead
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     DF_MARK(4);
     if (a.trace && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 255)) {
@@ -975,12 +957,9 @@ struct W2xArgs {
     const float *h;            // [9216]
     float *x;                  // [3072] residual stream, updated in place (every row is read and written by its one wave)
     unsigned long long *tl;    // optional (tuning): per-workgroup timeline
-    // Round 4 (A/B): early waves 0..7 pull the first pf_units KiB of the three projection rows wave w of the NEXT layer's
-    // k_dec_attn_fused block b will stream (same row formula, group = b % 8) into this XCD's L2.
-    const unsigned char *pf_w; int pf_units; unsigned pf_gate;
 };
 constexpr int W2X_THREADS = 768, W2X_K = 9216;
-constexpr int W2X_LDS_BYTES = W2X_K * 4 + 64 + 12 * 1024;     // h, pad, one 1 KiB prefetch scratch slot per wave
+constexpr int W2X_LDS_BYTES = W2X_K * 4 + 64;
 
 template <bool W8>
 __global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
@@ -990,7 +969,6 @@ __global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned wofs = (unsigned)wave * 1024u;
     const unsigned long long tl0 = tl_begin(a.tl);
-    const unsigned long long pf_t0 = a.pf_units > 0 ? wall_clock64() : 0ull;
     const int row = blockIdx.x * 12 + wave;
     const float resid = a.x[row];
 #pragma unroll
@@ -1032,26 +1010,11 @@ __global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
     acc = df_wave_sum<true>(acc);
     if constexpr (W8) acc *= a.s2[row];
     if (lane == 0) a.x[row] = resid + acc;
-    if (a.pf_units > 0) {
-        if (wave < DF_WAVES && (unsigned)(wall_clock64() - pf_t0) < a.pf_gate) {
-            const int g = blockIdx.x % DF_GROUPS, j = blockIdx.x / DF_GROUPS;
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const int lr = 3 * wave + i;
-                const int prow = lr < 16 ? DF_NQ * g + 16 * j + lr
-                               : lr < 20 ? DF_DQ + DF_HD * g + 4 * j + (lr - 16)
-                                         : DF_DQ + DF_DKV + DF_HD * g + 4 * j + (lr - 20);
-                const unsigned char *src = a.pf_w + (size_t)prow * (DF_D * 2) + lane * 16;
-                for (int u = 0; u < a.pf_units; u++) glds16(src + u * 1024, lds_addr(smem + W2X_K + 16) + wofs);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
     tl_end(a.tl, tl0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_ffn_fused (round 4) - the whole FFN block of a decoder step as ONE launch:
+// k_ffn_fused (round 4) - the whole FFN block of a decoder step as ONE launch (bf16 weights):
 //     x' = x + sum_g wo_part[g] -> ffn_norm, ada -> h = silu(W1 x) * (W3 x)   |hand-off|   x'' = x' + W2 h
 // (voxtral_decoder.c:676-690; replaces k_gemv_w13x + k_gemv_w2x: 20.7 + 10.7 us per layer, of which one kernel boundary, one
 // start-up ramp and one drain - ~3 us - move no weight byte).
@@ -1059,22 +1022,42 @@ __global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
 // Why this hand-off can be free where the others were not (a hand-off under a full-rate stream costs what a kernel
 // boundary costs, because a load issued into a saturated memory system returns behind everything queued before it): here that
 // property is used, not fought.  A wave that has finished its three row pairs of W1 / W3 publishes its three h values as
-// {epoch, value} granules (one write-through store each) and AT ONCE queues its whole row of W2 (18 KB, registers: the W1 / W3
-// registers are dead) - the weight stream never stops at the phase edge.  Once all 12 waves of the workgroup are there, every
-// thread queues its 12 granule loads of the h sweep BEHIND the W2 rows.  They come back when the W2 rows have landed, ~9 us
-// later, and every producer on the chip published its h long before that (the workgroups of a launch finish their first phase
-// within ~3 us of each other): the sweep normally needs no retry, and its round trip is hidden behind bytes that had to be
-// streamed anyway.  What remains exposed is the tail: tags checked, h to LDS, one barrier, 18 x 8 FMAs per lane, wave
-// reduction, 12 stores per workgroup.
+// {epoch, value} granules (one write-through store each).  Once all 12 waves of the workgroup are there, every wave queues its
+// 18 KB of W2 (registers: the W1 / W3 registers are dead) and, BEHIND them, its 12 granule loads per lane of the h sweep.  They
+// come back when the W2 bytes have landed, ~7 us later, and every producer on the chip published its h long before that (the
+// workgroups of a launch finish their first phase within ~3 us of each other): the sweep normally needs no retry, and its round
+// trip is hidden behind bytes that had to be streamed anyway.
+//
+// The W2 stage is K-SLICED over the waves: wave w does not take ONE row of the workgroup's 12 but columns 768 w .. 768 w + 767 of
+// ALL of them.  Its 12 x 768 weights are 18 loads of 64 lanes x 8: load 3m = row 2m, columns 0..511 of the slice; load 3m+1 =
+// row 2m, columns 512..767 (lanes 0-31) and row 2m+1, columns 0..255 (lanes 32-63); load 3m+2 = row 2m+1, columns 256..767.  The
+// 768 h values a wave needs are exactly the 12 granules per lane of its share of the sweep: they go through a 3 KB LDS slice only
+// this wave touches (no workgroup barrier), and a lane reads 24 of them once for all rows.  (With one row per wave every wave
+// read the whole h vector from LDS - 12 x 36 KB per workgroup, 1.6 of the 1.8 us that used to follow the sweep.)  What remains
+// exposed after the stream: tags checked, 18 x 8 FMAs per lane, 12 DPP row sums, one barrier, 12 stores per workgroup.
+//
+// Hand-off schedules that were built and measured (ms per step at 232 / 1900 keys, one box, alternating runs; two launches:
+// 1.3872 / 1.5689; this one, "B": 1.3662 / 1.5539 before the K-slicing):
+//   A  early waves queue their W2 bytes at once, workgroup barrier, sweep: 1.4436 / 1.6373 - the early W2 loads delay the late
+//      waves' last W1 / W3 pieces, and the sweep behind the barrier has nothing left to hide behind: 5.6 us, which is what a
+//      72 KB all-to-all granule sweep costs on this chip;
+//   B' B with the sweep behind the first two thirds of the W2 bytes: no gain;
+//   C  no barrier, wave w sweeps the granules of the waves w of all workgroups right behind its own W2 bytes (1.82 / 2.01: early
+//      sweeps find stale tags, every retry queues behind the CU's whole stream and 3072 polling waves take bandwidth from it);
+//   E  the sweep IN FRONT of the W2 bytes so that the dot products run piece by piece under the stream (1.3988 / 1.5908: the sweep
+//      still takes its ~6 us, now in front of everything, and slows the loads it shares the queue with); D+E: 1.4165 / 1.6006;
+//   fp8 weights: with half the W2 bytes the sweep is no longer hidden (1.1055 against 1.0271 ms on two launches): fp8 keeps
+//      k_gemv_w13x<true> + k_gemv_w2x<true>;
+//   "projection ahead": the FOLLOWING layer's attention_norm -> wq / wk / wv -> RoPE at the end of this launch (+0.18 ms per step:
+//      a CU's stores leave through the same queue as its loads, so the x'' hand-off published behind the projection rows was
+//      visible only when they had landed; profiles/r04_qkv_ahead_timeline.txt, the code is profiles/r04_qkv_ahead.patch).
 //
 // Needs its 256 workgroups co-resident (one per CU) like k_dec_attn_fused: every wait is bounded, a time-out sets *err and the
 // host re-runs the batch on the launch-per-GEMV chain.  The epoch is the launch counter of the layer's attention launch.
 // ---------------------------------------------------------------------------------------------------------
 struct FfnArgs {
-    const uint16_t *w1, *w3;   // [9216][3072] each (W8: fp8 e4m3 bytes, one f32 scale per row in s1 / s3)
-    const float *s1, *s3;
-    const uint16_t *w2;        // [3072][9216] (W8: fp8 bytes, scales s2)
-    const float *s2;
+    const uint16_t *w1, *w3;   // [9216][3072] bf16 each
+    const uint16_t *w2;        // [3072][9216] bf16
     const float *x;            // [3072] residual stream before the attention block's output is added
     const float *wo_part;      // [8][3072]
     const float *norm_w, *ada; // [3072]
@@ -1090,28 +1073,14 @@ struct FfnArgs {
 constexpr int FFN_THREADS = 768, FFN_H = 9216;
 constexpr int FFN_LDS_BYTES = W13X_LDS_BYTES;       // phase 2 reuses the prologue's staging area: x' (12 KB) + h (36 KB)
 
-// SCHED = the hand-off schedule (compile time: a run-time branch around register loads made the compiler spill).  Measured on one box,
-// alternating runs, ms per step at 232 / 1900 keys (gpurun_out/r4j; two launches: 1.3872 / 1.5689):
-//   2 (B, the default)  nothing of phase 2 is queued before the whole workgroup has finished phase 1; then the W2 rows, then the sweep
-//          behind them: 1.3662 / 1.5539.  Timeline: workgroup barrier at +18.0 us, sweep back at +25.2 (the 216 KB of W2 rows per CU
-//          landed in 7.2 us), done at +27.0: the 72 KB sweep costs nothing, the dot products at the end cost 1.8 us.
-//   1 (A)  early waves queue their W2 row at once (the stream never drains), workgroup barrier, sweep: 1.4436 / 1.6373 - the early
-//          W2 rows delay the late waves' last W1 / W3 pieces (barrier at +23.7 us), and the sweep behind the barrier has nothing
-//          left to hide behind: 5.6 us, which is what a 72 KB all-to-all granule sweep costs on this chip.
-// Built, measured and removed: C - no barrier, wave w sweeps the granules of the waves w of all workgroups right behind its own W2
-// row (1.82 / 2.01: early sweeps find stale tags, every retry queues behind the CU's whole stream and 3072 polling waves take
-// bandwidth from it); E - the sweep IN FRONT of the W2 rows so that the dot products run piece by piece under the stream
-// (1.3988 / 1.5908: the sweep still takes its ~6 us, now in front of everything, and slows the rows it shares the queue with);
-// D+E - E with a third of the W2 row queued before the barrier (1.4165 / 1.6006).
-template <bool W8, int SCHED = 1>
 __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *stage = smem;                 // [9][3072]: x, wo_part[0..7]; after the prologue: row 0 = x', rows 1..3 = h
     float *nws = smem + 9 * DF_D;        // [3072] norm weights
     float *ads = nws + DF_D;             // [3072] ada
-    float *xs = ads + DF_D;              // [3072]
+    float *xs = ads + DF_D;              // [3072] normalised x'; phase 2: [12 waves][12 rows] partial sums
     float *red = xs + DF_D;              // [16]
-    float *hs = stage + DF_D;            // [9216] h (phase 2)
+    float *hs = stage + DF_D;            // [9216] h (phase 2), wave w owns [768 w, 768 w + 768)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned wofs = (unsigned)wave * 1024u;
@@ -1120,26 +1089,24 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
 #define FFN_MARK(k) do { if (a.tl) df_stamp[k] = wall_clock64(); } while (0)
     FFN_MARK(0);
 
-    // ---- phase 1: exactly k_gemv_w13x (same memory-queue order, same arithmetic) ------------------------------------------
+    // ---- phase 1: exactly k_gemv_w13x<false> (same memory-queue order, same arithmetic) --------------------------------------
     glds16(a.x + tid * 4, lds_addr(stage) + wofs);
 #pragma unroll
     for (int gi = 0; gi < 8; gi++) glds16(a.wo_part + (size_t)gi * DF_D + tid * 4, lds_addr(stage + (gi + 1) * DF_D) + wofs);
     glds16(a.norm_w + tid * 4, lds_addr(nws) + wofs);
     glds16(a.ada + tid * 4, lds_addr(ads) + wofs);
     __builtin_amdgcn_sched_barrier(0);
-    constexpr int NP = W8 ? 3 : 6, EPP = W8 ? 16 : 8;
-    uint4 w[2][3][NP];
+    uint4 w[2][3][6];
     const int pair0 = blockIdx.x * 36 + wave * 3;
     const uint4 *p1[3], *p3[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        constexpr size_t ROWB = W8 ? DF_D : 2 * DF_D;
-        p1[r] = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.w1) + (size_t)(pair0 + r) * ROWB) + lane;
-        p3[r] = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.w3) + (size_t)(pair0 + r) * ROWB) + lane;
+        p1[r] = reinterpret_cast<const uint4 *>(a.w1 + (size_t)(pair0 + r) * DF_D) + lane;
+        p3[r] = reinterpret_cast<const uint4 *>(a.w3 + (size_t)(pair0 + r) * DF_D) + lane;
     }
 #define FFN_ISSUE(C)                                                                    \
-    if constexpr ((C) < NP) { _Pragma("unroll") for (int r = 0; r < 3; r++) w[0][r][(C) < NP ? (C) : 0] = ld_stream(p1[r] + (C) * 64); \
-      _Pragma("unroll") for (int r = 0; r < 3; r++) w[1][r][(C) < NP ? (C) : 0] = ld_stream(p3[r] + (C) * 64); }
+    { _Pragma("unroll") for (int r = 0; r < 3; r++) w[0][r][C] = ld_stream(p1[r] + (C) * 64); \
+      _Pragma("unroll") for (int r = 0; r < 3; r++) w[1][r][C] = ld_stream(p3[r] + (C) * 64); }
     FFN_ISSUE(0) FFN_ISSUE(1)
     __builtin_amdgcn_sched_barrier(0);
     FFN_MARK(1);
@@ -1173,21 +1140,10 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
     FFN_MARK(3);
     float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 #define FFN_DOT(C)                                                                      \
-    if constexpr ((C) < NP) {                                                           \
-        constexpr int CC = (C) < NP ? (C) : 0;                                          \
-        const float *xp = xs + (CC * 64 + lane) * EPP;                                  \
-        const float4 x0 = *reinterpret_cast<const float4 *>(xp);                        \
-        const float4 x1 = *reinterpret_cast<const float4 *>(xp + 4);                    \
-        if constexpr (W8) {                                                             \
-            const float4 x2 = *reinterpret_cast<const float4 *>(xp + 8);                \
-            const float4 x3 = *reinterpret_cast<const float4 *>(xp + 12);               \
-            _Pragma("unroll") for (int m = 0; m < 2; m++)                               \
-                _Pragma("unroll") for (int r = 0; r < 3; r++) acc[m][r] = dot16_fp8(w[m][r][CC], x0, x1, x2, x3, acc[m][r]); \
-        } else {                                                                        \
-            _Pragma("unroll") for (int m = 0; m < 2; m++)                               \
-                _Pragma("unroll") for (int r = 0; r < 3; r++) acc[m][r] = dot8_bf16(w[m][r][CC], x0, x1, acc[m][r]); \
-        }                                                                               \
-    }
+    {   const float4 x0 = *reinterpret_cast<const float4 *>(xs + ((C) * 64 + lane) * 8);          \
+        const float4 x1 = *reinterpret_cast<const float4 *>(xs + ((C) * 64 + lane) * 8 + 4);      \
+        _Pragma("unroll") for (int m = 0; m < 2; m++)                                   \
+            _Pragma("unroll") for (int r = 0; r < 3; r++) acc[m][r] = dot8_bf16(w[m][r][C], x0, x1, acc[m][r]); }
     FFN_ISSUE(2) FFN_ISSUE(3)
     __builtin_amdgcn_sched_barrier(0);
     FFN_DOT(0) FFN_DOT(1)
@@ -1195,29 +1151,6 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
     FFN_ISSUE(4) FFN_ISSUE(5)
     __builtin_amdgcn_sched_barrier(0);
     FFN_DOT(2) FFN_DOT(3)
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- the phase edge: this wave's row of W2 goes into the queue before its last dot products, so the stream never drains -----
-    constexpr int NP2 = W8 ? 9 : 18;
-    uint4 w2r[NP2];
-    const int row = blockIdx.x * 12 + wave;
-    const uint4 *wp = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(a.w2) + (size_t)row * (W8 ? FFN_H : 2 * FFN_H)) + lane;
-    // bf16 (round 4, "K-sliced waves"): wave w does not take ONE row of the workgroup's 12 but columns 768 w .. 768 w + 767 of ALL of
-    // them.  Its 12 x 768 weights are 18 loads of 64 lanes x 8: load 3m = row 2m, columns 0..511 of the slice; load 3m+1 = row 2m,
-    // columns 512..767 (lanes 0-31) and row 2m+1, columns 0..255 (lanes 32-63); load 3m+2 = row 2m+1, columns 256..767.  The 768 h
-    // values a wave needs are exactly the 12 granules per lane of its share of the sweep: they go through a 3 KB LDS slice only this
-    // wave touches (no workgroup barrier), and a lane reads 24 of them once for all rows.  With one row per wave every wave read the
-    // whole h vector from LDS - 12 x 36 KB per workgroup, 1.6 of the 1.8 us between "h swept" and "done" in the round-4 timeline.
-    const unsigned char *w2s = reinterpret_cast<const unsigned char *>(a.w2) + ((size_t)blockIdx.x * 12 * FFN_H + 768 * wave) * 2;
-    auto w2ptr = [&](int c) -> const uint4 * {
-        if constexpr (W8) return wp + c * 64;
-        const int m = c / 3, k = c - 3 * m;
-        const int r = k == 0 ? 2 * m : k == 2 ? 2 * m + 1 : 2 * m + (lane >> 5);
-        const int col = k == 0 ? 8 * lane : k == 2 ? 256 + 8 * lane : (lane < 32 ? 512 + 8 * lane : 8 * (lane - 32));
-        return reinterpret_cast<const uint4 *>(w2s + ((size_t)r * FFN_H + col) * 2);
-    };
-    constexpr int NEARLY = SCHED == 1 ? NP2 : 0;     // W2 pieces queued before the workgroup barrier
-#pragma unroll
-    for (int c = 0; c < NEARLY; c++) w2r[c] = ld_stream(w2ptr(c));
     __builtin_amdgcn_sched_barrier(0);
     FFN_DOT(4) FFN_DOT(5)
 #undef FFN_ISSUE
@@ -1228,40 +1161,31 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
         for (int r = 0; r < 3; r++) acc[m][r] = df_wave_sum<true>(acc[m][r]);
     if (lane == 0) {
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            float g = acc[0][r], u = acc[1][r];
-            if constexpr (W8) { g *= a.s1[pair0 + r]; u *= a.s3[pair0 + r]; }
-            df_store_granule(a.gh + pair0 + r, a.epoch, silu(g) * u);                   // voxtral_decoder.c:684-687
-        }
+        for (int r = 0; r < 3; r++) df_store_granule(a.gh + pair0 + r, a.epoch, silu(acc[0][r]) * acc[1][r]);      // voxtral_decoder.c:684-687
     }
     FFN_MARK(4);
-    // ---- hand-off: workgroup barrier (stage rows 1..8 are dead from here), W2 rows, then every thread's 12 granules behind them ----
+    // ---- the phase edge: workgroup barrier (stage rows 1..8 are dead from here), this wave's W2 bytes, its share of the sweep behind them
     __syncthreads();
-    // SCHED 3 = B with the sweep behind the first two thirds of the W2 row instead of all of it: h is in LDS while the last third
-    // is still landing, and only that third's dot products remain when the stream ends
-    constexpr int NBEFORE = SCHED == 3 ? (NP2 * 2) / 3 : NP2;
-    if constexpr (SCHED >= 2) {      // schedule B: nothing of phase 2 is queued before the whole workgroup has finished phase 1
+    uint4 w2r[18];
+    {
+        const unsigned char *w2s = reinterpret_cast<const unsigned char *>(a.w2) + ((size_t)blockIdx.x * 12 * FFN_H + 768 * wave) * 2;
 #pragma unroll
-        for (int c = 0; c < NBEFORE; c++) w2r[c] = ld_stream(w2ptr(c));
+        for (int c = 0; c < 18; c++) {
+            const int m = c / 3, k = c - 3 * m;
+            const int r = k == 0 ? 2 * m : k == 2 ? 2 * m + 1 : 2 * m + (lane >> 5);
+            const int col = k == 0 ? 8 * lane : k == 2 ? 256 + 8 * lane : (lane < 32 ? 512 + 8 * lane : 8 * (lane - 32));
+            w2r[c] = ld_stream(reinterpret_cast<const uint4 *>(w2s + ((size_t)r * FFN_H + col) * 2));
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     FFN_MARK(5);
     {
         u64 gv[12];
-        int gi[12];
+        const u64 *gsl = a.gh + 768 * wave + lane;
+        // First attempt in straight-line code (inside a loop the compiler merges the wait counts of "W2 bytes queued" and "not queued" and
+        // waits for all of W2 before it looks at the first tag); the retry loop is entered only if a tag was stale.
 #pragma unroll
-        for (int u = 0; u < 12; u++) gi[u] = W8 ? u * FFN_THREADS + tid : 768 * wave + 64 * u + lane;      // bf16: this wave's own slice of h
-        // First attempt in straight-line code (inside a loop the compiler merges the wait counts of "W2 rows queued" and "not queued" and
-        // waits for the whole W2 row before it looks at the first tag); the retry loop is entered only if a tag was stale.
-#pragma unroll
-        for (int u = 0; u < 12; u++) gv[u] = df_load_granule(a.gh + gi[u]);
-        if constexpr (SCHED == 3) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = NBEFORE; c < NP2; c++) w2r[c] = ld_stream(w2ptr(c));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
+        for (int u = 0; u < 12; u++) gv[u] = df_load_granule(gsl + 64 * u);
         bool ok = true;
 #pragma unroll
         for (int u = 0; u < 12; u++) ok = ok && (unsigned)(gv[u] >> 32) == a.epoch;
@@ -1273,36 +1197,38 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
                 __builtin_amdgcn_s_sleep(8);
                 ok = true;
 #pragma unroll
-                for (int u = 0; u < 12; u++) gv[u] = df_load_granule(a.gh + gi[u]);
+                for (int u = 0; u < 12; u++) gv[u] = df_load_granule(gsl + 64 * u);
 #pragma unroll
                 for (int u = 0; u < 12; u++) ok = ok && (unsigned)(gv[u] >> 32) == a.epoch;
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;           // the wave moves as one: its loads go out together
             }
         }
 #pragma unroll
-        for (int u = 0; u < 12; u++) hs[gi[u]] = __uint_as_float((unsigned)gv[u]);
+        for (int u = 0; u < 12; u++) hs[768 * wave + 64 * u + lane] = __uint_as_float((unsigned)gv[u]);
     }
-    if constexpr (!W8) {
-        // ---- phase 2, K-sliced: partial sums of all 12 rows over this wave's 768 columns --------------------------------------------
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the slice is written and read by this wave only: LDS operations of
-        __builtin_amdgcn_wave_barrier();                            // one wave execute in order, no workgroup barrier
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        FFN_MARK(6);
+    // the slice is written and read by this wave only: LDS operations of one wave execute in order, no workgroup barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    FFN_MARK(6);
+
+    // ---- phase 2: partial sums of all 12 rows over this wave's 768 columns, then x''[row] = x'[row] + the 12 partials in wave order ----
+    {
         const float *hw = hs + 768 * wave;
         const int cb = lane < 32 ? 512 + 8 * lane : 8 * (lane - 32);
         const float4 hA0 = *reinterpret_cast<const float4 *>(hw + 8 * lane), hA1 = *reinterpret_cast<const float4 *>(hw + 8 * lane + 4);
         const float4 hB0 = *reinterpret_cast<const float4 *>(hw + cb), hB1 = *reinterpret_cast<const float4 *>(hw + cb + 4);
         const float4 hC0 = *reinterpret_cast<const float4 *>(hw + 256 + 8 * lane), hC1 = *reinterpret_cast<const float4 *>(hw + 256 + 8 * lane + 4);
-        float *part = xs;                    // [12 waves][12 rows] (the normalised x' is dead)
         float rs[12];
 #pragma unroll
         for (int m = 0; m < 6; m++) {
-            const float p0 = dot8_bf16(w2r[3 * m], hA0, hA1, 0.f);
-            const float p1 = dot8_bf16(w2r[3 * m + 1], hB0, hB1, 0.f);
-            const float p2 = dot8_bf16(w2r[3 * m + 2], hC0, hC1, 0.f);
-            rs[2 * m] = df_wave_sum<true>(p0 + (lane < 32 ? p1 : 0.f));
-            rs[2 * m + 1] = df_wave_sum<true>(p2 + (lane < 32 ? 0.f : p1));
+            const float q0 = dot8_bf16(w2r[3 * m], hA0, hA1, 0.f);
+            const float q1 = dot8_bf16(w2r[3 * m + 1], hB0, hB1, 0.f);
+            const float q2 = dot8_bf16(w2r[3 * m + 2], hC0, hC1, 0.f);
+            rs[2 * m] = df_wave_sum<true>(q0 + (lane < 32 ? q1 : 0.f));
+            rs[2 * m + 1] = df_wave_sum<true>(q2 + (lane < 32 ? 0.f : q1));
         }
+        float *part = xs;
         if (lane == 0) {
 #pragma unroll
             for (int r4 = 0; r4 < 3; r4++)
@@ -1316,31 +1242,6 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
             const int orow = blockIdx.x * 12 + tid;
             a.x_out[orow] = stage[orow] + sum;
         }
-    } else {
-    __syncthreads();
-    FFN_MARK(6);
-
-    // ---- phase 2: x''[row] = x'[row] + W2[row] . h  (k_gemv_w2x's arithmetic) -----------------------------------------------------
-    {
-        constexpr int EPP2 = W8 ? 16 : 8;
-        float acc2 = 0.f;
-#pragma unroll
-        for (int c = 0; c < NP2; c++) {
-            const float *xp = hs + (c * 64 + lane) * EPP2;
-            const float4 x0 = *reinterpret_cast<const float4 *>(xp);
-            const float4 x1 = *reinterpret_cast<const float4 *>(xp + 4);
-            if constexpr (W8) {
-                const float4 x2 = *reinterpret_cast<const float4 *>(xp + 8);
-                const float4 x3 = *reinterpret_cast<const float4 *>(xp + 12);
-                acc2 = dot16_fp8(w2r[c], x0, x1, x2, x3, acc2);
-            } else {
-                acc2 = dot8_bf16(w2r[c], x0, x1, acc2);
-            }
-        }
-        acc2 = df_wave_sum<true>(acc2);
-        if constexpr (W8) acc2 *= a.s2[row];
-        if (lane == 0) a.x_out[row] = stage[row] + acc2;
-    }
     }
     FFN_MARK(7);
 #undef FFN_MARK

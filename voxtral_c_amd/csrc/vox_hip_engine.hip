@@ -243,7 +243,6 @@ struct vox_hip_engine {
     u64 *d_gq = nullptr, *d_gp = nullptr, *d_gh = nullptr;
     float *d_xprime = nullptr;    // x' of the fused FFN launch, written only for the debug taps
     bool use_ffn = false;         // FFN block as one launch (k_ffn_fused) instead of k_gemv_w13x + k_gemv_w2x
-    int ffn_sweep = 2;            // hand-off schedule of k_ffn_fused (VOX_HIP_FFN_SWEEP=1: schedule A, see the kernel)
     float *d_wo_part = nullptr;
     unsigned *d_fuse_err = nullptr;
     unsigned fuse_epoch = 0;
@@ -287,11 +286,10 @@ struct vox_hip_engine {
     // debug taps of the decoder's residual stream (vox_hip_debug_tap_config): at the decode steps whose KV position is listed,
     // x at the start of every layer, x after every attention block and x after the last layer are copied to d_taps in stream order
     std::vector<int> tap_pos; float *d_taps = nullptr;
-    // Round 4: L2 prefetch of the next launch's first weight bytes (vox_decfuse.h, DfPrefetch).  VOX_HIP_PF="units,member_units,when",
-    // VOX_HIP_PF13="units,gate_ticks", VOX_HIP_PF2="units,gate_ticks" override the defaults (A/B).
+    // Round 4: L2 prefetch of the next launch's first weight bytes (vox_decfuse.h, DfPrefetch).  VOX_HIP_PF="units,member_units,when"
+    // overrides the default (A/B).
     // Default (measured): 24 KiB per target block (6.3 MB per launch) issued by the non-members in front of their Wo rows.
     int pf_units = 24, pf_member_units = 0, pf_when = 3;
-    int pf13_units = 0, pf2_units = 0; unsigned pf13_gate = 0, pf2_gate = 0;
 };
 
 // Every host-side wait on the engine stream goes through here and is counted (vox_hip_host_syncs): the multi-GPU
@@ -674,26 +672,18 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  hipFuncSetAttribute((const void *)k_dec_attn_fused<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_dec_attn_fused<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DF_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w13x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_gemv_w13x<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_gemv_w13x<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w13x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w2x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w2x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_ffn_fused<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_ffn_fused<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_ffn_fused<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_ffn_fused<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess;
+                 hipFuncSetAttribute((const void *)k_ffn_fused, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess;
             if (!ok) { (void)hipGetLastError(); fprintf(stderr, "vox_hip: fused decode kernels unavailable; launch-per-GEMV chain\n"); }
             e->use_fused = ok; e->fused_ok = ok;
             e->use_ffn = ok && !getenv("VOX_HIP_NO_FFN_FUSED");        // A/B: k_gemv_w13x + k_gemv_w2x instead of k_ffn_fused
-            if (getenv("VOX_HIP_FFN_SWEEP")) e->ffn_sweep = atoi(getenv("VOX_HIP_FFN_SWEEP"));
             if (ok && getenv("VOX_HIP_FUSE_TRACE") && hipMalloc((void **)&e->d_fuse_trace, 64 * 8) == hipSuccess)
                 hipMemset(e->d_fuse_trace, 0, 64 * 8);
             e->fp8_attn_bf16 = getenv("VOX_HIP_FP8_ATTN_BF16") != nullptr;
             e->fp8_lmhead_bf16 = getenv("VOX_HIP_FP8_LMHEAD_BF16") != nullptr;
             if (const char *pf = getenv("VOX_HIP_PF")) sscanf(pf, "%d,%d,%d", &e->pf_units, &e->pf_member_units, &e->pf_when);
-            if (const char *pf = getenv("VOX_HIP_PF13")) sscanf(pf, "%d,%u", &e->pf13_units, &e->pf13_gate);
-            if (const char *pf = getenv("VOX_HIP_PF2")) sscanf(pf, "%d,%u", &e->pf2_units, &e->pf2_gate);
             if (ok && getenv("VOX_HIP_FUSE_TL") && hipMalloc((void **)&e->d_fuse_tl, 3 * 1024 * TL_STRIDE * 8) == hipSuccess)
                 hipMemset(e->d_fuse_tl, 0, 3 * 1024 * TL_STRIDE * 8);
         }
@@ -1960,17 +1950,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.gh = e->d_gh; a.epoch = e->fuse_epoch; a.err = e->d_fuse_err; a.spin_limit = 500000ull;
 
                 a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + TL_STRIDE * 1024 : nullptr;
-                if (e->use_fp8) {
-                    a.w1 = reinterpret_cast<const uint16_t *>(L.w138); a.w3 = reinterpret_cast<const uint16_t *>(L.w138 + (size_t)DH * DD);
-                    a.w2 = reinterpret_cast<const uint16_t *>(L.w28); a.s1 = L.s13; a.s3 = L.s13 + DH; a.s2 = L.s2;
-                    hipLaunchKernelGGL((k_ffn_fused<true, 2>), dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a);
-                } else if (e->ffn_sweep == 1) {
-                    hipLaunchKernelGGL((k_ffn_fused<false, 1>), dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a);
-                } else if (e->ffn_sweep == 3) {
-                    hipLaunchKernelGGL((k_ffn_fused<false, 3>), dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a);
-                } else {
-                    hipLaunchKernelGGL((k_ffn_fused<false, 2>), dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a);
-                }
+                hipLaunchKernelGGL(k_ffn_fused, dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a);
                 prof_mark(e, PK_SWIGLU);
                 tap(2 * l + 1, e->d_xprime);
                 std::swap(xin, xalt);
@@ -1983,19 +1963,12 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.eps = d.dec_eps; a.x_out = xalt; a.h = e->dh;
                 a.trace = (l == 13) ? e->d_fuse_trace : nullptr;
                 a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + TL_STRIDE * 1024 : nullptr;
-                if (e->pf13_units > 0) {
-                    a.pf_w = e->use_fp8 ? reinterpret_cast<const unsigned char *>(L.w28) : reinterpret_cast<const unsigned char *>(L.w2);
-                    a.pf_row_bytes = e->use_fp8 ? DH : 2 * DH; a.pf_units = std::min(e->pf13_units, e->use_fp8 ? 9 : 18); a.pf_gate = e->pf13_gate;
-                }
                 if (e->use_fp8) {
                     a.w1 = reinterpret_cast<const uint16_t *>(L.w138); a.w3 = reinterpret_cast<const uint16_t *>(L.w138 + (size_t)DH * DD);
                     a.s1 = L.s13; a.s3 = L.s13 + DH;
                     hipLaunchKernelGGL(k_gemv_w13x<true>, dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
                 } else {
-                    static const int early = getenv("VOX_HIP_W13_EARLY") ? atoi(getenv("VOX_HIP_W13_EARLY")) : 0;      // A/B, see k_gemv_w13x
-                    if (early == 1) hipLaunchKernelGGL((k_gemv_w13x<false, 1>), dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
-                    else if (early == 2) hipLaunchKernelGGL((k_gemv_w13x<false, 2>), dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
-                    else hipLaunchKernelGGL((k_gemv_w13x<false, 0>), dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
+                    hipLaunchKernelGGL(k_gemv_w13x<false>, dim3(256), dim3(W13X_THREADS), W13X_LDS_BYTES, s, a);
                 }
                 prof_mark(e, PK_SWIGLU);
             }
@@ -2011,9 +1984,6 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                     W2xArgs a{};
                     a.w2 = e->sim_on ? L.w2_s : L.w2; a.h = e->dh; a.x = xalt;        // x' += h . W2^T, in place (one wave per row)
                     a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + 2 * TL_STRIDE * 1024 : nullptr;
-                    if (e->pf2_units > 0 && l + 1 < d.dec_layers) {
-                        a.pf_w = reinterpret_cast<const unsigned char *>(e->dec[l + 1].wqkv); a.pf_units = std::min(e->pf2_units, 6); a.pf_gate = e->pf2_gate;
-                    }
                     if (e->use_fp8) {
                         a.w2 = reinterpret_cast<const uint16_t *>(L.w28); a.s2 = L.s2;
                         hipLaunchKernelGGL(k_gemv_w2x<true>, dim3(256), dim3(W2X_THREADS), W2X_LDS_BYTES, s, a);

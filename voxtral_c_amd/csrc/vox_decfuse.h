@@ -108,6 +108,7 @@ struct DecFuseArgs {
     // Round 4: L2 prefetch of the NEXT launch's (k_gemv_w13x) first weight bytes in this kernel's tail, when the memory system is
     // idle (DfPrefetch below).  pf.units = 0 switches it off.
     DfPrefetch pf;
+    int wo_late;                     // round 4: long contexts request their Wo rows behind their partial instead of under the first tile (see the kernel)
 };
 // stamps stay in registers until the end (no stores in the middle of the memory schedule)
 #define DF_MARK(k) do { if (a.trace || a.tl) df_stamp[k] = wall_clock64(); } while (0)
@@ -488,9 +489,8 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
             if (ti + 1 < n_tiles)                                    // next tile into the other buffer, under this tile's math
                 df_tile_dma(a, g, t0 + DF_TILE, s_hi, lds_addr(tiles + ((ti + 1) & 1) * 2 * DF_TILE_BYTES),
                             lds_addr(tiles + ((ti + 1) & 1) * 2 * DF_TILE_BYTES + DF_TILE_BYTES), wave, lane);
-            // Long contexts: the Wo rows of an attention member stream under its first tile's math (q/k/v and the tile are in,
-            // nothing this workgroup waits for is queued behind them until the partial sweep).
-            if (ti == 0 && !wo_light) { DF_LATE_WO(0) DF_LATE_WO(4) DF_LATE_WO(8) }
+            // A/B (VOX_HIP_FUSE_WO_LATE=0, rounds 2 - 3): the Wo rows of an attention member stream under its first tile's math
+            if (ti == 0 && !wo_light && !a.wo_late) { DF_LATE_WO(0) DF_LATE_WO(4) DF_LATE_WO(8) }
             if (t0 + DF_TILE > pos && t0 <= pos) {
                 // this step's own K/V row is not visible in the ring to other CUs yet: patch it in from the hand-off
                 const int key = pos - t0;
@@ -610,6 +610,13 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
             df_store_granule(mine + ho * DF_HD + dd, epoch, o_acc);
             if (dd == 0) { df_store_granule(mine + 4 * DF_HD + 2 * ho, epoch, cr[4 + ho]); df_store_granule(mine + 4 * DF_HD + 2 * ho + 1, epoch, cr[8 + ho]); }
         }
+        // Long contexts (members carry Wo rows too): the rows are requested only now, BEHIND the partial.  A CU's stores leave through
+        // the same queue as its loads: published behind 96 KB of queued rows (rounds 2 - 3: they were requested under the first tile's
+        // math) the partial became visible to the group only when they had landed, and their issue stalled the score phase by 1.3 us.
+        // Same box, alternating, ms per step at 600 / 1000 / 1900 / 3800 / 8000 keys: 1.4331 / 1.4490 / 1.5265 / 1.6296 / 1.8045 ->
+        // 1.4289 / 1.4404 / 1.5141 / 1.5882 / 1.7540 (requesting them right behind the q/k/v sweep instead: +2 % up to 1900 keys - a
+        // sweep that finds a stale tag repeats its load behind the rows - and -1 % beyond).
+        if (!wo_light && a.wo_late) { __builtin_amdgcn_sched_barrier(0); DF_LATE_WO(0) DF_LATE_WO(4) DF_LATE_WO(8) }
         if (pf_on && pf_Vm > 0) {      // a member is done: its share of the next launch's first bytes (every tile read is behind the barrier above)
             __builtin_amdgcn_sched_barrier(0);
             df_prefetch_units(a.pf, g, 0, pf_Vm, j * DF_WAVES + wave, ns * DF_WAVES, lane, pf_lds);

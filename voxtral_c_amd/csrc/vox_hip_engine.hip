@@ -241,6 +241,7 @@ struct vox_hip_engine {
     bool fused_ok = false;        // the fused kernels exist for this geometry / device (use_fused may be suspended after a time-out)
     long fuse_rearm = 0;          // clean decode steps on the chain before the fused kernel is tried again (0 = not suspended)
     u64 *d_gq = nullptr, *d_gp = nullptr, *d_gh = nullptr;
+    int wo_late = 1;              // VOX_HIP_FUSE_WO_LATE=0 (A/B, see DecFuseArgs)
     float *d_xprime = nullptr;    // x' of the fused FFN launch, written only for the debug taps
     bool use_ffn = false;         // FFN block as one launch (k_ffn_fused) instead of k_gemv_w13x + k_gemv_w2x
     float *d_wo_part = nullptr;
@@ -681,6 +682,7 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
             e->use_ffn = ok && !getenv("VOX_HIP_NO_FFN_FUSED");        // A/B: k_gemv_w13x + k_gemv_w2x instead of k_ffn_fused
             if (ok && getenv("VOX_HIP_FUSE_TRACE") && hipMalloc((void **)&e->d_fuse_trace, 64 * 8) == hipSuccess)
                 hipMemset(e->d_fuse_trace, 0, 64 * 8);
+            if (getenv("VOX_HIP_FUSE_WO_LATE")) e->wo_late = atoi(getenv("VOX_HIP_FUSE_WO_LATE"));
             e->fp8_attn_bf16 = getenv("VOX_HIP_FP8_ATTN_BF16") != nullptr;
             e->fp8_lmhead_bf16 = getenv("VOX_HIP_FP8_LMHEAD_BF16") != nullptr;
             if (const char *pf = getenv("VOX_HIP_PF")) sscanf(pf, "%d,%d,%d", &e->pf_units, &e->pf_member_units, &e->pf_when);
@@ -1917,6 +1919,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.merge_three_trips = merge3 || f_split > 64;
                 static const int attn_old = getenv("VOX_HIP_FUSE_ATTN_PER_HEAD") ? 1 : 0;
                 a.attn_gqa = !attn_old;
+                a.wo_late = e->wo_late;
                 if (e->pf_units > 0) {        // the next launch's (k_gemv_w13x) first bytes, see DfPrefetch
                     a.pf.w = e->use_fp8 ? reinterpret_cast<const unsigned char *>(L.w138) : reinterpret_cast<const unsigned char *>(L.w13);
                     a.pf.row_bytes = e->use_fp8 ? DD : 2 * DD; a.pf.rows_m = DH;

@@ -1080,8 +1080,8 @@ struct FfnArgs {
 constexpr int FFN_THREADS = 768, FFN_H = 9216;
 constexpr int FFN_LDS_BYTES = W13X_LDS_BYTES;       // phase 2 reuses the prologue's staging area: x' (12 KB) + h (36 KB)
 
-__global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// gx (optional): x'' also leaves as {epoch, value} granules (k_ffn_attn12: the attention block of the next layer in the same launch)
+__device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx) {
     float *stage = smem;                 // [9][3072]: x, wo_part[0..7]; after the prologue: row 0 = x', rows 1..3 = h
     float *nws = smem + 9 * DF_D;        // [3072] norm weights
     float *ads = nws + DF_D;             // [3072] ada
@@ -1247,12 +1247,385 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
 #pragma unroll
             for (int w12 = 0; w12 < 12; w12++) sum += part[w12 * 12 + tid];         // fixed order
             const int orow = blockIdx.x * 12 + tid;
-            a.x_out[orow] = stage[orow] + sum;
+            const float xv = stage[orow] + sum;
+            a.x_out[orow] = xv;
+            if (gx) df_store_granule(gx + orow, a.epoch, xv);
         }
     }
     FFN_MARK(7);
 #undef FFN_MARK
     tl_end(a.tl, tl0, df_stamp, 8);
+}
+__global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ffn_body(a, smem, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// df_attn12_body (round 4, late) - k_dec_attn_fused's block in the FFN kernel's shape: 768 threads = 12 waves, at most 168 registers,
+// specialised to the short-context regime the 30 s clip lives in (<= 8 key slices of 64 keys: one tile per attention member, the
+// members carry no Wo rows, one XCD per KV head), bf16 weights, DPP reductions, layers > 0.  It exists so that the FFN block of
+// layer l and the attention block of layer l + 1 can be ONE launch (k_ffn_attn12 below).  Same arithmetic as k_dec_attn_fused
+// (same row mapping, same hand-off granules, same partials), differences in the shape only:
+//   projection: 2 rows per wave (rows 2w, 2w+1 of the workgroup's 24), 12 loads per lane;
+//   Wo rows:    the group's 3072 rows over (32 - ns) x 12 waves, <= 12 per wave;
+//   attention:  waves 0..7 (the 64-key tile is 8 waves' work), waves 8..11 only keep the barriers.
+// XG: x'' of the previous FFN block arrives as granules (gx, tagged x_epoch) instead of through memory after a kernel boundary:
+// the sweep (4 loads per thread) is queued behind the first two pieces of the projection rows.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DA12_THREADS = 768, DA12_WAVES = 12, DA12_NWO = 12;
+constexpr int DA12_LDS_BYTES = 2 * DF_D * 4 + 2 * DF_TILE_BYTES + 1024 + 512;
+template <bool XG>
+__device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned char *smem_raw, const u64 *gx, unsigned x_epoch) {
+    float *xs = reinterpret_cast<float *>(smem_raw);                           // [3072] x, then [3072] norm weights (contiguous)
+    float *nw = xs + DF_D;
+    unsigned char *tiles = smem_raw + 2 * DF_D * 4;                            // [K tile | V tile]; later the Wo reduction scratch
+    float *frq = reinterpret_cast<float *>(tiles + 2 * DF_TILE_BYTES);         // [256] inv_freq (64 valid)
+    float *red = frq + 256;                                                    // [128]: wave sums, the 24 row results
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x % DF_GROUPS, j = blockIdx.x / DF_GROUPS;
+    const unsigned epoch = a.epoch;
+    const int pos = a.pos;
+    unsigned long long df_stamp[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tl0 = tl_begin(a.tl);
+    DF_MARK(0);
+    // ---- this workgroup's 24 projection rows: wave w streams rows 2w, 2w+1 ----------------------------------------------------------
+    const unsigned char *rp[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int lr = 2 * wave + i;
+        const int row = lr < 16 ? DF_NQ * g + 16 * j + lr
+                      : lr < 20 ? DF_DQ + DF_HD * g + 4 * j + (lr - 16)
+                                : DF_DQ + DF_DKV + DF_HD * g + 4 * j + (lr - 20);
+        rp[i] = reinterpret_cast<const unsigned char *>(a.wqkv) + (size_t)row * (DF_D * 2) + lane * 16;
+    }
+    const int ns = a.nsplit;                                     // <= 8 here
+    int lo = pos - a.window + 1; if (lo < 0) lo = 0;
+    const int s_lo = lo + j * a.split_keys;
+    int s_hi = s_lo + a.split_keys - 1; if (s_hi > pos) s_hi = pos;
+    const bool att_block = j < ns;
+    // ---- t0: the vectors by LDS-DMA, then the weights -------------------------------------------------------------------------------
+    if (wave < 1) glds16(reinterpret_cast<const unsigned char *>(a.inv_freq) + lane * 16, lds_addr(frq));
+    if constexpr (XG) {
+        glds16(a.norm_w + tid * 4, lds_addr(nw) + (unsigned)wave * 1024u);
+    } else {
+#pragma unroll
+        for (int p = 0; p < 2; p++) glds16((p ? a.norm_w : a.x) + tid * 4, lds_addr(xs) + (unsigned)(p * 12288 + wave * 1024));
+    }
+    DF_MARK(11);
+    __builtin_amdgcn_s_barrier();          // every wave's share of the vectors is in the CU's queue before anybody's weights (see k_dec_attn_fused)
+    DF_MARK(12);
+    uint4 w[2][6];
+    u64 gxv[4] = {0, 0, 0, 0};
+    if constexpr (XG) {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) w[i][c] = ld_stream(reinterpret_cast<const uint4 *>(rp[i] + c * 1024));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) gxv[u] = df_load_granule(gx + u * DA12_THREADS + tid);      // back when the first two pieces are
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 2; c < 6; c++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) w[i][c] = ld_stream(reinterpret_cast<const uint4 *>(rp[i] + c * 1024));
+    } else {
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) w[i][c] = ld_stream(reinterpret_cast<const uint4 *>(rp[i] + c * 1024));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // Wo rows (row r = Wo[r][512 g .. 512 g + 511] = 1 KiB): the 32 - ns non-members share the group's 3072 rows, <= 12 per wave
+    uint4 wv[DA12_NWO];
+    const int nb = DF_BPG - ns, rpb = ((DF_D + nb - 1) / nb + 11) / 12 * 12;
+    const int wo_rpw = rpb / 12;
+    const int wo_row0 = att_block ? DF_D : (j - ns) * rpb + wave * wo_rpw;
+    const int wo_n = max(0, min(wo_rpw, DF_D - wo_row0));
+    const int wo_rmax = wo_n > 0 ? wo_row0 + wo_n - 1 : DF_D - 1;
+    const unsigned char *wo_base = reinterpret_cast<const unsigned char *>(a.wo) + (size_t)(DF_NQ * g) * 2 + lane * 16;
+    const int tile_slot0 = __builtin_amdgcn_readfirstlane(att_block ? s_lo % a.kv_cap : 0);
+    DF_MARK(1);
+    // ---- the activation vector -----------------------------------------------------------------------------------------------------
+    if constexpr (XG) {
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < 4; u++) ok = ok && (unsigned)(gxv[u] >> 32) == x_epoch;
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
+            const unsigned long long t0 = wall_clock64();
+            for (unsigned it = 0;; it++) {
+                if ((it & 15u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(4);
+                ok = true;
+#pragma unroll
+                for (int u = 0; u < 4; u++) gxv[u] = df_load_granule(gx + u * DA12_THREADS + tid);
+#pragma unroll
+                for (int u = 0; u < 4; u++) ok = ok && (unsigned)(gxv[u] >> 32) == x_epoch;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) xs[u * DA12_THREADS + tid] = __uint_as_float((unsigned)gxv[u]);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // the vector DMAs are older than everything else; pieces 2..5 may still stream
+    } else {
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // only the 12 weight loads are younger than the activation DMAs
+    }
+    __syncthreads();
+    DF_MARK(2);
+    {   // RMSNorm (voxtral_kernels.c:346-363), under the weight stream: 4 elements per thread
+        float4 v = *reinterpret_cast<const float4 *>(xs + tid * 4);
+        float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        ss = df_wave_sum<true>(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < DA12_WAVES; i++) tot += red[i];
+        const float inv = 1.0f / sqrtf(tot / (float)DF_D + a.eps);
+        const float4 gw = *reinterpret_cast<const float4 *>(nw + tid * 4);
+        v.x = v.x * inv * gw.x; v.y = v.y * inv * gw.y; v.z = v.z * inv * gw.z; v.w = v.w * inv * gw.w;
+        *reinterpret_cast<float4 *>(xs + tid * 4) = v;
+        __syncthreads();
+    }
+    DF_MARK(3);
+    float rope_c = 1.f, rope_s = 0.f;
+    if (tid < 10) {
+        const int in_head = tid < 8 ? (16 * j + 2 * tid) % DF_HD : 4 * j + 2 * (tid - 8);
+        const float ang = (float)pos * frq[in_head >> 1];
+        rope_c = cosf(ang); rope_s = sinf(ang);
+    }
+    float acc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const float4 x0 = *reinterpret_cast<const float4 *>(xs + (c * 64 + lane) * 8);
+        const float4 x1 = *reinterpret_cast<const float4 *>(xs + (c * 64 + lane) * 8 + 4);
+#pragma unroll
+        for (int i = 0; i < 2; i++) acc[i] = dot8_bf16(w[i][c], x0, x1, acc[i]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]) :: "memory");     // the tile DMAs below stay below the dot products
+    if (att_block && wave < 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) df_tile_op(a, g, s_lo, s_hi, lds_addr(tiles), lds_addr(tiles + DF_TILE_BYTES), wave, lane, k, true, tile_slot0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float sres = df_wave_sum<true>(acc[i]);
+        if (lane == 0) red[16 + 2 * wave + i] = sres;
+    }
+    DF_MARK(4);
+    __syncthreads();
+    // ---- RoPE, KV append, publish q/k/v: 12 threads, one (even, odd) row pair each ------------------------------------------------
+    u64 *gq = a.gq + (size_t)g * DF_GQ;
+    if (tid < 12) {
+        const int p = tid;
+        float e0 = red[16 + 2 * p], e1 = red[16 + 2 * p + 1];
+        if (p < 10) { const float r0 = e0 * rope_c - e1 * rope_s, r1 = e0 * rope_s + e1 * rope_c; e0 = r0; e1 = r1; }     // voxtral_kernels.c:502-526
+        if (p < 8) {
+            df_store_granule(gq + 16 * j + 2 * p, epoch, e0); df_store_granule(gq + 16 * j + 2 * p + 1, epoch, e1);
+        } else {
+            const bool isk = p < 10;
+            const int kl = 4 * j + 2 * (isk ? p - 8 : p - 10);
+            const size_t slot = (size_t)(pos % a.kv_cap) * DF_DKV + DF_HD * g + kl;
+            float *ring = isk ? a.kring : a.vring;
+            ring[slot] = e0; ring[slot + 1] = e1;
+            const int gi = DF_NQ + (isk ? 0 : DF_HD) + kl;
+            df_store_granule(gq + gi, epoch, e0); df_store_granule(gq + gi + 1, epoch, e1);
+        }
+    }
+    __syncthreads();                       // xs / nw are dead from here on: scratch for the attention stage
+    DF_MARK(5);
+    const bool pf_on = a.pf.units > 0;
+    const int pf_V = 32 * a.pf.units;
+    const unsigned pf_lds = lds_addr(tiles) + 53248u + (unsigned)wave * 896u;       // 12 x 896 B behind the Wo reduction scratch (52 KB)
+    if (!att_block) {
+        if (pf_on) {
+            df_prefetch_units(a.pf, g, 0, pf_V, (j - ns) * DA12_WAVES + wave, (DF_BPG - ns) * DA12_WAVES, lane, pf_lds);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < DA12_NWO; i++) wv[i] = ld_stream(reinterpret_cast<const uint4 *>(wo_base + (size_t)min(wo_row0 + i, wo_rmax) * (DF_DQ * 2)));
+    }
+    float *qs = xs;                        // [512] the group's q
+    float *kvn = xs + 512;                 // [256] this step's k | v of head g
+    float *att = xs + 768;                 // [512] merged attention output of the group's 4 heads
+    float *pt = xs + 1792;                 // [4 heads][64 keys] softmax numerators
+    float *cr = xs + 2048;                 // [4] max, [4] sum
+    float *sc8 = xs + 2560;                // [4 heads][8 dim slices][64 keys] partial scores, then [4 key quarters][4 heads][128] partial outputs
+    u64 *gp = a.gp + ((size_t)g * DF_BPG) * DF_GP;
+    if (att_block) {
+        // ---- hand-off 1: sweep the group's 768 granules ---------------------------------------------------------------------------------
+        if (tid < 512) {
+            u64 gv0 = df_load_granule(gq + tid), gv1 = 0;
+            if (tid < 256) gv1 = df_load_granule(gq + 512 + tid);
+            qs[tid] = (unsigned)(gv0 >> 32) == epoch ? __uint_as_float((unsigned)gv0) : df_wait_granule(gq + tid, epoch, a, 1u);
+            if (tid < 256) kvn[tid] = (unsigned)(gv1 >> 32) == epoch ? __uint_as_float((unsigned)gv1) : df_wait_granule(gq + 512 + tid, epoch, a, 1u);
+        }
+        DF_MARK(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the tile has landed
+        __syncthreads();
+        unsigned char *kt = tiles, *vt = tiles + DF_TILE_BYTES;
+        const int t0 = s_lo;
+        if (t0 + DF_TILE > pos && t0 <= pos) {
+            // this step's own K/V row is not visible in the ring to other CUs yet: patch it in from the hand-off
+            const int key = pos - t0;
+            if (tid < 32) *reinterpret_cast<float4 *>(kt + key * 512 + ((tid ^ (key & 31)) << 4)) = *reinterpret_cast<const float4 *>(kvn + tid * 4);
+            else if (tid < 64) *reinterpret_cast<float4 *>(vt + key * 512 + ((tid - 32) << 4)) = *reinterpret_cast<const float4 *>(kvn + DF_HD + (tid - 32) * 4);
+            __syncthreads();
+        }
+        DF_MARK(11);
+        // scores: wave (0..7) -> 16 of the 128 dims for all 4 heads, lane -> key; the 8 partial sums per (head, key) meet in LDS
+        if (wave < 8) {
+            const unsigned char *krow = kt + lane * 512;
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int ch = 4 * wave + c;
+                const float4 kv4 = *reinterpret_cast<const float4 *>(krow + ((ch ^ (lane & 31)) << 4));
+#pragma unroll
+                for (int hh = 0; hh < 4; hh++) {
+                    const float4 q4 = *reinterpret_cast<const float4 *>(qs + hh * DF_HD + ch * 4);
+                    s4[hh] = fmaf(q4.x, kv4.x, s4[hh]); s4[hh] = fmaf(q4.y, kv4.y, s4[hh]);
+                    s4[hh] = fmaf(q4.z, kv4.z, s4[hh]); s4[hh] = fmaf(q4.w, kv4.w, s4[hh]);
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < 4; hh++) sc8[(hh * 8 + wave) * 64 + lane] = s4[hh];
+        }
+        __syncthreads();
+        DF_MARK(12);
+        if (wave < 4) {   // one wave per head: softmax numerators over this slice's keys (one tile: running max / sum start here)
+            float sv = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; w8++) sv += sc8[(wave * 8 + w8) * 64 + lane];
+            sv *= a.scale;
+            if (t0 + lane > s_hi) sv = -INFINITY;
+            const float m_new = fmaxf(-1e30f, df_wave_max<true>(sv));
+            const float p = expf(sv - m_new);
+            const float l_new = df_wave_sum<true>(p);          // (0 * exp(-1e30 - m) + sum, as the tile loop of k_dec_attn_fused computes it)
+            pt[wave * 64 + lane] = p;
+            if (lane == 0) { cr[4 + wave] = m_new; cr[8 + wave] = l_new; }
+        }
+        __syncthreads();
+        const int ho = (tid >> 7) & 3, dd = tid & 127;
+        if (tid < 512) {  // quarter sums: keys 16 kq .. 16 kq + 15 of the tile, dim dd, all 4 heads (only the valid keys)
+            const int kq = tid >> 7;
+            const float *vcol = reinterpret_cast<const float *>(vt) + dd;
+            const int nv = min(DF_TILE, s_hi - t0 + 1);
+            float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int k0 = 16 * kq + 4 * i;
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = k0 + u < nv ? vcol[(k0 + u) * 128] : 0.f;
+#pragma unroll
+                for (int hh = 0; hh < 4; hh++) {
+                    const float4 p4 = *reinterpret_cast<const float4 *>(pt + hh * 64 + k0);
+                    a4[hh] = fmaf(p4.x, v[0], a4[hh]); a4[hh] = fmaf(p4.y, v[1], a4[hh]);
+                    a4[hh] = fmaf(p4.z, v[2], a4[hh]); a4[hh] = fmaf(p4.w, v[3], a4[hh]);
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < 4; hh++) sc8[(kq * 4 + hh) * DF_HD + dd] = a4[hh];
+        }
+        __syncthreads();
+        if (tid < 512) {
+            const float accv = (sc8[(0 * 4 + ho) * DF_HD + dd] + sc8[(1 * 4 + ho) * DF_HD + dd]) +
+                               (sc8[(2 * 4 + ho) * DF_HD + dd] + sc8[(3 * 4 + ho) * DF_HD + dd]);
+            const float o_acc = 0.f * 0.f + accv;              // (o_acc * corr + accv with o_acc = 0)
+            u64 *mine = gp + (size_t)j * DF_GP;
+            df_store_granule(mine + ho * DF_HD + dd, epoch, o_acc);
+            if (dd == 0) { df_store_granule(mine + 4 * DF_HD + 2 * ho, epoch, cr[4 + ho]); df_store_granule(mine + 4 * DF_HD + 2 * ho + 1, epoch, cr[8 + ho]); }
+        }
+        DF_MARK(7);
+    } else {
+        DF_MARK(6);
+        DF_MARK(7);
+        // ---- hand-off 2: one thread polls, then everybody sweeps the group's partials and merges them in slice order -------------------
+        const int h = (tid >> 7) & 3, d = tid & 127;
+        float M = -1e30f, L = 0.f, O = 0.f;
+        if (tid == 0) (void)df_wait_granule(gp + (size_t)(ns - 1) * DF_GP + 4 * DF_HD, epoch, a, 2u);
+        __syncthreads();
+        if (tid < 512) {
+            for (int s0 = 0; s0 < ns; s0 += 4) {
+                u64 gv[4][3];
+                const unsigned long long t0 = wall_clock64();
+                for (unsigned it = 0;; it++) {
+                    bool ok = true;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const u64 *part = gp + (size_t)min(s0 + u, ns - 1) * DF_GP;
+                        gv[u][0] = df_load_granule(part + h * DF_HD + d);
+                        gv[u][1] = df_load_granule(part + 4 * DF_HD + 2 * h);
+                        gv[u][2] = df_load_granule(part + 4 * DF_HD + 2 * h + 1);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) ok = ok && (unsigned)(gv[u][k] >> 32) == epoch;
+                    if (ok) break;
+                    if ((it & 15u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                    if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (s0 + u >= ns) break;
+                    const float v0 = __uint_as_float((unsigned)gv[u][0]), vm = __uint_as_float((unsigned)gv[u][1]), vl = __uint_as_float((unsigned)gv[u][2]);
+                    const float mn = fmaxf(M, vm);
+                    const float c0 = expf(M - mn), c1 = expf(vm - mn);
+                    L = L * c0 + vl * c1;
+                    O = O * c0 + v0 * c1;
+                    M = mn;
+                }
+            }
+            att[h * DF_HD + d] = L > 0.f ? O / L : 0.f;
+        }
+        DF_MARK(8);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the Wo rows (and the prefetch DMAs) have landed
+        __syncthreads();
+        DF_MARK(9);
+        if (wo_n > 0) {
+            // the wave's <= 12 row sums as ONE transposed reduction through LDS (see k_dec_attn_fused)
+            const float4 x0 = *reinterpret_cast<const float4 *>(att + lane * 8);
+            const float4 x1 = *reinterpret_cast<const float4 *>(att + lane * 8 + 4);
+            float *wr = reinterpret_cast<float *>(tiles) + wave * (16 * 68);
+#pragma unroll
+            for (int i = 0; i < DA12_NWO; i++) wr[i * 68 + lane] = dot8_bf16(wv[i], x0, x1, 0.f);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int row = lane >> 2, q = lane & 3;
+            float sres = 0.f;
+            if (row < DA12_NWO) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float4 v = *reinterpret_cast<const float4 *>(wr + row * 68 + q * 16 + 4 * c);
+                    sres += (v.x + v.y) + (v.z + v.w);
+                }
+            }
+            sres += __shfl_xor(sres, 1, 4);
+            sres += __shfl_xor(sres, 2, 4);
+            if (q == 0 && row < wo_n) a.wo_part[(size_t)g * DF_D + wo_row0 + row] = sres;
+        }
+        DF_MARK(10);
+    }
+    tl_end(a.tl, tl0, df_stamp, 13);
+}
+__global__ __launch_bounds__(DA12_THREADS, 1) void k_attn12(const DecFuseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem12[];
+    df_attn12_body<false>(a, smem12, nullptr, 0u);
+}
+// FFN block of layer l, then the attention block of layer l + 1, one launch (fa = the attention block's arguments)
+__global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_attn12(const FfnArgs f, const DecFuseArgs a, u64 *gx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ffn_body(f, smem, gx);
+    __syncthreads();                        // every reader of the FFN block's LDS is done
+    df_attn12_body<true>(a, reinterpret_cast<unsigned char *>(smem), gx, f.epoch);
 }
 
 }  // namespace vox

@@ -241,6 +241,8 @@ struct vox_hip_engine {
     bool fused_ok = false;        // the fused kernels exist for this geometry / device (use_fused may be suspended after a time-out)
     long fuse_rearm = 0;          // clean decode steps on the chain before the fused kernel is tried again (0 = not suspended)
     u64 *d_gq = nullptr, *d_gp = nullptr, *d_gh = nullptr;
+    int merge12 = 2;              // VOX_HIP_MERGE12: 0 = two launches per layer in the 8-wave shape (before), 1 = k_attn12 in place of k_dec_attn_fused where it applies (A/B of the shape), 2 = k_ffn_attn12
+    u64 *d_gx = nullptr;          // [3072] x'' hand-off of k_ffn_attn12
     int wo_late = 1;              // VOX_HIP_FUSE_WO_LATE=0 (A/B, see DecFuseArgs)
     float *d_xprime = nullptr;    // x' of the fused FFN launch, written only for the debug taps
     bool use_ffn = false;         // FFN block as one launch (k_ffn_fused) instead of k_gemv_w13x + k_gemv_w2x
@@ -676,13 +678,17 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  hipFuncSetAttribute((const void *)k_gemv_w13x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W13X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w2x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w2x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_ffn_fused, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess;
+                 hipFuncSetAttribute((const void *)k_ffn_fused, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, DA12_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_ffn_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess &&
+                 dalloc(e, &e->d_gx, (size_t)DF_D) == 0 && hipMemset(e->d_gx, 0, (size_t)DF_D * 8) == hipSuccess;
             if (!ok) { (void)hipGetLastError(); fprintf(stderr, "vox_hip: fused decode kernels unavailable; launch-per-GEMV chain\n"); }
             e->use_fused = ok; e->fused_ok = ok;
             e->use_ffn = ok && !getenv("VOX_HIP_NO_FFN_FUSED");        // A/B: k_gemv_w13x + k_gemv_w2x instead of k_ffn_fused
             if (ok && getenv("VOX_HIP_FUSE_TRACE") && hipMalloc((void **)&e->d_fuse_trace, 64 * 8) == hipSuccess)
                 hipMemset(e->d_fuse_trace, 0, 64 * 8);
             if (getenv("VOX_HIP_FUSE_WO_LATE")) e->wo_late = atoi(getenv("VOX_HIP_FUSE_WO_LATE"));
+            if (getenv("VOX_HIP_MERGE12")) e->merge12 = atoi(getenv("VOX_HIP_MERGE12"));
             e->fp8_attn_bf16 = getenv("VOX_HIP_FP8_ATTN_BF16") != nullptr;
             e->fp8_lmhead_bf16 = getenv("VOX_HIP_FP8_LMHEAD_BF16") != nullptr;
             if (const char *pf = getenv("VOX_HIP_PF")) sscanf(pf, "%d,%d,%d", &e->pf_units, &e->pf_member_units, &e->pf_when);
@@ -720,7 +726,7 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     F(e->hann); F(e->cosT); F(e->sinT); F(e->filtT); F(e->enc_inv_freq); F(e->dec_inv_freq); F(e->dec_rope);
     F(e->d_st); F(e->dx); F(e->dx2); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
     F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_gq); F(e->d_gp); F(e->d_wo_part); F(e->d_fuse_err);
-    F(e->d_gh); F(e->d_xprime);
+    F(e->d_gh); F(e->d_gx); F(e->d_xprime);
     Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
                    &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml, &e->ssplitk};
     for (Buf *b : bufs) F(b->p);
@@ -1889,10 +1895,15 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
         hipMemcpyAsync(e->d_taps + ((size_t)tap_i * (2 * d.dec_layers + 1) + slot) * DD, src, (size_t)DD * 4, hipMemcpyDeviceToDevice, s);
     };
     static const int tl_layer = getenv("VOX_HIP_FUSE_TL_LAYER") ? atoi(getenv("VOX_HIP_FUSE_TL_LAYER")) : 13;
+    // the 12-wave shape (k_attn12 / k_ffn_attn12) covers the short-context regime only: <= 8 key slices, bf16, DPP, no debug hooks
+    static const int spread_env0 = getenv("VOX_HIP_FUSE_SPREAD") ? atoi(getenv("VOX_HIP_FUSE_SPREAD")) : -1;
+    const bool shape12 = fused && e->merge12 > 0 && e->use_ffn && !e->use_fp8 && !e->sim_on && f_ns <= 8 && spread_env0 <= 0 && e->skip_kinds == 0 &&
+                         tap_i < 0 && !e->prof_on && e->pf_when == 3 && e->pf_member_units == 0 && !getenv("VOX_HIP_FUSE_ATTN_PER_HEAD");
+    bool attn_done = false;           // this layer's attention block ran at the end of the previous layer's launch (k_ffn_attn12)
     for (int l = 0; l < d.dec_layers; l++) {
         DecLayer &L = e->dec[l];
         if (fused) {
-            if (!(e->skip_kinds & (1u << PK_QKV))) {
+            if (!attn_done && !(e->skip_kinds & (1u << PK_QKV))) {
                 // attention_norm -> wq/wk/wv -> RoPE -> KV append -> attention -> wo (K-split partials): one launch
                 DecFuseArgs a{};
                 a.wqkv = e->sim_on ? L.wqkv_s : L.wqkv; a.wo = e->sim_on ? L.wo_s : L.wo; a.x = xin; a.norm_w = L.n1; a.eps = d.dec_eps; a.inv_freq = e->dec_inv_freq;
@@ -1933,6 +1944,8 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                     a.sqkv = L.sqkv; a.so = L.so;
                     if (emb) hipLaunchKernelGGL((k_dec_attn_fused<true, true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
                     else hipLaunchKernelGGL((k_dec_attn_fused<false, true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
+                } else if (shape12 && !emb) {
+                    hipLaunchKernelGGL(k_attn12, dim3(DF_BLOCKS), dim3(DA12_THREADS), DA12_LDS_BYTES, s, a);
                 } else if (e->use_dpp) {
                     if (emb) hipLaunchKernelGGL((k_dec_attn_fused<true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
                     else hipLaunchKernelGGL((k_dec_attn_fused<false, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
@@ -1942,6 +1955,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 }
                 prof_mark(e, PK_QKV);
             }
+            attn_done = false;
             tap(2 * l, xin);              // (layer 0 of a stream step builds x inside the launch above and writes it to xin)
             // (fp8 mode keeps the two launches: with half the W2 bytes the 72 KB sweep and the dot products at the end are no longer
             //  hidden - measured 1.1055 against 1.0271 ms per step, gpurun_out/r4k)
@@ -1953,6 +1967,24 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.gh = e->d_gh; a.epoch = e->fuse_epoch; a.err = e->d_fuse_err; a.spin_limit = 500000ull;
 
                 a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + TL_STRIDE * 1024 : nullptr;
+                if (shape12 && e->merge12 == 2 && l + 1 < d.dec_layers) {
+                    // k_ffn_attn12: this FFN block and the NEXT layer's attention block in one launch; x'' goes over in granules
+                    DecLayer &N = e->dec[l + 1];
+                    DecFuseArgs b{};
+                    b.wqkv = N.wqkv; b.wo = N.wo; b.x = xalt; b.norm_w = N.n1; b.eps = d.dec_eps; b.inv_freq = e->dec_inv_freq;
+                    b.kring = N.kring; b.vring = N.vring; b.kv_cap = e->dec_ring_cap; b.pos = kv_pos; b.window = d.dec_window; b.scale = scale;
+                    b.gq = e->d_gq; b.gp = e->d_gp; b.wo_part = e->d_wo_part;
+                    if (++e->fuse_epoch == 0) e->fuse_epoch = 1;
+                    b.epoch = e->fuse_epoch; b.split_keys = f_split; b.nsplit = f_ns;
+                    b.err = e->d_fuse_err; b.spin_limit = 500000ull; b.attn_gqa = 1;
+                    b.tl = (l + 1 == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl : nullptr;
+                    if (e->pf_units > 0) {
+                        b.pf.w = reinterpret_cast<const unsigned char *>(N.w13); b.pf.row_bytes = 2 * DD; b.pf.rows_m = DH;
+                        b.pf.units = std::min(e->pf_units, 72 * 6); b.pf.member_units = 0; b.pf.when = 3;
+                    }
+                    hipLaunchKernelGGL(k_ffn_attn12, dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a, b, e->d_gx);
+                    attn_done = true;
+                } else
                 hipLaunchKernelGGL(k_ffn_fused, dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a);
                 prof_mark(e, PK_SWIGLU);
                 tap(2 * l + 1, e->d_xprime);

@@ -249,6 +249,9 @@ double vox_hip_time_empty_launches_graph(vox_hip_engine_t *e, int n, int grid);
  * with and without its launches; (full - skipped) / layers = what one launch adds to the chain. */
 int vox_hip_time_decoder_step_without(vox_hip_engine_t *e, int iters, int kv_len, int kind,
                                       double *full_s, double *skipped_s);
+/* Launches of k_ffn_attn12 in a decode step at this KV length (0 = the step uses k_dec_attn_fused + k_ffn_fused per layer).  With a non-zero
+ * answer, kind 6 of vox_hip_time_decoder_step_without leaves out exactly these launches. */
+int vox_hip_merged_launches_per_step(const vox_hip_engine_t *e, int kv_len);
 
 /* BASELINE config 5: quantise the decoder matrices and the tied embedding to fp8 e4m3 (one f32 scale
  * per output row) for the decode GEMVs; prefill and the encoder keep bf16.  Call after the uploads.
@@ -278,10 +281,11 @@ enum vox_hip_path {
     VOX_PATH_GEMM_PLANES      = 1u << 9,   /* large-M GEMMs on producer-split bf16 planes, LDS-DMA pipeline (k_gemm_planes) */
     VOX_PATH_FFN_FUSED        = 1u << 10,  /* decode step: the FFN block as one launch (k_ffn_fused), 2 launches per layer */
     VOX_PATH_ROWSGEMM         = 1u << 11,  /* 33 .. 128-row passes (decoder prefill, encoder flush) on the weight-streaming MFMA kernel k_rowsgemm */
+    VOX_PATH_FFN_ATTN12       = 1u << 12,  /* decode step, up to 512 keys: FFN block of layer l + attention block of layer l + 1 as ONE launch (k_ffn_attn12) */
 };
 #define VOX_PATH_ALL_BF16 (VOX_PATH_GEMM_MFMA_BF16X3 | VOX_PATH_GEMM_MFMA_F32 | VOX_PATH_GEMM_SPLITK | \
                            VOX_PATH_ATTN_ENC_MFMA | VOX_PATH_ATTN_DEC_DPP | VOX_PATH_GEMV3 | VOX_PATH_DEC_FUSED | VOX_PATH_SKINNY_ENC | \
-                           VOX_PATH_GEMM_PLANES | VOX_PATH_FFN_FUSED | VOX_PATH_ROWSGEMM)
+                           VOX_PATH_GEMM_PLANES | VOX_PATH_FFN_FUSED | VOX_PATH_ROWSGEMM | VOX_PATH_FFN_ATTN12)
 unsigned vox_hip_active_paths(const vox_hip_engine_t *e);
 
 /* The fused decode kernel (VOX_PATH_DEC_FUSED) needs its 256 workgroups co-resident; a hand-off that times out (another

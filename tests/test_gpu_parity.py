@@ -669,6 +669,36 @@ def test_fp8_fused_decode_step_matches_the_fp8_chain(vox):
     assert diff <= 2, (diff, n)
 
 
+def test_merged_ffn_attention_launch_matches_the_two_launch_path(vox):
+    """Round 4 (late): up to 512 keys the FFN block of layer l and the attention block of layer l + 1 are ONE launch (k_ffn_attn12:
+    attention block in the 12-wave shape, x'' handed over in granules).  60 s of audio = ~750 steps: the first ~470 run merged, then
+    the step switches to k_dec_attn_fused + k_ffn_fused per layer (more than 8 key slices) in the middle of the decode.  Reference =
+    the same engine with VOX_HIP_MERGE12=0 (two launches per layer throughout), its ids teacher-forced: logits equal up to the
+    summation order of the RMSNorm and of the Wo rows' K slices, argmax different at numerical near-ties only."""
+    audio = synth_speech(60.0, 99)
+    os.environ["VOX_HIP_MERGE12"] = "0"
+    try:
+        with vox.Model(model_dir("full")) as m2:
+            assert "ffn_attn12" not in m2.active_paths()[1]
+            c = m2.transcribe(audio, record_logits=800)
+    finally:
+        del os.environ["VOX_HIP_MERGE12"]
+    with vox.Model(model_dir("full")) as m:
+        assert "ffn_attn12" in m.active_paths()[1]
+        a = m.transcribe(audio, record_logits=800, force_tokens=c["tokens"])
+        assert "dec_fused" in m.active_paths()[1], "a hand-off timed out: the engine fell back to the chain"
+        free = m.transcribe(audio)
+    n = len(c["tokens"])
+    assert n > 700 and len(a["tokens"]) == n
+    k = min(len(a["logits"]), len(c["logits"]))
+    err = float(np.abs(np.asarray(a["logits"])[:k] - np.asarray(c["logits"])[:k]).max())
+    diff = int((np.asarray(a["tokens"]) != np.asarray(c["tokens"])).sum())
+    diag("merged_vs_two_launches", steps=n, logit_rows=k, max_logit_diff=err, differing_argmax=diff,
+         free_running_equal=bool(np.array_equal(np.asarray(free["tokens"]), np.asarray(c["tokens"]))))
+    assert err < 2e-4, err
+    assert diff <= 1, (diff, n)
+
+
 def test_fused_decode_step_matches_the_chain_at_long_context(vox):
     """The same comparison where the fused kernel works differently: 200 s of audio = 2500 decoder steps, KV to ~2540 -
     every member of a KV-head group runs attention (up to 32 key slices, two K/V tiles each beyond 2048 keys), Wo rows ride under

@@ -1897,8 +1897,8 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     static const int tl_layer = getenv("VOX_HIP_FUSE_TL_LAYER") ? atoi(getenv("VOX_HIP_FUSE_TL_LAYER")) : 13;
     // the 12-wave shape (k_attn12 / k_ffn_attn12) covers the short-context regime only: <= 8 key slices, bf16, DPP, no debug hooks
     static const int spread_env0 = getenv("VOX_HIP_FUSE_SPREAD") ? atoi(getenv("VOX_HIP_FUSE_SPREAD")) : -1;
-    const bool shape12 = fused && e->merge12 > 0 && e->use_ffn && !e->use_fp8 && !e->sim_on && f_ns <= 8 && spread_env0 <= 0 && e->skip_kinds == 0 &&
-                         tap_i < 0 && !e->prof_on && e->pf_when == 3 && e->pf_member_units == 0 && !getenv("VOX_HIP_FUSE_ATTN_PER_HEAD");
+    const bool shape12 = fused && e->merge12 > 0 && e->use_ffn && !e->use_fp8 && !e->sim_on && f_ns <= 8 && spread_env0 <= 0 && (e->skip_kinds & ~(1u << PK_W2)) == 0 &&
+                         tap_i < 0 && e->pf_when == 3 && e->pf_member_units == 0 && !getenv("VOX_HIP_FUSE_ATTN_PER_HEAD");
     bool attn_done = false;           // this layer's attention block ran at the end of the previous layer's launch (k_ffn_attn12)
     for (int l = 0; l < d.dec_layers; l++) {
         DecLayer &L = e->dec[l];
@@ -1959,7 +1959,14 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             tap(2 * l, xin);              // (layer 0 of a stream step builds x inside the launch above and writes it to xin)
             // (fp8 mode keeps the two launches: with half the W2 bytes the 72 KB sweep and the dot products at the end are no longer
             //  hidden - measured 1.1055 against 1.0271 ms per step, gpurun_out/r4k)
-            if (e->use_ffn && !e->use_fp8 && !e->sim_on && !(e->skip_kinds & ((1u << PK_SWIGLU) | (1u << PK_W2)))) {
+            const bool merged_here = shape12 && e->merge12 == 2 && l + 1 < d.dec_layers;
+            if (merged_here && (e->skip_kinds & (1u << PK_W2))) {      // timing experiment: the step without its k_ffn_attn12 launches
+                if (++e->fuse_epoch == 0) e->fuse_epoch = 1;
+                attn_done = true;
+                std::swap(xin, xalt);
+                continue;
+            }
+            if (e->use_ffn && !e->use_fp8 && !e->sim_on && !(e->skip_kinds & (1u << PK_SWIGLU)) && ((shape12 && e->merge12 == 2) || !(e->skip_kinds & (1u << PK_W2)))) {
                 // the whole FFN block as one launch (k_ffn_fused): x' -> ffn_norm -> silu(W1 x) * (W3 x) -> in-kernel hand-off of h -> x' + W2 h
                 FfnArgs a{};
                 a.w1 = L.w13; a.w3 = L.w13 + (size_t)DH * DD; a.w2 = L.w2; a.x = xin; a.wo_part = e->d_wo_part; a.norm_w = L.n2; a.ada = L.ada;
@@ -1967,7 +1974,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 a.gh = e->d_gh; a.epoch = e->fuse_epoch; a.err = e->d_fuse_err; a.spin_limit = 500000ull;
 
                 a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + TL_STRIDE * 1024 : nullptr;
-                if (shape12 && e->merge12 == 2 && l + 1 < d.dec_layers) {
+                if (merged_here) {
                     // k_ffn_attn12: this FFN block and the NEXT layer's attention block in one launch; x'' goes over in granules
                     DecLayer &N = e->dec[l + 1];
                     DecFuseArgs b{};
@@ -1984,9 +1991,11 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                     }
                     hipLaunchKernelGGL(k_ffn_attn12, dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a, b, e->d_gx);
                     attn_done = true;
-                } else
-                hipLaunchKernelGGL(k_ffn_fused, dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a);
-                prof_mark(e, PK_SWIGLU);
+                    prof_mark(e, PK_W2);          // (the per-kernel table lists the merged launches in the slot the fused FFN path leaves empty)
+                } else {
+                    hipLaunchKernelGGL(k_ffn_fused, dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a);
+                    prof_mark(e, PK_SWIGLU);
+                }
                 tap(2 * l + 1, e->d_xprime);
                 std::swap(xin, xalt);
                 continue;
@@ -2643,11 +2652,23 @@ extern "C" int vox_hip_time_decoder_step_without(vox_hip_engine_t *e, int iters,
     const double a = vox_hip_time_decoder_step(e, iters, kv_len);
     e->skip_kinds = 1u << kind;
     if (kind == PK_SWIGLU && e->use_fused && e->use_ffn && !e->use_fp8) e->skip_kinds |= 1u << PK_W2;      // k_ffn_fused is ONE launch: w1;w3 and w2 go together
+    // (kind 6 alone, where vox_hip_merged_launches_per_step() > 0: the step without its k_ffn_attn12 launches)
     const double b = vox_hip_time_decoder_step(e, iters, kv_len);
     e->skip_kinds = 0;
     if (full_s) *full_s = a;
     if (skipped_s) *skipped_s = b;
     return (a > 0 && b > 0) ? 0 : -1;
+}
+
+static bool merged_static_ok(const vox_hip_engine *e) {
+    const vox_hip_dims_t &d = e->d;
+    const bool fast = e->use_gemv2 && d.dec_dim == 3072 && e->dec_qd == 4096 && e->dec_kvd == 1024 && d.dec_hidden == 9216;
+    return fast && e->use_fused && e->use_dpp && e->merge12 == 2 && e->use_ffn && !e->use_fp8 && !e->sim_on && e->pf_when == 3 && e->pf_member_units == 0;
+}
+extern "C" int vox_hip_merged_launches_per_step(const vox_hip_engine_t *e, int kv_len) {
+    if (!e || !merged_static_ok(e)) return 0;
+    const int kl = std::min(std::max(kv_len, 1), e->d.dec_window);
+    return (kl + 63) / 64 <= 8 ? e->d.dec_layers - 1 : 0;
 }
 
 // Per-kernel average durations of the decode step, measured with HIP events recorded on the
@@ -3037,6 +3058,7 @@ extern "C" unsigned vox_hip_active_paths(const vox_hip_engine_t *e) {
     if (e->use_planes && e->use_mfma && e->use_bf16x3) m |= VOX_PATH_GEMM_PLANES;
     if (fast_geom && e->use_fused && e->use_dpp && e->use_ffn && !e->use_fp8) m |= VOX_PATH_FFN_FUSED;
     if (e->use_rowsgemm && e->use_mfma) m |= VOX_PATH_ROWSGEMM;
+    if (merged_static_ok(e)) m |= VOX_PATH_FFN_ATTN12;
     return m;
 }
 

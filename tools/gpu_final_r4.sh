@@ -31,7 +31,7 @@ VOX_HIP_FUSE_TL=$O/fuse_tl_232.txt python tools/fuse_tl_kv.py 232 > $O/tl232.log
 VOX_HIP_FUSE_TL=$O/fuse_tl_1900.txt python tools/fuse_tl_kv.py 1900 > $O/tl1900.log 2>&1; ( cat $O/tl1900.log | tail -1; python tools/fuse_timeline.py $O/fuse_tl_1900.txt ) > $O/fuse_timeline_kv1900.txt 2>&1
 head -12 $O/fuse_timeline_kv232.txt; rm -f $O/fuse_tl_232.txt $O/fuse_tl_1900.txt
 python tools/dec_step_probe.py full 40 2>&1 | tail -1 | tee $O/decode_step_by_kv.txt
-timeout 900 python tools/pf_sweep.py --reps 4 --iters 100 --kv 232,600,1900 round4: "no_ffn_fused:VOX_HIP_NO_FFN_FUSED=1" "no_prefetch:VOX_HIP_PF=0,0,0" \
+timeout 900 python tools/pf_sweep.py --reps 4 --iters 100 --kv 232,600,1900 round4: "two_launches_per_layer:VOX_HIP_MERGE12=0" "no_ffn_fused:VOX_HIP_NO_FFN_FUSED=1" "no_prefetch:VOX_HIP_PF=0,0,0" \
     "round3:VOX_HIP_NO_FFN_FUSED=1;VOX_HIP_PF=0,0,0" 2>&1 | tee $O/decode_ab.txt | tail -6
 echo "== few-rows encoder layer: time by rows, timeline of its GEMM launches"
 VOX_HIP_ENC_TL=$O/enc_tl_25.txt timeout 300 python tools/enc_rows_probe.py 25,1,8,16,32 750 30 2>&1 | tail -1 | tee $O/enc_rows.txt

@@ -1898,7 +1898,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     // the 12-wave shape (k_attn12 / k_ffn_attn12) covers the short-context regime only: <= 8 key slices, bf16, DPP, no debug hooks
     static const int spread_env0 = getenv("VOX_HIP_FUSE_SPREAD") ? atoi(getenv("VOX_HIP_FUSE_SPREAD")) : -1;
     const bool shape12 = fused && e->merge12 > 0 && e->use_ffn && !e->use_fp8 && !e->sim_on && f_ns <= 8 && spread_env0 <= 0 && (e->skip_kinds & ~(1u << PK_W2)) == 0 &&
-                         tap_i < 0 && e->pf_when == 3 && e->pf_member_units == 0 && !getenv("VOX_HIP_FUSE_ATTN_PER_HEAD");
+                         tap_i < 0 && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0)) && !getenv("VOX_HIP_FUSE_ATTN_PER_HEAD");
     bool attn_done = false;           // this layer's attention block ran at the end of the previous layer's launch (k_ffn_attn12)
     for (int l = 0; l < d.dec_layers; l++) {
         DecLayer &L = e->dec[l];
@@ -2663,7 +2663,7 @@ extern "C" int vox_hip_time_decoder_step_without(vox_hip_engine_t *e, int iters,
 static bool merged_static_ok(const vox_hip_engine *e) {
     const vox_hip_dims_t &d = e->d;
     const bool fast = e->use_gemv2 && d.dec_dim == 3072 && e->dec_qd == 4096 && e->dec_kvd == 1024 && d.dec_hidden == 9216;
-    return fast && e->use_fused && e->use_dpp && e->merge12 == 2 && e->use_ffn && !e->use_fp8 && !e->sim_on && e->pf_when == 3 && e->pf_member_units == 0;
+    return fast && e->use_fused && e->use_dpp && e->merge12 == 2 && e->use_ffn && !e->use_fp8 && !e->sim_on && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0));
 }
 extern "C" int vox_hip_merged_launches_per_step(const vox_hip_engine_t *e, int kv_len) {
     if (!e || !merged_static_ok(e)) return 0;

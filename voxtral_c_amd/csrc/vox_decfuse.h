@@ -968,9 +968,9 @@ struct W2xArgs {
 constexpr int W2X_THREADS = 768, W2X_K = 9216;
 constexpr int W2X_LDS_BYTES = W2X_K * 4 + 64;
 
+// gx (optional): x'' also leaves as {epoch, value} granules (k_w2x_attn12: the attention block of the next layer in the same launch)
 template <bool W8>
-__global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void w2x_body(const W2xArgs &a, float *smem, u64 *gx, unsigned gx_epoch) {
     float *hs = smem;                    // [9216]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1016,8 +1016,16 @@ __global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
 #undef W2_DOT
     acc = df_wave_sum<true>(acc);
     if constexpr (W8) acc *= a.s2[row];
-    if (lane == 0) a.x[row] = resid + acc;
+    if (lane == 0) {
+        a.x[row] = resid + acc;
+        if (gx) df_store_granule(gx + row, gx_epoch, resid + acc);
+    }
     tl_end(a.tl, tl0);
+}
+template <bool W8>
+__global__ __launch_bounds__(W2X_THREADS, 1) void k_gemv_w2x(const W2xArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    w2x_body<W8>(a, smem, nullptr, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1275,7 +1283,7 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int DA12_THREADS = 768, DA12_WAVES = 12, DA12_NWO = 12;
 constexpr int DA12_LDS_BYTES = 2 * DF_D * 4 + 2 * DF_TILE_BYTES + 1024 + 512;
-template <bool XG>
+template <bool XG, bool W8 = false>
 __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned char *smem_raw, const u64 *gx, unsigned x_epoch) {
     float *xs = reinterpret_cast<float *>(smem_raw);                           // [3072] x, then [3072] norm weights (contiguous)
     float *nw = xs + DF_D;
@@ -1291,14 +1299,19 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
     const unsigned long long tl0 = tl_begin(a.tl);
     DF_MARK(0);
     // ---- this workgroup's 24 projection rows: wave w streams rows 2w, 2w+1 ----------------------------------------------------------
+    constexpr int NPW = W8 ? 3 : 6;               // 1 KiB pieces per projection row (fp8: 16 weights per lane and piece)
+    constexpr int XSP = W8 ? 1 : 2;               // XG: pieces requested in front of the x'' sweep
+    constexpr int NWL = W8 ? 6 : DA12_NWO;        // Wo loads per wave (fp8: two rows per load, as in k_dec_attn_fused<W8>)
     const unsigned char *rp[2];
+    int prow[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const int lr = 2 * wave + i;
         const int row = lr < 16 ? DF_NQ * g + 16 * j + lr
                       : lr < 20 ? DF_DQ + DF_HD * g + 4 * j + (lr - 16)
                                 : DF_DQ + DF_DKV + DF_HD * g + 4 * j + (lr - 20);
-        rp[i] = reinterpret_cast<const unsigned char *>(a.wqkv) + (size_t)row * (DF_D * 2) + lane * 16;
+        prow[i] = row;
+        rp[i] = reinterpret_cast<const unsigned char *>(a.wqkv) + (size_t)row * (W8 ? DF_D : DF_D * 2) + lane * 16;
     }
     const int ns = a.nsplit;                                     // <= 8 here
     int lo = pos - a.window + 1; if (lo < 0) lo = 0;
@@ -1316,36 +1329,37 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
     DF_MARK(11);
     __builtin_amdgcn_s_barrier();          // every wave's share of the vectors is in the CU's queue before anybody's weights (see k_dec_attn_fused)
     DF_MARK(12);
-    uint4 w[2][6];
+    uint4 w[2][NPW];
     u64 gxv[4] = {0, 0, 0, 0};
     if constexpr (XG) {
 #pragma unroll
-        for (int c = 0; c < 2; c++)
+        for (int c = 0; c < XSP; c++)
 #pragma unroll
             for (int i = 0; i < 2; i++) w[i][c] = ld_stream(reinterpret_cast<const uint4 *>(rp[i] + c * 1024));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 4; u++) gxv[u] = df_load_granule(gx + u * DA12_THREADS + tid);      // back when the first two pieces are
+        for (int u = 0; u < 4; u++) gxv[u] = df_load_granule(gx + u * DA12_THREADS + tid);      // back when the first pieces are
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 2; c < 6; c++)
+        for (int c = XSP; c < NPW; c++)
 #pragma unroll
             for (int i = 0; i < 2; i++) w[i][c] = ld_stream(reinterpret_cast<const uint4 *>(rp[i] + c * 1024));
     } else {
 #pragma unroll
-        for (int c = 0; c < 6; c++)
+        for (int c = 0; c < NPW; c++)
 #pragma unroll
             for (int i = 0; i < 2; i++) w[i][c] = ld_stream(reinterpret_cast<const uint4 *>(rp[i] + c * 1024));
     }
     __builtin_amdgcn_sched_barrier(0);
     // Wo rows (row r = Wo[r][512 g .. 512 g + 511] = 1 KiB): the 32 - ns non-members share the group's 3072 rows, <= 12 per wave
-    uint4 wv[DA12_NWO];
+    uint4 wv[NWL];
+    float wo_sc[W8 ? NWL : 1];
     const int nb = DF_BPG - ns, rpb = ((DF_D + nb - 1) / nb + 11) / 12 * 12;
     const int wo_rpw = rpb / 12;
     const int wo_row0 = att_block ? DF_D : (j - ns) * rpb + wave * wo_rpw;
     const int wo_n = max(0, min(wo_rpw, DF_D - wo_row0));
     const int wo_rmax = wo_n > 0 ? wo_row0 + wo_n - 1 : DF_D - 1;
-    const unsigned char *wo_base = reinterpret_cast<const unsigned char *>(a.wo) + (size_t)(DF_NQ * g) * 2 + lane * 16;
+    const unsigned char *wo_base = reinterpret_cast<const unsigned char *>(a.wo) + (size_t)(DF_NQ * g) * (W8 ? 1 : 2) + (W8 ? (lane & 31) : lane) * 16;
     const int tile_slot0 = __builtin_amdgcn_readfirstlane(att_block ? s_lo % a.kv_cap : 0);
     DF_MARK(1);
     // ---- the activation vector -----------------------------------------------------------------------------------------------------
@@ -1369,9 +1383,9 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) xs[u * DA12_THREADS + tid] = __uint_as_float((unsigned)gxv[u]);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // the vector DMAs are older than everything else; pieces 2..5 may still stream
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NPW - XSP)) : "memory");    // the vector DMAs are older than everything else; the later pieces may still stream
     } else {
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // only the 12 weight loads are younger than the activation DMAs
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");             // only the weight loads are younger than the activation DMAs
     }
     __syncthreads();
     DF_MARK(2);
@@ -1399,11 +1413,19 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
     }
     float acc[2] = {0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 6; c++) {
-        const float4 x0 = *reinterpret_cast<const float4 *>(xs + (c * 64 + lane) * 8);
-        const float4 x1 = *reinterpret_cast<const float4 *>(xs + (c * 64 + lane) * 8 + 4);
+    for (int c = 0; c < NPW; c++) {
+        if constexpr (W8) {
+            const float *xp = xs + (c * 64 + lane) * 16;
+            const float4 x0 = *reinterpret_cast<const float4 *>(xp), x1 = *reinterpret_cast<const float4 *>(xp + 4);
+            const float4 x2 = *reinterpret_cast<const float4 *>(xp + 8), x3 = *reinterpret_cast<const float4 *>(xp + 12);
 #pragma unroll
-        for (int i = 0; i < 2; i++) acc[i] = dot8_bf16(w[i][c], x0, x1, acc[i]);
+            for (int i = 0; i < 2; i++) acc[i] = dot16_fp8(w[i][c], x0, x1, x2, x3, acc[i]);
+        } else {
+            const float4 x0 = *reinterpret_cast<const float4 *>(xs + (c * 64 + lane) * 8);
+            const float4 x1 = *reinterpret_cast<const float4 *>(xs + (c * 64 + lane) * 8 + 4);
+#pragma unroll
+            for (int i = 0; i < 2; i++) acc[i] = dot8_bf16(w[i][c], x0, x1, acc[i]);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("" : "+v"(acc[0]), "+v"(acc[1]) :: "memory");     // the tile DMAs below stay below the dot products
@@ -1413,7 +1435,8 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
     }
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-        const float sres = df_wave_sum<true>(acc[i]);
+        float sres = df_wave_sum<true>(acc[i]);
+        if constexpr (W8) sres *= a.sqkv[prow[i]];                  // per-row dequantisation scale
         if (lane == 0) red[16 + 2 * wave + i] = sres;
     }
     DF_MARK(4);
@@ -1447,7 +1470,15 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int i = 0; i < DA12_NWO; i++) wv[i] = ld_stream(reinterpret_cast<const uint4 *>(wo_base + (size_t)min(wo_row0 + i, wo_rmax) * (DF_DQ * 2)));
+        for (int i = 0; i < NWL; i++) {
+            if constexpr (W8) {      // load i = rows wo_row0 + 2 i (lanes 0-31) and + 2 i + 1 (lanes 32-63), 16 weights per lane
+                const int r = min(wo_row0 + 2 * i + (lane >> 5), wo_rmax);
+                wv[i] = ld_stream(reinterpret_cast<const uint4 *>(wo_base + (size_t)r * DF_DQ));
+                wo_sc[i] = a.so[r];
+            } else {
+                wv[i] = ld_stream(reinterpret_cast<const uint4 *>(wo_base + (size_t)min(wo_row0 + i, wo_rmax) * (DF_DQ * 2)));
+            }
+        }
     }
     float *qs = xs;                        // [512] the group's q
     float *kvn = xs + 512;                 // [256] this step's k | v of head g
@@ -1589,13 +1620,30 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the Wo rows (and the prefetch DMAs) have landed
         __syncthreads();
         DF_MARK(9);
+        if constexpr (W8) {
+            if (wo_n > 0) {
+                // lane l holds 16 weights of row wo_row0 + 2 i + (l >> 5), columns 16 (l & 31) .. + 15 of the group's 512
+                const float *xp = att + (lane & 31) * 16;
+                const float4 x0 = *reinterpret_cast<const float4 *>(xp), x1 = *reinterpret_cast<const float4 *>(xp + 4);
+                const float4 x2 = *reinterpret_cast<const float4 *>(xp + 8), x3 = *reinterpret_cast<const float4 *>(xp + 12);
+                float sums[NWL];
+#pragma unroll
+                for (int i = 0; i < NWL; i++) sums[i] = row16_sum<true>(dot16_fp8(wv[i], x0, x1, x2, x3, 0.f));
+#pragma unroll
+                for (int i = 0; i < NWL; i++) {
+                    const float o = __shfl_xor(sums[i], 16, 64);
+                    const int row = wo_row0 + 2 * i + (lane >> 5);
+                    if ((lane & 31) == 0 && row < wo_row0 + wo_n) a.wo_part[(size_t)g * DF_D + row] = (sums[i] + o) * wo_sc[i];
+                }
+            }
+        } else
         if (wo_n > 0) {
             // the wave's <= 12 row sums as ONE transposed reduction through LDS (see k_dec_attn_fused)
             const float4 x0 = *reinterpret_cast<const float4 *>(att + lane * 8);
             const float4 x1 = *reinterpret_cast<const float4 *>(att + lane * 8 + 4);
             float *wr = reinterpret_cast<float *>(tiles) + wave * (16 * 68);
 #pragma unroll
-            for (int i = 0; i < DA12_NWO; i++) wr[i * 68 + lane] = dot8_bf16(wv[i], x0, x1, 0.f);
+            for (int i = 0; i < NWL; i++) wr[i * 68 + lane] = dot8_bf16(wv[i], x0, x1, 0.f);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1619,6 +1667,13 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
 __global__ __launch_bounds__(DA12_THREADS, 1) void k_attn12(const DecFuseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem12[];
     df_attn12_body<false>(a, smem12, nullptr, 0u);
+}
+// fp8 mode: the W2 launch of layer l, then the attention block of layer l + 1 (fp8 projection / Wo rows), one launch
+__global__ __launch_bounds__(W2X_THREADS, 1) void k_w2x_attn12(const W2xArgs f, const DecFuseArgs a, u64 *gx, unsigned gx_epoch) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    w2x_body<true>(f, smem, gx, gx_epoch);
+    __syncthreads();
+    df_attn12_body<true, true>(a, reinterpret_cast<unsigned char *>(smem), gx, gx_epoch);
 }
 // FFN block of layer l, then the attention block of layer l + 1, one launch (fa = the attention block's arguments)
 __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_attn12(const FfnArgs f, const DecFuseArgs a, u64 *gx) {

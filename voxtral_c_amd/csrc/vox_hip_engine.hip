@@ -680,6 +680,7 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  hipFuncSetAttribute((const void *)k_gemv_w2x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_ffn_fused, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, DA12_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_w2x_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, DA12_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_ffn_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess &&
                  dalloc(e, &e->d_gx, (size_t)DF_D) == 0 && hipMemset(e->d_gx, 0, (size_t)DF_D * 8) == hipSuccess;
             if (!ok) { (void)hipGetLastError(); fprintf(stderr, "vox_hip: fused decode kernels unavailable; launch-per-GEMV chain\n"); }
@@ -1899,6 +1900,9 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     static const int spread_env0 = getenv("VOX_HIP_FUSE_SPREAD") ? atoi(getenv("VOX_HIP_FUSE_SPREAD")) : -1;
     const bool shape12 = fused && e->merge12 > 0 && e->use_ffn && !e->use_fp8 && !e->sim_on && f_ns <= 8 && spread_env0 <= 0 && (e->skip_kinds & ~(1u << PK_W2)) == 0 &&
                          tap_i < 0 && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0)) && !getenv("VOX_HIP_FUSE_ATTN_PER_HEAD");
+    // fp8 mode: the W2 launch of layer l and the (fp8) attention block of layer l + 1 as one launch, same regime
+    const bool shape12_f8 = fused && e->merge12 == 2 && e->use_fp8 && !e->fp8_attn_bf16 && !e->sim_on && f_ns <= 8 && spread_env0 <= 0 && e->skip_kinds == 0 &&
+                            tap_i < 0 && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0)) && !getenv("VOX_HIP_FUSE_ATTN_PER_HEAD") && !getenv("VOX_HIP_OLD_W2");
     bool attn_done = false;           // this layer's attention block ran at the end of the previous layer's launch (k_ffn_attn12)
     for (int l = 0; l < d.dec_layers; l++) {
         DecLayer &L = e->dec[l];
@@ -2028,7 +2032,26 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                     W2xArgs a{};
                     a.w2 = e->sim_on ? L.w2_s : L.w2; a.h = e->dh; a.x = xalt;        // x' += h . W2^T, in place (one wave per row)
                     a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + 2 * TL_STRIDE * 1024 : nullptr;
-                    if (e->use_fp8) {
+                    if (e->use_fp8 && shape12_f8 && l + 1 < d.dec_layers) {
+                        a.w2 = reinterpret_cast<const uint16_t *>(L.w28); a.s2 = L.s2;
+                        DecLayer &N = e->dec[l + 1];
+                        DecFuseArgs b{};
+                        b.wqkv = reinterpret_cast<const uint16_t *>(N.wqkv8); b.wo = reinterpret_cast<const uint16_t *>(N.wo8); b.sqkv = N.sqkv; b.so = N.so;
+                        b.x = xalt; b.norm_w = N.n1; b.eps = d.dec_eps; b.inv_freq = e->dec_inv_freq;
+                        b.kring = N.kring; b.vring = N.vring; b.kv_cap = e->dec_ring_cap; b.pos = kv_pos; b.window = d.dec_window; b.scale = scale;
+                        b.gq = e->d_gq; b.gp = e->d_gp; b.wo_part = e->d_wo_part;
+                        const unsigned x_epoch = e->fuse_epoch;
+                        if (++e->fuse_epoch == 0) e->fuse_epoch = 1;
+                        b.epoch = e->fuse_epoch; b.split_keys = f_split; b.nsplit = f_ns;
+                        b.err = e->d_fuse_err; b.spin_limit = 500000ull; b.attn_gqa = 1;
+                        b.tl = (l + 1 == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl : nullptr;
+                        if (e->pf_units > 0) {
+                            b.pf.w = reinterpret_cast<const unsigned char *>(N.w138); b.pf.row_bytes = DD; b.pf.rows_m = DH;
+                            b.pf.units = std::min(e->pf_units, 72 * 3); b.pf.member_units = 0; b.pf.when = 3;
+                        }
+                        hipLaunchKernelGGL(k_w2x_attn12, dim3(256), dim3(W2X_THREADS), DA12_LDS_BYTES, s, a, b, e->d_gx, x_epoch);
+                        attn_done = true;
+                    } else if (e->use_fp8) {
                         a.w2 = reinterpret_cast<const uint16_t *>(L.w28); a.s2 = L.s2;
                         hipLaunchKernelGGL(k_gemv_w2x<true>, dim3(256), dim3(W2X_THREADS), W2X_LDS_BYTES, s, a);
                     } else {

@@ -1901,7 +1901,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     const bool shape12 = fused && e->merge12 > 0 && e->use_ffn && !e->use_fp8 && !e->sim_on && f_ns <= 8 && spread_env0 <= 0 && (e->skip_kinds & ~(1u << PK_W2)) == 0 &&
                          tap_i < 0 && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0)) && !getenv("VOX_HIP_FUSE_ATTN_PER_HEAD");
     // fp8 mode: the W2 launch of layer l and the (fp8) attention block of layer l + 1 as one launch, same regime
-    const bool shape12_f8 = fused && e->merge12 == 2 && e->use_fp8 && !e->fp8_attn_bf16 && !e->sim_on && f_ns <= 8 && spread_env0 <= 0 && e->skip_kinds == 0 &&
+    const bool shape12_f8 = fused && e->merge12 == 2 && e->use_fp8 && !e->fp8_attn_bf16 && !e->sim_on && f_ns <= 8 && spread_env0 <= 0 && (e->skip_kinds & ~(1u << PK_SWIGLU)) == 0 &&
                             tap_i < 0 && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0)) && !getenv("VOX_HIP_FUSE_ATTN_PER_HEAD") && !getenv("VOX_HIP_OLD_W2");
     bool attn_done = false;           // this layer's attention block ran at the end of the previous layer's launch (k_ffn_attn12)
     for (int l = 0; l < d.dec_layers; l++) {

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Summarise a VOX_HIP_FUSE_TL dump (per-workgroup start/end stamps of the three layer-13 launches of a decoder step):
-start skew, tails, per-XCD finishing times, the gaps between launches.  Usage: fuse_timeline.py dump.txt"""
+"""Summarise a VOX_HIP_FUSE_TL dump (per-workgroup start/end stamps of layer 13's blocks in a decoder step):
+start skew, tails, per-XCD finishing times, the gaps between launches.  Usage: fuse_timeline.py dump.txt
+Record 0 = the attention block (k_dec_attn_fused, or df_attn12_body inside k_ffn_attn12: then its "entry" is the moment a workgroup
+leaves the previous layer's FFN block and there is no launch boundary in front of it), record 1 = the FFN block (k_ffn_fused / ffn_body
+inside k_ffn_attn12, or k_gemv_w13x), record 2 = the separate W2 launch where there is one.  Times in us from the first attention entry."""
 import sys
 import numpy as np
 
 rows = np.loadtxt(sys.argv[1], comments="#")
-names = {0: "k_dec_attn_fused", 1: "k_gemv_w13x", 2: "k_gemv3 W2"}
+names = {0: "attention block (k_dec_attn_fused / df_attn12_body)", 1: "FFN block (k_ffn_fused / ffn_body / k_gemv_w13x)", 2: "W2 launch"}
 prev_end = None
 for k in (0, 1, 2):
     r = rows[rows[:, 0] == k]

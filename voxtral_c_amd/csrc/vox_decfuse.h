@@ -1290,13 +1290,13 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
 // the sweep (4 loads per thread) is queued behind the first two pieces of the projection rows.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int DA12_THREADS = 768, DA12_WAVES = 12, DA12_NWO = 12;
-constexpr int DA12_LDS_BYTES = 2 * DF_D * 4 + 2 * DF_TILE_BYTES + 1024 + 512;
+constexpr int DA12_LDS_BYTES = 2 * DF_D * 4 + 4 * DF_TILE_BYTES + 1024 + 512;      // [xs | nw], K/V tiles double buffered, inv_freq, red
 template <bool XG, bool W8 = false>
 __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned char *smem_raw, const u64 *gx, unsigned x_epoch) {
     float *xs = reinterpret_cast<float *>(smem_raw);                           // [3072] x, then [3072] norm weights (contiguous)
     float *nw = xs + DF_D;
-    unsigned char *tiles = smem_raw + 2 * DF_D * 4;                            // [K tile | V tile]; later the Wo reduction scratch
-    float *frq = reinterpret_cast<float *>(tiles + 2 * DF_TILE_BYTES);         // [256] inv_freq (64 valid)
+    unsigned char *tiles = smem_raw + 2 * DF_D * 4;                            // [2 buffers][K tile | V tile]; later the Wo reduction scratch
+    float *frq = reinterpret_cast<float *>(tiles + 4 * DF_TILE_BYTES);         // [256] inv_freq (64 valid)
     float *red = frq + 256;                                                    // [128]: wave sums, the 24 row results
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1504,78 +1504,92 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
             if (tid < 256) kvn[tid] = (unsigned)(gv1 >> 32) == epoch ? __uint_as_float((unsigned)gv1) : df_wait_granule(gq + 512 + tid, epoch, a, 1u);
         }
         DF_MARK(6);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the tile has landed
-        __syncthreads();
-        unsigned char *kt = tiles, *vt = tiles + DF_TILE_BYTES;
-        const int t0 = s_lo;
-        if (t0 + DF_TILE > pos && t0 <= pos) {
-            // this step's own K/V row is not visible in the ring to other CUs yet: patch it in from the hand-off
-            const int key = pos - t0;
-            if (tid < 32) *reinterpret_cast<float4 *>(kt + key * 512 + ((tid ^ (key & 31)) << 4)) = *reinterpret_cast<const float4 *>(kvn + tid * 4);
-            else if (tid < 64) *reinterpret_cast<float4 *>(vt + key * 512 + ((tid - 32) << 4)) = *reinterpret_cast<const float4 *>(kvn + DF_HD + (tid - 32) * 4);
-            __syncthreads();
-        }
-        DF_MARK(11);
-        // scores: wave (0..7) -> 16 of the 128 dims for all 4 heads, lane -> key; the 8 partial sums per (head, key) meet in LDS
-        if (wave < 8) {
-            const unsigned char *krow = kt + lane * 512;
-            float s4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int ch = 4 * wave + c;
-                const float4 kv4 = *reinterpret_cast<const float4 *>(krow + ((ch ^ (lane & 31)) << 4));
-#pragma unroll
-                for (int hh = 0; hh < 4; hh++) {
-                    const float4 q4 = *reinterpret_cast<const float4 *>(qs + hh * DF_HD + ch * 4);
-                    s4[hh] = fmaf(q4.x, kv4.x, s4[hh]); s4[hh] = fmaf(q4.y, kv4.y, s4[hh]);
-                    s4[hh] = fmaf(q4.z, kv4.z, s4[hh]); s4[hh] = fmaf(q4.w, kv4.w, s4[hh]);
-                }
-            }
-#pragma unroll
-            for (int hh = 0; hh < 4; hh++) sc8[(hh * 8 + wave) * 64 + lane] = s4[hh];
-        }
-        __syncthreads();
-        DF_MARK(12);
-        if (wave < 4) {   // one wave per head: softmax numerators over this slice's keys (one tile: running max / sum start here)
-            float sv = 0.f;
-#pragma unroll
-            for (int w8 = 0; w8 < 8; w8++) sv += sc8[(wave * 8 + w8) * 64 + lane];
-            sv *= a.scale;
-            if (t0 + lane > s_hi) sv = -INFINITY;
-            const float m_new = fmaxf(-1e30f, df_wave_max<true>(sv));
-            const float p = expf(sv - m_new);
-            const float l_new = df_wave_sum<true>(p);          // (0 * exp(-1e30 - m) + sum, as the tile loop of k_dec_attn_fused computes it)
-            pt[wave * 64 + lane] = p;
-            if (lane == 0) { cr[4 + wave] = m_new; cr[8 + wave] = l_new; }
-        }
-        __syncthreads();
+        // ---- attention over this workgroup's key slice: 64-key tiles, double buffered, online softmax across tiles (one tile up to 512 keys) ----
+        const int n_tiles = (s_hi - s_lo + DF_TILE) / DF_TILE;
         const int ho = (tid >> 7) & 3, dd = tid & 127;
-        if (tid < 512) {  // quarter sums: keys 16 kq .. 16 kq + 15 of the tile, dim dd, all 4 heads (only the valid keys)
-            const int kq = tid >> 7;
-            const float *vcol = reinterpret_cast<const float *>(vt) + dd;
-            const int nv = min(DF_TILE, s_hi - t0 + 1);
-            float a4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int k0 = 16 * kq + 4 * i;
-                float v[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) v[u] = k0 + u < nv ? vcol[(k0 + u) * 128] : 0.f;
-#pragma unroll
-                for (int hh = 0; hh < 4; hh++) {
-                    const float4 p4 = *reinterpret_cast<const float4 *>(pt + hh * 64 + k0);
-                    a4[hh] = fmaf(p4.x, v[0], a4[hh]); a4[hh] = fmaf(p4.y, v[1], a4[hh]);
-                    a4[hh] = fmaf(p4.z, v[2], a4[hh]); a4[hh] = fmaf(p4.w, v[3], a4[hh]);
-                }
+        float o_acc = 0.f;
+        if (tid < 4) { cr[4 + tid] = -1e30f; cr[8 + tid] = 0.f; }
+        for (int ti = 0; ti < n_tiles; ti++) {
+            unsigned char *kt = tiles + (ti & 1) * 2 * DF_TILE_BYTES, *vt = kt + DF_TILE_BYTES;
+            const int t0 = s_lo + ti * DF_TILE;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this tile has landed
+            __syncthreads();
+            if (ti + 1 < n_tiles && wave < 8)                         // next tile into the other buffer, under this tile's math
+                df_tile_dma(a, g, t0 + DF_TILE, s_hi, lds_addr(tiles + ((ti + 1) & 1) * 2 * DF_TILE_BYTES),
+                            lds_addr(tiles + ((ti + 1) & 1) * 2 * DF_TILE_BYTES + DF_TILE_BYTES), wave, lane);
+            if (t0 + DF_TILE > pos && t0 <= pos) {
+                // this step's own K/V row is not visible in the ring to other CUs yet: patch it in from the hand-off
+                const int key = pos - t0;
+                if (tid < 32) *reinterpret_cast<float4 *>(kt + key * 512 + ((tid ^ (key & 31)) << 4)) = *reinterpret_cast<const float4 *>(kvn + tid * 4);
+                else if (tid < 64) *reinterpret_cast<float4 *>(vt + key * 512 + ((tid - 32) << 4)) = *reinterpret_cast<const float4 *>(kvn + DF_HD + (tid - 32) * 4);
+                __syncthreads();
             }
+            if (ti == 0) DF_MARK(11);
+            // scores: wave (0..7) -> 16 of the 128 dims for all 4 heads, lane -> key; the 8 partial sums per (head, key) meet in LDS
+            if (wave < 8) {
+                const unsigned char *krow = kt + lane * 512;
+                float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int hh = 0; hh < 4; hh++) sc8[(kq * 4 + hh) * DF_HD + dd] = a4[hh];
+                for (int c = 0; c < 4; c++) {
+                    const int ch = 4 * wave + c;
+                    const float4 kv4 = *reinterpret_cast<const float4 *>(krow + ((ch ^ (lane & 31)) << 4));
+#pragma unroll
+                    for (int hh = 0; hh < 4; hh++) {
+                        const float4 q4 = *reinterpret_cast<const float4 *>(qs + hh * DF_HD + ch * 4);
+                        s4[hh] = fmaf(q4.x, kv4.x, s4[hh]); s4[hh] = fmaf(q4.y, kv4.y, s4[hh]);
+                        s4[hh] = fmaf(q4.z, kv4.z, s4[hh]); s4[hh] = fmaf(q4.w, kv4.w, s4[hh]);
+                    }
+                }
+#pragma unroll
+                for (int hh = 0; hh < 4; hh++) sc8[(hh * 8 + wave) * 64 + lane] = s4[hh];
+            }
+            __syncthreads();
+            if (ti == 0) DF_MARK(12);
+            if (wave < 4) {   // one wave per head: online softmax over this tile's keys
+                float sv = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; w8++) sv += sc8[(wave * 8 + w8) * 64 + lane];
+                sv *= a.scale;
+                if (t0 + lane > s_hi) sv = -INFINITY;
+                const float m_old = cr[4 + wave], l_old = cr[8 + wave];
+                const float m_new = fmaxf(m_old, df_wave_max<true>(sv));
+                const float p = expf(sv - m_new);
+                const float corr = expf(m_old - m_new);
+                const float l_new = l_old * corr + df_wave_sum<true>(p);
+                pt[wave * 64 + lane] = p;
+                if (lane == 0) { cr[wave] = corr; cr[4 + wave] = m_new; cr[8 + wave] = l_new; }
+            }
+            __syncthreads();
+            if (tid < 512) {  // quarter sums: keys 16 kq .. 16 kq + 15 of the tile, dim dd, all 4 heads (only the valid keys)
+                const int kq = tid >> 7;
+                const float *vcol = reinterpret_cast<const float *>(vt) + dd;
+                const int nv = min(DF_TILE, s_hi - t0 + 1);
+                float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int k0 = 16 * kq + 4 * i;
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = k0 + u < nv ? vcol[(k0 + u) * 128] : 0.f;
+#pragma unroll
+                    for (int hh = 0; hh < 4; hh++) {
+                        const float4 p4 = *reinterpret_cast<const float4 *>(pt + hh * 64 + k0);
+                        a4[hh] = fmaf(p4.x, v[0], a4[hh]); a4[hh] = fmaf(p4.y, v[1], a4[hh]);
+                        a4[hh] = fmaf(p4.z, v[2], a4[hh]); a4[hh] = fmaf(p4.w, v[3], a4[hh]);
+                    }
+                }
+#pragma unroll
+                for (int hh = 0; hh < 4; hh++) sc8[(kq * 4 + hh) * DF_HD + dd] = a4[hh];
+            }
+            __syncthreads();
+            if (tid < 512) {
+                const float accv = (sc8[(0 * 4 + ho) * DF_HD + dd] + sc8[(1 * 4 + ho) * DF_HD + dd]) +
+                                   (sc8[(2 * 4 + ho) * DF_HD + dd] + sc8[(3 * 4 + ho) * DF_HD + dd]);
+                o_acc = o_acc * cr[ho] + accv;
+            }
         }
         __syncthreads();
         if (tid < 512) {
-            const float accv = (sc8[(0 * 4 + ho) * DF_HD + dd] + sc8[(1 * 4 + ho) * DF_HD + dd]) +
-                               (sc8[(2 * 4 + ho) * DF_HD + dd] + sc8[(3 * 4 + ho) * DF_HD + dd]);
-            const float o_acc = 0.f * 0.f + accv;              // (o_acc * corr + accv with o_acc = 0)
             u64 *mine = gp + (size_t)j * DF_GP;
             df_store_granule(mine + ho * DF_HD + dd, epoch, o_acc);
             if (dd == 0) { df_store_granule(mine + 4 * DF_HD + 2 * ho, epoch, cr[4 + ho]); df_store_granule(mine + 4 * DF_HD + 2 * ho + 1, epoch, cr[8 + ho]); }
@@ -1683,6 +1697,7 @@ __global__ __launch_bounds__(W2X_THREADS, 1) void k_w2x_attn12(const W2xArgs f, 
     __syncthreads();
     df_attn12_body<true, true>(a, reinterpret_cast<unsigned char *>(smem), gx, gx_epoch);
 }
+constexpr int FA12_LDS_BYTES = FFN_LDS_BYTES > DA12_LDS_BYTES ? FFN_LDS_BYTES : DA12_LDS_BYTES;
 // FFN block of layer l, then the attention block of layer l + 1, one launch (fa = the attention block's arguments)
 __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_attn12(const FfnArgs f, const DecFuseArgs a, u64 *gx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -243,6 +243,7 @@ struct vox_hip_engine {
     u64 *d_gq = nullptr, *d_gp = nullptr, *d_gh = nullptr;
     int merge12 = 2;              // VOX_HIP_MERGE12: 0 = two launches per layer in the 8-wave shape (before), 1 = k_attn12 in place of k_dec_attn_fused where it applies (A/B of the shape), 2 = k_ffn_attn12
     u64 *d_gx = nullptr;          // [3072] x'' hand-off of k_ffn_attn12
+    int merge12_maxkeys = 1024;   // VOX_HIP_MERGE12_MAXKEYS: the merged launches up to this context length (8 key slices of two tiles beyond 512 keys; measured: 2048 = four tiles per member loses 2 % at 1900 keys)
     int wo_late = 1;              // VOX_HIP_FUSE_WO_LATE=0 (A/B, see DecFuseArgs)
     float *d_xprime = nullptr;    // x' of the fused FFN launch, written only for the debug taps
     bool use_ffn = false;         // FFN block as one launch (k_ffn_fused) instead of k_gemv_w13x + k_gemv_w2x
@@ -681,7 +682,7 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  hipFuncSetAttribute((const void *)k_ffn_fused, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, DA12_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_w2x_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, DA12_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_ffn_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_ffn_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
                  dalloc(e, &e->d_gx, (size_t)DF_D) == 0 && hipMemset(e->d_gx, 0, (size_t)DF_D * 8) == hipSuccess;
             if (!ok) { (void)hipGetLastError(); fprintf(stderr, "vox_hip: fused decode kernels unavailable; launch-per-GEMV chain\n"); }
             e->use_fused = ok; e->fused_ok = ok;
@@ -690,6 +691,7 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                 hipMemset(e->d_fuse_trace, 0, 64 * 8);
             if (getenv("VOX_HIP_FUSE_WO_LATE")) e->wo_late = atoi(getenv("VOX_HIP_FUSE_WO_LATE"));
             if (getenv("VOX_HIP_MERGE12")) e->merge12 = atoi(getenv("VOX_HIP_MERGE12"));
+            if (getenv("VOX_HIP_MERGE12_MAXKEYS")) e->merge12_maxkeys = atoi(getenv("VOX_HIP_MERGE12_MAXKEYS"));
             e->fp8_attn_bf16 = getenv("VOX_HIP_FP8_ATTN_BF16") != nullptr;
             e->fp8_lmhead_bf16 = getenv("VOX_HIP_FP8_LMHEAD_BF16") != nullptr;
             if (const char *pf = getenv("VOX_HIP_PF")) sscanf(pf, "%d,%d,%d", &e->pf_units, &e->pf_member_units, &e->pf_when);
@@ -1883,6 +1885,8 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     int f_split = 64, f_ns = 1;
     if (fused) {
         while ((kv_len + f_split - 1) / f_split > DF_BPG) f_split += 64;
+        // the merged launches (k_ffn_attn12 / k_w2x_attn12) take up to 8 key slices: beyond 512 keys, up to merge12_maxkeys, of more than one tile each
+        if (e->merge12 == 2 && kv_len > 512 && kv_len <= e->merge12_maxkeys) f_split = ((kv_len + 7) / 8 + 63) / 64 * 64;
         f_ns = (kv_len + f_split - 1) / f_split;
     }
     // Fused path: the residual stream ping-pongs between two buffers.  k_gemv_w13x's block 0 writes x' = x + sum(wo partials)
@@ -1993,7 +1997,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                         b.pf.w = reinterpret_cast<const unsigned char *>(N.w13); b.pf.row_bytes = 2 * DD; b.pf.rows_m = DH;
                         b.pf.units = std::min(e->pf_units, 72 * 6); b.pf.member_units = 0; b.pf.when = 3;
                     }
-                    hipLaunchKernelGGL(k_ffn_attn12, dim3(256), dim3(FFN_THREADS), FFN_LDS_BYTES, s, a, b, e->d_gx);
+                    hipLaunchKernelGGL(k_ffn_attn12, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, a, b, e->d_gx);
                     attn_done = true;
                     prof_mark(e, PK_W2);          // (the per-kernel table lists the merged launches in the slot the fused FFN path leaves empty)
                 } else {
@@ -2691,7 +2695,7 @@ static bool merged_static_ok(const vox_hip_engine *e) {
 extern "C" int vox_hip_merged_launches_per_step(const vox_hip_engine_t *e, int kv_len) {
     if (!e || !merged_static_ok(e)) return 0;
     const int kl = std::min(std::max(kv_len, 1), e->d.dec_window);
-    return (kl + 63) / 64 <= 8 ? e->d.dec_layers - 1 : 0;
+    return kl <= std::max(512, e->merge12_maxkeys) ? e->d.dec_layers - 1 : 0;
 }
 
 // Per-kernel average durations of the decode step, measured with HIP events recorded on the

@@ -685,6 +685,11 @@ def test_merged_ffn_attention_launch_matches_the_two_launch_path(vox):
         del os.environ["VOX_HIP_MERGE12"]
     with vox.Model(model_dir("full")) as m:
         assert "ffn_attn12" in m.active_paths()[1]
+        import ctypes as C
+        vox.hip.vox_hip_merged_launches_per_step.restype = C.c_int
+        vox.hip.vox_hip_merged_launches_per_step.argtypes = [C.c_void_p, C.c_int]
+        per_step = [vox.hip.vox_hip_merged_launches_per_step(m.engine, kv) for kv in (1, 232, 512, 513, 1024, 1025, 8000)]
+        assert per_step == [25, 25, 25, 25, 25, 0, 0], per_step
         a = m.transcribe(audio, record_logits=800, force_tokens=c["tokens"])
         assert "dec_fused" in m.active_paths()[1], "a hand-off timed out: the engine fell back to the chain"
         free = m.transcribe(audio)

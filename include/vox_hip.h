@@ -281,7 +281,7 @@ enum vox_hip_path {
     VOX_PATH_GEMM_PLANES      = 1u << 9,   /* large-M GEMMs on producer-split bf16 planes, LDS-DMA pipeline (k_gemm_planes) */
     VOX_PATH_FFN_FUSED        = 1u << 10,  /* decode step: the FFN block as one launch (k_ffn_fused), 2 launches per layer */
     VOX_PATH_ROWSGEMM         = 1u << 11,  /* 33 .. 128-row passes (decoder prefill, encoder flush) on the weight-streaming MFMA kernel k_rowsgemm */
-    VOX_PATH_FFN_ATTN12       = 1u << 12,  /* decode step, up to 512 keys: FFN block of layer l + attention block of layer l + 1 as ONE launch (k_ffn_attn12) */
+    VOX_PATH_FFN_ATTN12       = 1u << 12,  /* decode step, up to 1024 keys: FFN block of layer l + attention block of layer l + 1 as ONE launch (k_ffn_attn12; fp8: k_w2x_attn12) */
 };
 #define VOX_PATH_ALL_BF16 (VOX_PATH_GEMM_MFMA_BF16X3 | VOX_PATH_GEMM_MFMA_F32 | VOX_PATH_GEMM_SPLITK | \
                            VOX_PATH_ATTN_ENC_MFMA | VOX_PATH_ATTN_DEC_DPP | VOX_PATH_GEMV3 | VOX_PATH_DEC_FUSED | VOX_PATH_SKINNY_ENC | \

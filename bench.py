@@ -203,7 +203,7 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True, graph_floor=
     v.hip.vox_hip_profile_decode.restype = C.c_double
     v.hip.vox_hip_profile_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     kv_len = int(min(39 + n_tok / 2, dims.dec_window))      # mean KV length over the decode of this clip
-    # round 4 (late): up to 512 keys the FFN block of layer l and the attention block of layer l + 1 are ONE launch (k_ffn_attn12)
+    # round 4 (late): up to 1024 keys the FFN block of layer l and the attention block of layer l + 1 are ONE launch (k_ffn_attn12)
     v.hip.vox_hip_merged_launches_per_step.restype = C.c_int
     v.hip.vox_hip_merged_launches_per_step.argtypes = [C.c_void_p, C.c_int]
     n_merged = int(v.hip.vox_hip_merged_launches_per_step(model.engine, kv_len)) if ffn else 0

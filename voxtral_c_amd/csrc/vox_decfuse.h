@@ -35,11 +35,11 @@
 // launch-per-GEMV chain and keeps it (vox_hip_active_paths loses VOX_PATH_DEC_FUSED).
 //
 // What is in this file, in the order of a decoder step (round 4):
-//   k_dec_attn_fused   attention block of a layer, 8 waves: layer 0 (with the embedding gather), every layer beyond 512 keys, fp8
+//   k_dec_attn_fused   attention block of a layer, 8 waves: layer 0 (with the embedding gather), every layer beyond 1024 keys
 //   k_gemv_w13x / k_gemv_w2x   FFN block as two launches (fp8 mode; A/B of k_ffn_fused)
-//   k_ffn_fused = ffn_body     FFN block as one launch (h handed over inside, behind the W2 bytes); last layer, every layer beyond 512 keys
-//   df_attn12_body / k_attn12  the attention block re-cut for the FFN kernels' shape (12 waves, <= 168 registers), <= 8 key slices
-//   k_ffn_attn12       FFN block of layer l + attention block of layer l + 1 as ONE launch (x'' in granules): 25 per token up to 512 keys
+//   k_ffn_fused = ffn_body     FFN block as one launch (h handed over inside, behind the W2 bytes); last layer, every layer beyond 1024 keys
+//   df_attn12_body / k_attn12  the attention block re-cut for the FFN kernels' shape (12 waves, <= 168 registers), <= 8 key slices of one or two tiles, bf16 or fp8
+//   k_ffn_attn12       FFN block of layer l + attention block of layer l + 1 as ONE launch (x'' in granules): 25 per token up to 1024 keys (two-tile attention members beyond 512)
 //   k_w2x_attn12       fp8 mode: W2 launch of layer l + fp8 attention block of layer l + 1 as one launch
 #pragma once
 #include "vox_common.h"

@@ -670,39 +670,49 @@ def test_fp8_fused_decode_step_matches_the_fp8_chain(vox):
 
 
 def test_merged_ffn_attention_launch_matches_the_two_launch_path(vox):
-    """Round 4 (late): up to 1024 keys the FFN block of layer l and the attention block of layer l + 1 are ONE launch (k_ffn_attn12:
-    attention block in the 12-wave shape, x'' handed over in granules).  90 s of audio = ~1130 steps: the first ~470 run merged with
-    one-tile attention members, up to 1024 keys with two-tile members (8 key slices of 128 keys), then the step switches to
-    k_dec_attn_fused + k_ffn_fused per layer in the middle of the decode.  Reference =
-    the same engine with VOX_HIP_MERGE12=0 (two launches per layer throughout), its ids teacher-forced: logits equal up to the
-    summation order of the RMSNorm and of the Wo rows' K slices, argmax different at numerical near-ties only."""
-    audio = synth_speech(90.0, 99)
+    """The FFN block of layer l and the attention block of layer l + 1 are ONE launch (k_ffn_attn12: attention block in the 12-wave
+    shape, x'' handed over in granules) at EVERY context length (round 5; round 4: up to 1024 keys).  180 s of audio = ~2250 steps
+    cross all four member shapes in the middle of a decode: one-tile members up to 512 keys, two-tile members (8 key slices of 128
+    keys) up to 1024, then the LONG form - 17 .. 32 one-tile slices up to 2048 keys (members spread over the XCDs, every workgroup
+    carries Wo rows, many-slices merge with the value granules fetched early), two-tile slices beyond (value granules fetched after
+    the (max, sum) pairs).  Reference = the same engine with VOX_HIP_MERGE12=0 (two launches per layer throughout), its ids
+    teacher-forced: logits equal up to the summation order of the RMSNorm and of the Wo rows' K slices, argmax different at
+    numerical near-ties only.  VOX_HIP_MERGE12_LONG=0 is the round-4 behaviour (two launches per layer beyond 1024 keys)."""
+    audio = synth_speech(180.0, 99)
     os.environ["VOX_HIP_MERGE12"] = "0"
     try:
         with vox.Model(model_dir("full")) as m2:
             assert "ffn_attn12" not in m2.active_paths()[1]
-            c = m2.transcribe(audio, record_logits=1200)
+            c = m2.transcribe(audio, record_logits=2400)
     finally:
         del os.environ["VOX_HIP_MERGE12"]
+    import ctypes as C
+    vox.hip.vox_hip_merged_launches_per_step.restype = C.c_int
+    vox.hip.vox_hip_merged_launches_per_step.argtypes = [C.c_void_p, C.c_int]
+    os.environ["VOX_HIP_MERGE12_LONG"] = "0"
+    try:
+        with vox.Model(model_dir("full")) as m4:
+            per_step = [vox.hip.vox_hip_merged_launches_per_step(m4.engine, kv) for kv in (1, 1024, 1025, 8000)]
+            assert per_step == [25, 25, 0, 0], per_step
+    finally:
+        del os.environ["VOX_HIP_MERGE12_LONG"]
     with vox.Model(model_dir("full")) as m:
         assert "ffn_attn12" in m.active_paths()[1]
-        import ctypes as C
-        vox.hip.vox_hip_merged_launches_per_step.restype = C.c_int
-        vox.hip.vox_hip_merged_launches_per_step.argtypes = [C.c_void_p, C.c_int]
-        per_step = [vox.hip.vox_hip_merged_launches_per_step(m.engine, kv) for kv in (1, 232, 512, 513, 1024, 1025, 8000)]
-        assert per_step == [25, 25, 25, 25, 25, 0, 0], per_step
-        a = m.transcribe(audio, record_logits=1200, force_tokens=c["tokens"])
+        per_step = [vox.hip.vox_hip_merged_launches_per_step(m.engine, kv) for kv in (1, 232, 512, 513, 1024, 1025, 2048, 2049, 8000, 8192)]
+        assert per_step == [25] * 10, per_step
+        a = m.transcribe(audio, record_logits=2400, force_tokens=c["tokens"])
         assert "dec_fused" in m.active_paths()[1], "a hand-off timed out: the engine fell back to the chain"
         free = m.transcribe(audio)
     n = len(c["tokens"])
-    assert n > 1080 and len(a["tokens"]) == n
+    assert n > 2200 and len(a["tokens"]) == n
     k = min(len(a["logits"]), len(c["logits"]))
-    err = float(np.abs(np.asarray(a["logits"])[:k] - np.asarray(c["logits"])[:k]).max())
+    assert k > 2200
+    err = max(float(np.abs(np.asarray(a["logits"][i:i + 256]) - np.asarray(c["logits"][i:i + 256])).max()) for i in range(0, k, 256))
     diff = int((np.asarray(a["tokens"]) != np.asarray(c["tokens"])).sum())
     diag("merged_vs_two_launches", steps=n, logit_rows=k, max_logit_diff=err, differing_argmax=diff,
          free_running_equal=bool(np.array_equal(np.asarray(free["tokens"]), np.asarray(c["tokens"]))))
     assert err < 2e-4, err
-    assert diff <= 1, (diff, n)
+    assert diff <= 2, (diff, n)
 
 
 def test_fused_decode_step_matches_the_chain_at_long_context(vox):

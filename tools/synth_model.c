@@ -12,8 +12,11 @@
  * Values are counter-based (splitmix64 of tensor-name hash + element index) so
  * the file is bit-identical on every machine and can be generated in parallel.
  *
- * usage: synth_model <out_dir> <preset: full|small|tiny> [seed]
+ * usage: synth_model <out_dir> <preset: full|small|tiny|deep>[-rs] [seed]
  *   writes <out_dir>/consolidated.safetensors and <out_dir>/tekken.json
+ *
+ * Style "-rs" ("realistic statistics", round 5): the same geometry with the weight statistics a trained
+ * checkpoint has and an iid Gaussian one lacks - see the block comment in front of rs_setup().
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -45,6 +48,11 @@ typedef struct {
     float std;
     uint64_t offset; /* byte offset in data section */
     uint64_t numel;
+    /* "-rs" style only */
+    int stack;       /* 0 = encoder width, 1 = decoder width: which outlier-channel set applies */
+    int col_out;     /* input columns of the stack's outlier channels carry the factor chan_f[] (wq, wk, w1, w3) */
+    int row_out;     /* output rows of the stack's outlier channels are multiplied by RS_ROW_GAIN (wo, w2: "massive activations") */
+    int norm_spike;  /* norm weight: the outlier channels carry chan_s[] instead of ~1 */
 } tensor_t;
 
 static tensor_t *g_t = NULL;
@@ -85,14 +93,99 @@ static inline uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
+/* ---------------------------------------------------------------------------------------------------
+ * Style "-rs": realistic statistics.  The plain presets are iid Gaussian with a damped residual stream, which
+ * cannot fail a kernel on the things trained checkpoints are known for.  This style adds, at the same geometry:
+ *  (i)   heavy tails: every matrix entry is Student-t(3) (unit variance, clamped at 24 sigma) instead of Gaussian:
+ *        kurtosis, single weights tens of sigma out - what block / row scales of an fp8 copy have to live with;
+ *  (ii)  outlier channels: a fixed ~0.5 % of the channels of each residual stream (the same set in every layer, as
+ *        in trained transformers) carry x30 - x100 columns in wq / wk / w1 / w3 and x3 - x6 spikes in the two norm
+ *        weights in front of them, so a handful of terms dominates those dot products (cancellation,
+ *        summation-order sensitivity, large score magnitudes); the matrices are renormalised so that the rms
+ *        of q, k, gate and up stays O(1);
+ *  (iii) massive activations: the rows of wo / w2 (and the adapter's output layer) that write the outlier channels
+ *        are x RS_ROW_GAIN, so the residual stream itself has a few channels well above the rest and RMSNorm
+ *        works on a skewed vector;
+ *  (iv)  residual gains at the limit the reference itself reproduces instead of a nearly linear stream: chosen
+ *        with tools/amplification.py (the reference run twice, the audio perturbed by 1e-6 relative).
+ * ------------------------------------------------------------------------------------------------- */
+static float RS_ROW_GAIN = 6.0f;   /* SYNTH_RS_ROW */
+static float RS_COL_LO = 30.0f, RS_COL_HI = 100.0f, RS_SPIKE_LO = 3.0f, RS_SPIKE_HI = 6.0f;   /* SYNTH_RS_COL / SYNTH_RS_SPIKE scale both ends */
+static float RS_FNORM = 0.1f;      /* SYNTH_RS_FNORM: the two final norms damp the outlier channels (as trained final norms do) */
+/* residual gains of the deep stacks in this style (tools/amplification.py; the plain presets use 0.05 / 0.15 / 1) */
+#define RS_DEEP_WO 0.05f
+#define RS_DEEP_W2 0.15f
+#define RS_DEEP_QK 1.0f
+static int g_rs = 0;
+static float *g_chan_f[2], *g_chan_s[2];     /* per stack: column factor (1 = ordinary channel), norm spike (0 = none) */
+static int g_chan_n[2];
+
+static void rs_setup(const dims_t *d, uint64_t seed) {
+    const int width[2] = {d->enc_dim, d->dec_dim};
+    for (int st = 0; st < 2; st++) {
+        int n = width[st], n_out = 0;
+        g_chan_n[st] = n;
+        g_chan_f[st] = malloc(sizeof(float) * n);
+        g_chan_s[st] = malloc(sizeof(float) * n);
+        for (int c = 0; c < n; c++) {
+            uint64_t h = splitmix64(seed ^ (0xC0FFEEull + 977ull * st) ^ ((uint64_t)c << 20));
+            int out = (h % 200) == 0;
+            float u = (float)((h >> 16) & 0xFFFF) / 65536.0f, u2 = (float)((h >> 32) & 0xFFFF) / 65536.0f;
+            g_chan_f[st][c] = out ? RS_COL_LO * powf(RS_COL_HI / RS_COL_LO, u) : 1.0f;
+            g_chan_s[st][c] = out ? RS_SPIKE_LO + (RS_SPIKE_HI - RS_SPIKE_LO) * u2 : 0.0f;
+            n_out += out;
+        }
+        if (n_out == 0) {                     /* narrow stacks: at least one outlier channel */
+            int c = (int)(splitmix64(seed ^ st) % n);
+            g_chan_f[st][c] = 55.0f; g_chan_s[st][c] = 4.5f;
+        }
+    }
+}
+/* variance of a dot product of a col_out matrix row with a normalised input, relative to the plain case
+ * (inputs ~unit on ordinary channels; RS_ROW_GAIN x spike on the outlier channels) */
+static float rs_col_boost(int st) {
+    double acc = 0;
+    for (int c = 0; c < g_chan_n[st]; c++) {
+        double f = g_chan_f[st][c], sp = g_chan_s[st][c] > 0 ? g_chan_s[st][c] * RS_ROW_GAIN : 1.0;
+        acc += f * f * sp * sp;
+    }
+    return (float)(acc / g_chan_n[st]);
+}
+
 typedef struct { uint16_t *dst; const tensor_t *t; uint64_t seed; uint64_t lo, hi; } job_t;
+
+/* Student-t(3) with unit variance from two hashes: n0 / sqrt(chi2_3 / 3) / sqrt(3). */
+static inline float approx_t3(uint64_t h) {
+    float n0 = approx_normal(h);
+    uint64_t g = splitmix64(h ^ 0x5851F42D4C957F2Dull);
+    float c2 = 0;
+    for (int k = 0; k < 3; k++) {
+        uint32_t b = (uint32_t)(g >> (21 * k)) & 0x1FFFFF;
+        float s = (float)(b & 0x7F) + (float)((b >> 7) & 0x7F) + (float)((b >> 14) & 0x7F);   /* Irwin-Hall(3) of 7-bit pieces */
+        s = (s + 1.5f) * (1.0f / 128.0f) - 1.5f;                                             /* mean 0, var 1/4 */
+        s *= 2.0f;
+        c2 += s * s;
+    }
+    float t = n0 / sqrtf(c2 * (1.0f / 3.0f) + 1e-4f) * 0.57735027f;
+    return t > 24.0f ? 24.0f : t < -24.0f ? -24.0f : t;
+}
 
 static void *fill_job(void *arg) {
     job_t *j = (job_t *)arg;
     const tensor_t *t = j->t;
+    const int rs_mat = g_rs && t->kind == 0 && !(getenv("SYNTH_RS_GAUSS_EMB") && strstr(t->name, "tok_embeddings")) && !getenv("SYNTH_RS_GAUSS");
+    const uint64_t cols = t->ndim > 1 ? (uint64_t)t->shape[1] * (t->ndim > 2 ? t->shape[2] : 1) : 1;
+    const float *cf = g_rs ? g_chan_f[t->stack] : NULL, *cs = g_rs ? g_chan_s[t->stack] : NULL;
     for (uint64_t i = j->lo; i < j->hi; i++) {
-        float n = approx_normal(splitmix64(j->seed + i));
+        uint64_t h = splitmix64(j->seed + i);
+        float n = rs_mat ? approx_t3(h) : approx_normal(h);
         float v = (t->kind == 1) ? 1.0f + 0.02f * n : (t->kind == 3) ? -3.0f + t->std * n : t->std * n;
+        if (g_rs) {
+            if (t->col_out) v *= cf[i % cols];
+            if (t->row_out && cs[i / cols] > 0) v *= RS_ROW_GAIN;
+            if (t->norm_spike == 1 && cs[i] > 0) v *= cs[i];
+            if (t->norm_spike == 2 && cs[i] > 0) v *= RS_FNORM;
+        }
         j->dst[i] = f32_to_bf16_rne(v);
     }
     return NULL;
@@ -111,15 +204,27 @@ static void b64(const unsigned char *in, int n, char *out) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s <out_dir> <full|small|tiny|deep> [seed]\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <out_dir> <full|small|tiny|deep>[-rs] [seed]\n", argv[0]); return 2; }
     const char *out_dir = argv[1];
     dims_t d;
-    if (!strcmp(argv[2], "full")) d = PRESET_FULL;
-    else if (!strcmp(argv[2], "small")) d = PRESET_SMALL;
-    else if (!strcmp(argv[2], "tiny")) d = PRESET_TINY;
-    else if (!strcmp(argv[2], "deep")) d = PRESET_DEEP;
+    char geom[32];
+    snprintf(geom, sizeof geom, "%s", argv[2]);
+    char *dash = strchr(geom, '-');
+    if (dash) {
+        if (strcmp(dash, "-rs")) { fprintf(stderr, "unknown style %s\n", dash); return 2; }
+        *dash = 0; g_rs = 1;
+    }
+    if (!strcmp(geom, "full")) d = PRESET_FULL;
+    else if (!strcmp(geom, "small")) d = PRESET_SMALL;
+    else if (!strcmp(geom, "tiny")) d = PRESET_TINY;
+    else if (!strcmp(geom, "deep")) d = PRESET_DEEP;
     else { fprintf(stderr, "unknown preset %s\n", argv[2]); return 2; }
     uint64_t seed = argc > 3 ? strtoull(argv[3], NULL, 10) : 1234;
+    if (getenv("SYNTH_RS_ROW")) RS_ROW_GAIN = (float)atof(getenv("SYNTH_RS_ROW"));
+    if (getenv("SYNTH_RS_FNORM")) RS_FNORM = (float)atof(getenv("SYNTH_RS_FNORM"));
+    if (getenv("SYNTH_RS_COL")) { float k = (float)atof(getenv("SYNTH_RS_COL")); RS_COL_LO = 0.3f * k; RS_COL_HI = k; }
+    if (getenv("SYNTH_RS_SPIKE")) { float k = (float)atof(getenv("SYNTH_RS_SPIKE")); RS_SPIKE_LO = 0.5f * k; RS_SPIKE_HI = k; }
+    if (g_rs) rs_setup(&d, seed);
 
     char nm[256];
     const char *EP = "mm_streams_embeddings.embedding_module.whisper_encoder";
@@ -142,54 +247,62 @@ int main(int argc, char **argv) {
      * (tools/make_golden.py).  Overridable through the environment for tuning only. */
     const int enc_deep = d.enc_layers > 4, dec_deep = d.dec_layers > 4;
     #define GAIN_ENV(name, dflt) (getenv(name) ? (float)atof(getenv(name)) : (dflt))
-    const float enc_gain = GAIN_ENV("SYNTH_ENC_GAIN", enc_deep ? 0.15f : 1.0f);
-    const float dec_gain = GAIN_ENV("SYNTH_DEC_GAIN", dec_deep ? 0.15f : 1.0f);
-    const float enc_wo = GAIN_ENV("SYNTH_ENC_WO", enc_deep ? 0.05f : 0.3f);
-    const float dec_wo = GAIN_ENV("SYNTH_DEC_WO", dec_deep ? 0.05f : 0.3f);
-    const float enc_qk = GAIN_ENV("SYNTH_ENC_QK", enc_deep ? 1.0f : 2.0f);
-    const float dec_qk = GAIN_ENV("SYNTH_DEC_QK", dec_deep ? 1.0f : 2.0f);
+    /* "-rs" style: gains at the reproducibility limit, see RS_GAINS below */
+    const float enc_gain = GAIN_ENV("SYNTH_ENC_GAIN", enc_deep ? (g_rs ? RS_DEEP_W2 : 0.15f) : 1.0f);
+    const float dec_gain = GAIN_ENV("SYNTH_DEC_GAIN", dec_deep ? (g_rs ? RS_DEEP_W2 : 0.15f) : 1.0f);
+    const float enc_wo = GAIN_ENV("SYNTH_ENC_WO", enc_deep ? (g_rs ? RS_DEEP_WO : 0.05f) : 0.3f);
+    const float dec_wo = GAIN_ENV("SYNTH_DEC_WO", dec_deep ? (g_rs ? RS_DEEP_WO : 0.05f) : 0.3f);
+    const float enc_qk = GAIN_ENV("SYNTH_ENC_QK", enc_deep ? (g_rs ? RS_DEEP_QK : 1.0f) : 2.0f);
+    const float dec_qk = GAIN_ENV("SYNTH_DEC_QK", dec_deep ? (g_rs ? RS_DEEP_QK : 1.0f) : 2.0f);
+    /* column-outlier matrices are renormalised so that q / k / gate / up keep the plain presets' rms */
+    const float ecol = g_rs ? 1.0f / sqrtf(rs_col_boost(0)) : 1.0f, dcol = g_rs ? 1.0f / sqrtf(rs_col_boost(1)) : 1.0f;
+#define LAST (g_t[g_nt - 1])
+#define COL(st) do { LAST.stack = (st); LAST.col_out = 1; } while (0)
+#define ROW(st) do { LAST.stack = (st); LAST.row_out = 1; } while (0)
+#define SPIKE(st) do { LAST.stack = (st); LAST.norm_spike = 1; } while (0)
+#define DAMP(st) do { LAST.stack = (st); LAST.norm_spike = 2; } while (0)
     /* tok_embeddings: logits std ~3 (realistic range); adapter output is scaled to a
      * comparable norm below so that the previous-token feedback visibly steers the
      * greedy sequence (a constant-token sequence would make id parity vacuous). */
     add("mm_streams_embeddings.embedding_module.tok_embeddings.weight", 0, STD(d.dec_dim), 2, d.vocab, d.dec_dim, 0);
     snprintf(nm, sizeof nm, "%s.conv_layers.0.conv.weight", EP); add(nm, 0, 3.0f * STD(d.mel_bins * 3), 3, d.enc_dim, d.mel_bins, 3);
     snprintf(nm, sizeof nm, "%s.conv_layers.0.conv.bias", EP);   add(nm, 3, 0.02f, 1, d.enc_dim, 0, 0);
-    snprintf(nm, sizeof nm, "%s.conv_layers.1.conv.weight", EP); add(nm, 0, 8.0f * STD(d.enc_dim * 3), 3, d.enc_dim, d.enc_dim, 3);
+    snprintf(nm, sizeof nm, "%s.conv_layers.1.conv.weight", EP); add(nm, 0, 8.0f * STD(d.enc_dim * 3), 3, d.enc_dim, d.enc_dim, 3); ROW(0);
     snprintf(nm, sizeof nm, "%s.conv_layers.1.conv.bias", EP);   add(nm, 3, 0.02f, 1, d.enc_dim, 0, 0);
     for (int i = 0; i < d.enc_layers; i++) {
 #define EN(sfx) snprintf(nm, sizeof nm, "%s.transformer.layers.%d." sfx, EP, i)
-        EN("attention.wq.weight"); add(nm, 0, enc_qk * STD(d.enc_dim), 2, eq, d.enc_dim, 0);
+        EN("attention.wq.weight"); add(nm, 0, ecol * enc_qk * STD(d.enc_dim), 2, eq, d.enc_dim, 0); COL(0);
         EN("attention.wq.bias");   add(nm, 2, 0.02f, 1, eq, 0, 0);
-        EN("attention.wk.weight"); add(nm, 0, STD(d.enc_dim), 2, eq, d.enc_dim, 0);
+        EN("attention.wk.weight"); add(nm, 0, ecol * STD(d.enc_dim), 2, eq, d.enc_dim, 0); COL(0);
         EN("attention.wv.weight"); add(nm, 0, STD(d.enc_dim), 2, eq, d.enc_dim, 0);
         EN("attention.wv.bias");   add(nm, 2, 0.02f, 1, eq, 0, 0);
-        EN("attention.wo.weight"); add(nm, 0, enc_wo * STD(eq), 2, d.enc_dim, eq, 0);
+        EN("attention.wo.weight"); add(nm, 0, enc_wo * STD(eq), 2, d.enc_dim, eq, 0); ROW(0);
         EN("attention.wo.bias");   add(nm, 2, 0.02f, 1, d.enc_dim, 0, 0);
-        EN("attention_norm.weight"); add(nm, 1, 0, 1, d.enc_dim, 0, 0);
-        EN("feed_forward.w1.weight"); add(nm, 0, STD(d.enc_dim), 2, d.enc_hidden, d.enc_dim, 0);
-        EN("feed_forward.w2.weight"); add(nm, 0, enc_gain * STD(d.enc_hidden), 2, d.enc_dim, d.enc_hidden, 0);
+        EN("attention_norm.weight"); add(nm, 1, 0, 1, d.enc_dim, 0, 0); SPIKE(0);
+        EN("feed_forward.w1.weight"); add(nm, 0, ecol * STD(d.enc_dim), 2, d.enc_hidden, d.enc_dim, 0); COL(0);
+        EN("feed_forward.w2.weight"); add(nm, 0, enc_gain * STD(d.enc_hidden), 2, d.enc_dim, d.enc_hidden, 0); ROW(0);
         EN("feed_forward.w2.bias");   add(nm, 2, 0.02f, 1, d.enc_dim, 0, 0);
-        EN("feed_forward.w3.weight"); add(nm, 0, STD(d.enc_dim), 2, d.enc_hidden, d.enc_dim, 0);
-        EN("ffn_norm.weight");        add(nm, 1, 0, 1, d.enc_dim, 0, 0);
+        EN("feed_forward.w3.weight"); add(nm, 0, ecol * STD(d.enc_dim), 2, d.enc_hidden, d.enc_dim, 0); COL(0);
+        EN("ffn_norm.weight");        add(nm, 1, 0, 1, d.enc_dim, 0, 0); SPIKE(0);
     }
-    snprintf(nm, sizeof nm, "%s.transformer.norm.weight", EP); add(nm, 1, 0, 1, d.enc_dim, 0, 0);
+    snprintf(nm, sizeof nm, "%s.transformer.norm.weight", EP); add(nm, 1, 0, 1, d.enc_dim, 0, 0); DAMP(0);
     add("mm_streams_embeddings.embedding_module.audio_language_projection.0.weight", 0, STD(d.enc_dim * 4), 2, d.dec_dim, d.enc_dim * 4, 0);
-    add("mm_streams_embeddings.embedding_module.audio_language_projection.2.weight", 0, STD(d.dec_dim), 2, d.dec_dim, d.dec_dim, 0);
+    add("mm_streams_embeddings.embedding_module.audio_language_projection.2.weight", 0, STD(d.dec_dim), 2, d.dec_dim, d.dec_dim, 0); ROW(1);
     for (int i = 0; i < d.dec_layers; i++) {
 #define DN(sfx) snprintf(nm, sizeof nm, "layers.%d." sfx, i)
         DN("ada_rms_norm_t_cond.0.weight"); add(nm, 0, STD(d.dec_dim), 2, d.ada_dim, d.dec_dim, 0);
         DN("ada_rms_norm_t_cond.2.weight"); add(nm, 0, 0.1f * STD(d.ada_dim), 2, d.dec_dim, d.ada_dim, 0);
-        DN("attention.wq.weight"); add(nm, 0, dec_qk * STD(d.dec_dim), 2, dq, d.dec_dim, 0);
-        DN("attention.wk.weight"); add(nm, 0, STD(d.dec_dim), 2, dkv, d.dec_dim, 0);
+        DN("attention.wq.weight"); add(nm, 0, dcol * dec_qk * STD(d.dec_dim), 2, dq, d.dec_dim, 0); COL(1);
+        DN("attention.wk.weight"); add(nm, 0, dcol * STD(d.dec_dim), 2, dkv, d.dec_dim, 0); COL(1);
         DN("attention.wv.weight"); add(nm, 0, STD(d.dec_dim), 2, dkv, d.dec_dim, 0);
-        DN("attention.wo.weight"); add(nm, 0, dec_wo * STD(dq), 2, d.dec_dim, dq, 0);
-        DN("attention_norm.weight"); add(nm, 1, 0, 1, d.dec_dim, 0, 0);
-        DN("feed_forward.w1.weight"); add(nm, 0, STD(d.dec_dim), 2, d.dec_hidden, d.dec_dim, 0);
-        DN("feed_forward.w2.weight"); add(nm, 0, dec_gain * STD(d.dec_hidden), 2, d.dec_dim, d.dec_hidden, 0);
-        DN("feed_forward.w3.weight"); add(nm, 0, STD(d.dec_dim), 2, d.dec_hidden, d.dec_dim, 0);
-        DN("ffn_norm.weight"); add(nm, 1, 0, 1, d.dec_dim, 0, 0);
+        DN("attention.wo.weight"); add(nm, 0, dec_wo * STD(dq), 2, d.dec_dim, dq, 0); ROW(1);
+        DN("attention_norm.weight"); add(nm, 1, 0, 1, d.dec_dim, 0, 0); SPIKE(1);
+        DN("feed_forward.w1.weight"); add(nm, 0, dcol * STD(d.dec_dim), 2, d.dec_hidden, d.dec_dim, 0); COL(1);
+        DN("feed_forward.w2.weight"); add(nm, 0, dec_gain * STD(d.dec_hidden), 2, d.dec_dim, d.dec_hidden, 0); ROW(1);
+        DN("feed_forward.w3.weight"); add(nm, 0, dcol * STD(d.dec_dim), 2, d.dec_hidden, d.dec_dim, 0); COL(1);
+        DN("ffn_norm.weight"); add(nm, 1, 0, 1, d.dec_dim, 0, 0); SPIKE(1);
     }
-    add("norm.weight", 1, 0, 1, d.dec_dim, 0, 0);
+    add("norm.weight", 1, 0, 1, d.dec_dim, 0, 0); DAMP(1);
 
     /* header */
     uint64_t off = 0;

@@ -1291,8 +1291,17 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int DA12_THREADS = 768, DA12_WAVES = 12, DA12_NWO = 12;
 constexpr int DA12_LDS_BYTES = 2 * DF_D * 4 + 4 * DF_TILE_BYTES + 1024 + 512;      // [xs | nw], K/V tiles double buffered, inv_freq, red
-template <bool XG, bool W8 = false>
+//
+// LONG (round 5): the same body for 9 .. 32 key slices (contexts beyond 1024 keys), so that the merged launch covers every context
+// length.  What changes is what k_dec_attn_fused does differently there too: the members of a KV-head group are spread over all
+// XCDs (group = blockIdx / 32: a group's K/V tiles and Wo rows then come through all eight L2s), EVERY workgroup carries Wo rows
+// (96 per workgroup = 8 per wave) and merges the partials, an attention member requests its Wo rows BEHIND its partial (a CU's
+// stores leave through the same queue as its loads), and the merge is the many-slices form: the (max, sum) pairs meet in LDS, every
+// slice's weight exp(m_s - M) / L is computed once per head, and a thread's 32 (head, dim) granules share one trip to L2 with them
+// while a slice is one tile (beyond that the members finish further apart and the early fetch would only be repeated).
+template <bool XG, bool W8 = false, bool LONG = false>
 __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned char *smem_raw, const u64 *gx, unsigned x_epoch) {
+    static_assert(!(LONG && W8), "the long-context form is bf16 only");
     float *xs = reinterpret_cast<float *>(smem_raw);                           // [3072] x, then [3072] norm weights (contiguous)
     float *nw = xs + DF_D;
     unsigned char *tiles = smem_raw + 2 * DF_D * 4;                            // [2 buffers][K tile | V tile]; later the Wo reduction scratch
@@ -1300,7 +1309,7 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
     float *red = frq + 256;                                                    // [128]: wave sums, the 24 row results
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = blockIdx.x % DF_GROUPS, j = blockIdx.x / DF_GROUPS;
+    const int g = LONG ? blockIdx.x / DF_BPG : blockIdx.x % DF_GROUPS, j = LONG ? blockIdx.x % DF_BPG : blockIdx.x / DF_GROUPS;
     const unsigned epoch = a.epoch;
     const int pos = a.pos;
     unsigned long long df_stamp[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1309,7 +1318,7 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
     // ---- this workgroup's 24 projection rows: wave w streams rows 2w, 2w+1 ----------------------------------------------------------
     constexpr int NPW = W8 ? 3 : 6;               // 1 KiB pieces per projection row (fp8: 16 weights per lane and piece)
     constexpr int XSP = W8 ? 1 : 2;               // XG: pieces requested in front of the x'' sweep
-    constexpr int NWL = W8 ? 6 : DA12_NWO;        // Wo loads per wave (fp8: two rows per load, as in k_dec_attn_fused<W8>)
+    constexpr int NWL = W8 ? 6 : LONG ? 8 : DA12_NWO;        // Wo loads per wave (fp8: two rows per load, as in k_dec_attn_fused<W8>; LONG: 96 rows per workgroup)
     const unsigned char *rp[2];
     int prow[2];
 #pragma unroll
@@ -1321,7 +1330,7 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
         prow[i] = row;
         rp[i] = reinterpret_cast<const unsigned char *>(a.wqkv) + (size_t)row * (W8 ? DF_D : DF_D * 2) + lane * 16;
     }
-    const int ns = a.nsplit;                                     // <= 8 here
+    const int ns = a.nsplit;                                     // <= 8 (LONG: <= 32)
     int lo = pos - a.window + 1; if (lo < 0) lo = 0;
     const int s_lo = lo + j * a.split_keys;
     int s_hi = s_lo + a.split_keys - 1; if (s_hi > pos) s_hi = pos;
@@ -1362,9 +1371,9 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
     // Wo rows (row r = Wo[r][512 g .. 512 g + 511] = 1 KiB): the 32 - ns non-members share the group's 3072 rows, <= 12 per wave
     uint4 wv[NWL];
     float wo_sc[W8 ? NWL : 1];
-    const int nb = DF_BPG - ns, rpb = ((DF_D + nb - 1) / nb + 11) / 12 * 12;
+    const int nb = LONG ? DF_BPG : DF_BPG - ns, rpb = LONG ? DF_WO_ROWS : ((DF_D + nb - 1) / nb + 11) / 12 * 12;
     const int wo_rpw = rpb / 12;
-    const int wo_row0 = att_block ? DF_D : (j - ns) * rpb + wave * wo_rpw;
+    const int wo_row0 = LONG ? j * rpb + wave * wo_rpw : att_block ? DF_D : (j - ns) * rpb + wave * wo_rpw;
     const int wo_n = max(0, min(wo_rpw, DF_D - wo_row0));
     const int wo_rmax = wo_n > 0 ? wo_row0 + wo_n - 1 : DF_D - 1;
     const unsigned char *wo_base = reinterpret_cast<const unsigned char *>(a.wo) + (size_t)(DF_NQ * g) * (W8 ? 1 : 2) + (W8 ? (lane & 31) : lane) * 16;
@@ -1469,24 +1478,25 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
     }
     __syncthreads();                       // xs / nw are dead from here on: scratch for the attention stage
     DF_MARK(5);
-    const bool pf_on = a.pf.units > 0;
+    const bool pf_on = !LONG && a.pf.units > 0;
     const int pf_V = 32 * a.pf.units;
     const unsigned pf_lds = lds_addr(tiles) + 53248u + (unsigned)wave * 896u;       // 12 x 896 B behind the Wo reduction scratch (52 KB)
+#define DA12_ISSUE_WO()                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < NWL; i++) {                                                                         \
+        if constexpr (W8) {      /* load i = rows wo_row0 + 2 i (lanes 0-31) and + 2 i + 1 (lanes 32-63), 16 weights per lane */ \
+            const int r = min(wo_row0 + 2 * i + (lane >> 5), wo_rmax);                                                        \
+            wv[i] = ld_stream(reinterpret_cast<const uint4 *>(wo_base + (size_t)r * DF_DQ));                                  \
+            wo_sc[i] = a.so[r];                                                                                               \
+        } else {                                                                                                              \
+            wv[i] = ld_stream(reinterpret_cast<const uint4 *>(wo_base + (size_t)min(wo_row0 + i, wo_rmax) * (DF_DQ * 2)));    \
+        }                                                                                                                     \
+    }
     if (!att_block) {
         if (pf_on) {
             df_prefetch_units(a.pf, g, 0, pf_V, (j - ns) * DA12_WAVES + wave, (DF_BPG - ns) * DA12_WAVES, lane, pf_lds);
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int i = 0; i < NWL; i++) {
-            if constexpr (W8) {      // load i = rows wo_row0 + 2 i (lanes 0-31) and + 2 i + 1 (lanes 32-63), 16 weights per lane
-                const int r = min(wo_row0 + 2 * i + (lane >> 5), wo_rmax);
-                wv[i] = ld_stream(reinterpret_cast<const uint4 *>(wo_base + (size_t)r * DF_DQ));
-                wo_sc[i] = a.so[r];
-            } else {
-                wv[i] = ld_stream(reinterpret_cast<const uint4 *>(wo_base + (size_t)min(wo_row0 + i, wo_rmax) * (DF_DQ * 2)));
-            }
-        }
+        DA12_ISSUE_WO()
     }
     float *qs = xs;                        // [512] the group's q
     float *kvn = xs + 512;                 // [256] this step's k | v of head g
@@ -1594,15 +1604,70 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
             df_store_granule(mine + ho * DF_HD + dd, epoch, o_acc);
             if (dd == 0) { df_store_granule(mine + 4 * DF_HD + 2 * ho, epoch, cr[4 + ho]); df_store_granule(mine + 4 * DF_HD + 2 * ho + 1, epoch, cr[8 + ho]); }
         }
+        if constexpr (LONG) {      // a member's Wo rows: requested behind its partial (see k_dec_attn_fused, wo_late)
+            __builtin_amdgcn_sched_barrier(0);
+            DA12_ISSUE_WO()
+        }
         DF_MARK(7);
     } else {
         DF_MARK(6);
         DF_MARK(7);
+    }
+#undef DA12_ISSUE_WO
+    if (LONG || !att_block) {
         // ---- hand-off 2: one thread polls, then everybody sweeps the group's partials and merges them in slice order -------------------
         const int h = (tid >> 7) & 3, d = tid & 127;
         float M = -1e30f, L = 0.f, O = 0.f;
         if (tid == 0) (void)df_wait_granule(gp + (size_t)(ns - 1) * DF_GP + 4 * DF_HD, epoch, a, 2u);
         __syncthreads();
+        if (LONG && ns > 8) {
+            // many slices: see k_dec_attn_fused (same arithmetic, same order)
+            float *mlv = xs + 2080;                    // [32 slices][4 heads][2]
+            float *scl = xs + 2080 + 256;              // [4 heads][32 slices]
+            const bool early = a.split_keys <= 64;     // one tile per slice: the value granules share the (max, sum) pairs' trip to L2
+            u64 gv[32];
+            // slice base = wave-uniform (SGPR pair), per-thread part = one 32-bit byte offset: 32 addresses cost one VGPR, not 64
+            const unsigned toff = (unsigned)(h * DF_HD + d) * 8u;
+#define DA12_GV_PTR(u) reinterpret_cast<const u64 *>(reinterpret_cast<const unsigned char *>(gp) + (size_t)min((u), ns - 1) * (DF_GP * 8) + toff)
+            if (early && tid < 512) {
+#pragma unroll
+                for (int u = 0; u < 32; u++) gv[u] = df_load_granule(DA12_GV_PTR(u));
+            }
+            if (tid < ns * 8) {
+                const u64 *src = gp + (size_t)(tid >> 3) * DF_GP + 4 * DF_HD + (tid & 7);
+                mlv[tid] = df_wait_granule(src, epoch, a, 2u);
+            }
+            __syncthreads();
+            if (tid < 128) {       // thread -> (head = tid >> 5, slice = tid & 31): max and sum over the 32-lane segment
+                const int hh = tid >> 5, s1 = tid & 31;
+                const float ms = s1 < ns ? mlv[(s1 * 4 + hh) * 2] : -1e30f, lsum = s1 < ns ? mlv[(s1 * 4 + hh) * 2 + 1] : 0.f;
+                float Mx = ms;
+#pragma unroll
+                for (int o = 16; o >= 1; o >>= 1) Mx = fmaxf(Mx, __shfl_xor(Mx, o, 32));
+                const float ew = expf(ms - Mx);
+                float Ls = lsum * ew;
+#pragma unroll
+                for (int o = 16; o >= 1; o >>= 1) Ls += __shfl_xor(Ls, o, 32);
+                scl[hh * 32 + s1] = Ls > 0.f ? ew / Ls : 0.f;
+            }
+            __syncthreads();
+            if (tid < 512) {
+                if (!early) {
+#pragma unroll
+                    for (int u = 0; u < 32; u++) gv[u] = df_load_granule(DA12_GV_PTR(u));
+                }
+                // a stale tag (rare: the pairs of every slice are in) is waited for granule by granule - no retry loop over all 32
+                // addresses, which the compiler would keep in 64 registers across the loop
+#pragma unroll
+                for (int u = 0; u < 32; u++)
+                    if (u < ns && (unsigned)(gv[u] >> 32) != epoch) gv[u] = (u64)__float_as_uint(df_wait_granule(DA12_GV_PTR(u), epoch, a, 2u));
+#pragma unroll
+                for (int u = 0; u < 32; u++)
+                    if (u < ns) O = fmaf(scl[h * 32 + u], __uint_as_float((unsigned)gv[u]), O);
+                att[h * DF_HD + d] = O;
+#undef DA12_GV_PTR
+            }
+        } else
         if (tid < 512) {
             for (int s0 = 0; s0 < ns; s0 += 4) {
                 u64 gv[4][3];
@@ -1671,7 +1736,7 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int row = lane >> 2, q = lane & 3;
             float sres = 0.f;
-            if (row < DA12_NWO) {
+            if (row < NWL) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const float4 v = *reinterpret_cast<const float4 *>(wr + row * 68 + q * 16 + 4 * c);
@@ -1686,9 +1751,10 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
     }
     tl_end(a.tl, tl0, df_stamp, 13);
 }
+template <bool LONG>
 __global__ __launch_bounds__(DA12_THREADS, 1) void k_attn12(const DecFuseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem12[];
-    df_attn12_body<false>(a, smem12, nullptr, 0u);
+    df_attn12_body<false, false, LONG>(a, smem12, nullptr, 0u);
 }
 // fp8 mode: the W2 launch of layer l, then the attention block of layer l + 1 (fp8 projection / Wo rows), one launch
 __global__ __launch_bounds__(W2X_THREADS, 1) void k_w2x_attn12(const W2xArgs f, const DecFuseArgs a, u64 *gx, unsigned gx_epoch) {
@@ -1699,11 +1765,12 @@ __global__ __launch_bounds__(W2X_THREADS, 1) void k_w2x_attn12(const W2xArgs f, 
 }
 constexpr int FA12_LDS_BYTES = FFN_LDS_BYTES > DA12_LDS_BYTES ? FFN_LDS_BYTES : DA12_LDS_BYTES;
 // FFN block of layer l, then the attention block of layer l + 1, one launch (fa = the attention block's arguments)
+template <bool LONG>
 __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_attn12(const FfnArgs f, const DecFuseArgs a, u64 *gx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ffn_body(f, smem, gx);
     __syncthreads();                        // every reader of the FFN block's LDS is done
-    df_attn12_body<true>(a, reinterpret_cast<unsigned char *>(smem), gx, f.epoch);
+    df_attn12_body<true, false, LONG>(a, reinterpret_cast<unsigned char *>(smem), gx, f.epoch);
 }
 
 }  // namespace vox

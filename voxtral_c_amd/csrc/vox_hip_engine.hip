@@ -243,6 +243,7 @@ struct vox_hip_engine {
     u64 *d_gq = nullptr, *d_gp = nullptr, *d_gh = nullptr;
     int merge12 = 2;              // VOX_HIP_MERGE12: 0 = two launches per layer in the 8-wave shape (before), 1 = k_attn12 in place of k_dec_attn_fused where it applies (A/B of the shape), 2 = k_ffn_attn12
     u64 *d_gx = nullptr;          // [3072] x'' hand-off of k_ffn_attn12
+    int merge12_long = 1;         // VOX_HIP_MERGE12_LONG=0 (A/B): beyond merge12_maxkeys two launches per layer in the 8-wave shape (round 4); 1 = k_ffn_attn12<LONG> (9 .. 32 key slices)
     int merge12_maxkeys = 1024;   // VOX_HIP_MERGE12_MAXKEYS: the merged launches up to this context length (8 key slices of two tiles beyond 512 keys; measured: 2048 = four tiles per member loses 2 % at 1900 keys)
     int wo_late = 1;              // VOX_HIP_FUSE_WO_LATE=0 (A/B, see DecFuseArgs)
     float *d_xprime = nullptr;    // x' of the fused FFN launch, written only for the debug taps
@@ -349,10 +350,19 @@ static int dmalloc(vox_hip_engine *e, void **p, size_t bytes) {
 template <typename T>
 static int dalloc(vox_hip_engine *e, T **p, size_t n) { return dmalloc(e, (void **)p, n * sizeof(T)); }
 
+// A buffer that grows is freed: peer copies other engines still owe this one (vox_hip_encoder_state_push: K/V rings, conv
+// history rows, enc_out rows, recorded as enc_fences and otherwise only waited for by the next encoder-side launch) must have
+// landed first, or they would write into freed memory and the copied-over state rows would be stale.
+static int settle_enc_fences(vox_hip_engine *e) {
+    for (hipEvent_t ev : e->enc_fences) HC(hipEventSynchronize(ev));
+    e->enc_fences.clear();
+    return 0;
+}
 static int ensure(vox_hip_engine *e, Buf &b, size_t bytes) {
     if (b.bytes >= bytes) return 0;
     size_t nb = std::max(bytes, b.bytes * 3 / 2);
     void *np = nullptr;
+    if (settle_enc_fences(e)) return -1;
     HC(esync(e));
     HC(hipMalloc(&np, nb));
     if (b.p) { HC(hipFree(b.p)); e->mem_used -= b.bytes; }
@@ -364,6 +374,7 @@ static int ensure_keep(vox_hip_engine *e, Buf &b, size_t bytes, size_t keep) {
     if (b.bytes >= bytes) return 0;
     size_t nb = std::max(bytes, b.bytes * 3 / 2);
     void *np = nullptr;
+    if (settle_enc_fences(e)) return -1;
     HC(esync(e));
     HC(hipMalloc(&np, nb));
     HC(hipMemset(np, 0, nb));
@@ -680,9 +691,11 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  hipFuncSetAttribute((const void *)k_gemv_w2x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_gemv_w2x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W2X_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_ffn_fused, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, DA12_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_attn12<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DA12_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_attn12<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DA12_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_w2x_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, DA12_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_ffn_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_ffn_attn12<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_ffn_attn12<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
                  dalloc(e, &e->d_gx, (size_t)DF_D) == 0 && hipMemset(e->d_gx, 0, (size_t)DF_D * 8) == hipSuccess;
             if (!ok) { (void)hipGetLastError(); fprintf(stderr, "vox_hip: fused decode kernels unavailable; launch-per-GEMV chain\n"); }
             e->use_fused = ok; e->fused_ok = ok;
@@ -692,6 +705,7 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
             if (getenv("VOX_HIP_FUSE_WO_LATE")) e->wo_late = atoi(getenv("VOX_HIP_FUSE_WO_LATE"));
             if (getenv("VOX_HIP_MERGE12")) e->merge12 = atoi(getenv("VOX_HIP_MERGE12"));
             if (getenv("VOX_HIP_MERGE12_MAXKEYS")) e->merge12_maxkeys = atoi(getenv("VOX_HIP_MERGE12_MAXKEYS"));
+            if (getenv("VOX_HIP_MERGE12_LONG")) e->merge12_long = atoi(getenv("VOX_HIP_MERGE12_LONG"));
             e->fp8_attn_bf16 = getenv("VOX_HIP_FP8_ATTN_BF16") != nullptr;
             e->fp8_lmhead_bf16 = getenv("VOX_HIP_FP8_LMHEAD_BF16") != nullptr;
             if (const char *pf = getenv("VOX_HIP_PF")) sscanf(pf, "%d,%d,%d", &e->pf_units, &e->pf_member_units, &e->pf_when);
@@ -1900,9 +1914,10 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
         hipMemcpyAsync(e->d_taps + ((size_t)tap_i * (2 * d.dec_layers + 1) + slot) * DD, src, (size_t)DD * 4, hipMemcpyDeviceToDevice, s);
     };
     static const int tl_layer = getenv("VOX_HIP_FUSE_TL_LAYER") ? atoi(getenv("VOX_HIP_FUSE_TL_LAYER")) : 13;
-    // the 12-wave shape (k_attn12 / k_ffn_attn12) covers the short-context regime only: <= 8 key slices, bf16, DPP, no debug hooks
+    // the 12-wave shape (k_attn12 / k_ffn_attn12): <= 8 key slices (up to merge12_maxkeys keys), 9 .. 32 in its LONG form (round 5); bf16, DPP, no debug hooks
     static const int spread_env0 = getenv("VOX_HIP_FUSE_SPREAD") ? atoi(getenv("VOX_HIP_FUSE_SPREAD")) : -1;
-    const bool shape12 = fused && e->merge12 > 0 && e->use_ffn && !e->use_fp8 && !e->sim_on && f_ns <= 8 && spread_env0 <= 0 && (e->skip_kinds & ~(1u << PK_W2)) == 0 &&
+    const bool long12 = f_ns > 8;
+    const bool shape12 = fused && e->merge12 > 0 && e->use_ffn && !e->use_fp8 && !e->sim_on && (f_ns <= 8 || e->merge12_long) && spread_env0 <= 0 && (e->skip_kinds & ~(1u << PK_W2)) == 0 &&
                          tap_i < 0 && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0)) && !getenv("VOX_HIP_FUSE_ATTN_PER_HEAD");
     // fp8 mode: the W2 launch of layer l and the (fp8) attention block of layer l + 1 as one launch, same regime
     const bool shape12_f8 = fused && e->merge12 == 2 && e->use_fp8 && !e->fp8_attn_bf16 && !e->sim_on && f_ns <= 8 && spread_env0 <= 0 && (e->skip_kinds & ~(1u << PK_SWIGLU)) == 0 &&
@@ -1953,7 +1968,8 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                     if (emb) hipLaunchKernelGGL((k_dec_attn_fused<true, true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
                     else hipLaunchKernelGGL((k_dec_attn_fused<false, true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
                 } else if (shape12 && !emb) {
-                    hipLaunchKernelGGL(k_attn12, dim3(DF_BLOCKS), dim3(DA12_THREADS), DA12_LDS_BYTES, s, a);
+                    if (long12) hipLaunchKernelGGL(k_attn12<true>, dim3(DF_BLOCKS), dim3(DA12_THREADS), DA12_LDS_BYTES, s, a);
+                    else hipLaunchKernelGGL(k_attn12<false>, dim3(DF_BLOCKS), dim3(DA12_THREADS), DA12_LDS_BYTES, s, a);
                 } else if (e->use_dpp) {
                     if (emb) hipLaunchKernelGGL((k_dec_attn_fused<true, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
                     else hipLaunchKernelGGL((k_dec_attn_fused<false, true>), dim3(DF_BLOCKS), dim3(DF_THREADS), DF_LDS_BYTES, s, a);
@@ -1997,7 +2013,8 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                         b.pf.w = reinterpret_cast<const unsigned char *>(N.w13); b.pf.row_bytes = 2 * DD; b.pf.rows_m = DH;
                         b.pf.units = std::min(e->pf_units, 72 * 6); b.pf.member_units = 0; b.pf.when = 3;
                     }
-                    hipLaunchKernelGGL(k_ffn_attn12, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, a, b, e->d_gx);
+                    if (long12) hipLaunchKernelGGL(k_ffn_attn12<true>, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, a, b, e->d_gx);
+                    else hipLaunchKernelGGL(k_ffn_attn12<false>, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, a, b, e->d_gx);
                     attn_done = true;
                     prof_mark(e, PK_W2);          // (the per-kernel table lists the merged launches in the slot the fused FFN path leaves empty)
                 } else {
@@ -2317,6 +2334,9 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
     hipStream_t s = e->stream;
     const size_t V = e->d.vocab;
     int done = 0;
+    // the wait for the shard that holds the first row is another GPU's encoder time, not decode time: in front of ev0
+    // (as prefill_stream does); waits for later shards inside the run overlap with decoding and stay where they are
+    if (!e->row_fences.empty() && apply_row_fences(e, first_row)) return -1;
     HC(hipEventRecord(e->ev0, s));
     while (done < n_steps) {
         const int batch = std::min(n_steps - done, logits_out ? 64 : MAX_RUN_STEPS);
@@ -2695,7 +2715,7 @@ static bool merged_static_ok(const vox_hip_engine *e) {
 extern "C" int vox_hip_merged_launches_per_step(const vox_hip_engine_t *e, int kv_len) {
     if (!e || !merged_static_ok(e)) return 0;
     const int kl = std::min(std::max(kv_len, 1), e->d.dec_window);
-    return kl <= std::max(512, e->merge12_maxkeys) ? e->d.dec_layers - 1 : 0;
+    return (kl <= std::max(512, e->merge12_maxkeys) || e->merge12_long) ? e->d.dec_layers - 1 : 0;
 }
 
 // Per-kernel average durations of the decode step, measured with HIP events recorded on the
@@ -3390,7 +3410,7 @@ extern "C" int vox_hip_shard_end_push(vox_hip_engine_t *src, vox_hip_engine_t *o
         if (adapter_dev(src, (const float *)src->stmp_out.p, m, (float *)src->stmp_in.p)) return -1;
         if (peer_copy_async(owner, dst_rows, src, src->stmp_in.p, (size_t)m * DD * 4, src->stream)) return -1;
         // the owner's stream does NOT wait here: its decoder waits for these rows when it gets to them (row_fences)
-        static const bool no_overlap = getenv("VOX_MULTI_NO_OVERLAP") != nullptr;       // A/B: the round-3 behaviour
+        const bool no_overlap = getenv("VOX_MULTI_NO_OVERLAP") != nullptr;              // A/B: the round-3 behaviour (read per call, like host/vox_stream.c)
         if (no_overlap) { if (chain_streams(src, owner)) return -1; }
         else {
             hipEvent_t ev;
@@ -3419,7 +3439,7 @@ extern "C" int vox_hip_encoder_state_push(vox_hip_engine_t *src, vox_hip_engine_
     if (peer_copy_async(dst, dst->conv_in1.p, src, src->conv_in1.p, (size_t)2 * ED * 4, src->stream)) return -1;
     if (peer_copy_async(dst, dst->enc_out.p, src, src->enc_out.p, (size_t)3 * ED * 4, src->stream)) return -1;
     dst->enc_pos = src->enc_pos; dst->c0_carry = src->c0_carry; dst->enc_res = src->enc_res;
-    static const bool no_overlap = getenv("VOX_MULTI_NO_OVERLAP") != nullptr;
+    const bool no_overlap = getenv("VOX_MULTI_NO_OVERLAP") != nullptr;
     if (no_overlap) return chain_streams(src, dst);
     hipEvent_t ev;
     if (record_xev(src, &ev)) return -1;

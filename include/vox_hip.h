@@ -281,11 +281,12 @@ enum vox_hip_path {
     VOX_PATH_GEMM_PLANES      = 1u << 9,   /* large-M GEMMs on producer-split bf16 planes, LDS-DMA pipeline (k_gemm_planes) */
     VOX_PATH_FFN_FUSED        = 1u << 10,  /* decode step: the FFN block as one launch (k_ffn_fused), 2 launches per layer */
     VOX_PATH_ROWSGEMM         = 1u << 11,  /* 33 .. 128-row passes (decoder prefill, encoder flush) on the weight-streaming MFMA kernel k_rowsgemm */
-    VOX_PATH_FFN_ATTN12       = 1u << 12,  /* decode step, up to 1024 keys: FFN block of layer l + attention block of layer l + 1 as ONE launch (k_ffn_attn12; fp8: k_w2x_attn12) */
+    VOX_PATH_FFN_ATTN12       = 1u << 12,  /* decode step: FFN block of layer l + attention block of layer l + 1 as ONE launch (k_ffn_attn12, every context length since round 5; fp8: k_w2x_attn12 up to 1024 keys) */
+    VOX_PATH_DEC_STACK        = 1u << 13,  /* decode step: FFN(0) and the attention + FFN blocks of layers 1 .. L-1 as ONE launch (k_dec_stack): 4 launches per token */
 };
 #define VOX_PATH_ALL_BF16 (VOX_PATH_GEMM_MFMA_BF16X3 | VOX_PATH_GEMM_MFMA_F32 | VOX_PATH_GEMM_SPLITK | \
                            VOX_PATH_ATTN_ENC_MFMA | VOX_PATH_ATTN_DEC_DPP | VOX_PATH_GEMV3 | VOX_PATH_DEC_FUSED | VOX_PATH_SKINNY_ENC | \
-                           VOX_PATH_GEMM_PLANES | VOX_PATH_FFN_FUSED | VOX_PATH_ROWSGEMM | VOX_PATH_FFN_ATTN12)
+                           VOX_PATH_GEMM_PLANES | VOX_PATH_FFN_FUSED | VOX_PATH_ROWSGEMM | VOX_PATH_FFN_ATTN12 | VOX_PATH_DEC_STACK)
 unsigned vox_hip_active_paths(const vox_hip_engine_t *e);
 
 /* The fused decode kernel (VOX_PATH_DEC_FUSED) needs its 256 workgroups co-resident; a hand-off that times out (another

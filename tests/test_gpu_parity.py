@@ -700,9 +700,23 @@ def test_merged_ffn_attention_launch_matches_the_two_launch_path(vox):
         assert "ffn_attn12" in m.active_paths()[1]
         per_step = [vox.hip.vox_hip_merged_launches_per_step(m.engine, kv) for kv in (1, 232, 512, 513, 1024, 1025, 2048, 2049, 8000, 8192)]
         assert per_step == [25] * 10, per_step
+        assert "dec_stack" in m.active_paths()[1]
         a = m.transcribe(audio, record_logits=2400, force_tokens=c["tokens"])
         assert "dec_fused" in m.active_paths()[1], "a hand-off timed out: the engine fell back to the chain"
         free = m.transcribe(audio)
+    # round 5: the default engine runs FFN(0) and layers 1 .. 25 as ONE launch (k_dec_stack: x' handed over in two granule hops);
+    # VOX_HIP_STACK=0 = one k_ffn_attn12 launch per layer.  Same arithmetic in the same order: the logits must be EQUAL.
+    os.environ["VOX_HIP_STACK"] = "0"
+    try:
+        with vox.Model(model_dir("full")) as m5:
+            assert "dec_stack" not in m5.active_paths()[1] and "ffn_attn12" in m5.active_paths()[1]
+            b5 = m5.transcribe(audio, record_logits=2400, force_tokens=c["tokens"])
+    finally:
+        del os.environ["VOX_HIP_STACK"]
+    k5 = min(len(a["logits"]), len(b5["logits"]))
+    err5 = max(float(np.abs(np.asarray(a["logits"][i:i + 256]) - np.asarray(b5["logits"][i:i + 256])).max()) for i in range(0, k5, 256))
+    diag("stack_vs_launch_per_layer", logit_rows=k5, max_logit_diff=err5, ids_equal=bool(np.array_equal(np.asarray(a["tokens"]), np.asarray(b5["tokens"]))))
+    assert err5 == 0.0 and np.array_equal(np.asarray(a["tokens"]), np.asarray(b5["tokens"])), err5
     n = len(c["tokens"])
     assert n > 2200 and len(a["tokens"]) == n
     k = min(len(a["logits"]), len(c["logits"]))

@@ -127,12 +127,17 @@ __device__ __forceinline__ void df_store_granule(u64 *g, unsigned epoch, float v
 __device__ __forceinline__ u64 df_load_granule(const u64 *g) {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The thread index as a value the compiler cannot see through.  k_dec_stack runs the FFN and attention bodies inside a loop over the
+// layers: with a plain threadIdx.x every address the bodies derive from it is loop-invariant, gets hoisted out of the loop and kept
+// live across it - hundreds of spilled registers.  Laundered once per body entry, the arithmetic stays where it is written.
+__device__ __forceinline__ int df_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+__device__ __forceinline__ int df_bid() { int b = blockIdx.x; asm volatile("" : "+s"(b)); return b; }
 // Re-read one granule until its tag is this launch's epoch (bounded).  Returns the payload.
 // Once ANY wait of ANY launch has timed out (*err != 0: e.g. the 256 workgroups were not co-resident because another
 // process or stream held CUs), every later wait gives up at once: the launches already queued behind the failure then
 // drain in microseconds instead of one time-out each, and the host re-runs the batch on the launch-per-GEMV chain.
 //
-__device__ __forceinline__ float df_wait_granule(const u64 *g, unsigned epoch, const DecFuseArgs &a, unsigned code) {
+__device__ __forceinline__ float df_wait_granule_e(const u64 *g, unsigned epoch, unsigned *err, unsigned long long spin_limit, unsigned code) {
     u64 v = df_load_granule(g);
     if ((unsigned)(v >> 32) != epoch) {
         const unsigned long long t0 = wall_clock64();
@@ -140,11 +145,14 @@ __device__ __forceinline__ float df_wait_granule(const u64 *g, unsigned epoch, c
             __builtin_amdgcn_s_sleep(2);
             v = df_load_granule(g);
             if ((unsigned)(v >> 32) == epoch) break;
-            if ((it & 15u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-            if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if ((it & 15u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            if (wall_clock64() - t0 > spin_limit) { __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
     }
     return __uint_as_float((unsigned)v);
+}
+__device__ __forceinline__ float df_wait_granule(const u64 *g, unsigned epoch, const DecFuseArgs &a, unsigned code) {
+    return df_wait_granule_e(g, epoch, a.err, a.spin_limit, code);
 }
 
 // Wave-wide sum: four DPP row steps, then the four row sums through readlane (no LDS traffic, unlike ds_bpermute
@@ -1096,15 +1104,30 @@ struct FfnArgs {
 constexpr int FFN_THREADS = 768, FFN_H = 9216;
 constexpr int FFN_LDS_BYTES = W13X_LDS_BYTES;       // phase 2 reuses the prologue's staging area: x' (12 KB) + h (36 KB)
 
+// XP (round 5, k_dec_stack): x' arrives by granules instead of through memory after a kernel boundary, in two hops.  The Wo partial
+// sums of this layer's attention block leave as granules (gw[8][3072], tagged w_epoch); the workgroup that owns rows 12 b .. 12 b + 11
+// of the residual stream (the rows whose x'' it produced in the previous FFN block) fetches their 8 partials and its own x'' values,
+// adds them in the order the memory prologue uses (x, then groups 0 .. 7) and publishes 12 x' granules; everybody sweeps the 3072 x'
+// granules.  Both trips are queued BEHIND weight bytes that have to be streamed anyway (the first behind round 0 of W1 / W3, the
+// second behind round 1): a workgroup starts streaming the moment its own Wo rows are out, nobody waits for the slowest workgroup
+// of a launch, and no launch boundary follows.
+struct FfnXp {
+    const u64 *gw;             // [8][3072] Wo partial sums of this layer's attention block
+    const u64 *gxin;           // [3072] x'' of the previous FFN block
+    u64 *gxp;                  // [3072] x' of this block (tagged a.epoch)
+    unsigned w_epoch, x_epoch;
+};
 // gx (optional): x'' also leaves as {epoch, value} granules (k_ffn_attn12: the attention block of the next layer in the same launch)
-__device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx) {
+template <bool XP = false>
+__device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx, const FfnXp &xp = FfnXp{}) {
     float *stage = smem;                 // [9][3072]: x, wo_part[0..7]; after the prologue: row 0 = x', rows 1..3 = h
     float *nws = smem + 9 * DF_D;        // [3072] norm weights
     float *ads = nws + DF_D;             // [3072] ada
     float *xs = ads + DF_D;              // [3072] normalised x'; phase 2: [12 waves][12 rows] partial sums
     float *red = xs + DF_D;              // [16]
     float *hs = stage + DF_D;            // [9216] h (phase 2), wave w owns [768 w, 768 w + 768)
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = df_tid(), lane = tid & 63;
+    const int bid = df_bid();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned wofs = (unsigned)wave * 1024u;
     unsigned long long df_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1113,14 +1136,16 @@ __device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx)
     FFN_MARK(0);
 
     // ---- phase 1: exactly k_gemv_w13x<false> (same memory-queue order, same arithmetic) --------------------------------------
-    glds16(a.x + tid * 4, lds_addr(stage) + wofs);
+    if constexpr (!XP) {
+        glds16(a.x + tid * 4, lds_addr(stage) + wofs);
 #pragma unroll
-    for (int gi = 0; gi < 8; gi++) glds16(a.wo_part + (size_t)gi * DF_D + tid * 4, lds_addr(stage + (gi + 1) * DF_D) + wofs);
+        for (int gi = 0; gi < 8; gi++) glds16(a.wo_part + (size_t)gi * DF_D + tid * 4, lds_addr(stage + (gi + 1) * DF_D) + wofs);
+    }
     glds16(a.norm_w + tid * 4, lds_addr(nws) + wofs);
     glds16(a.ada + tid * 4, lds_addr(ads) + wofs);
     __builtin_amdgcn_sched_barrier(0);
     uint4 w[2][3][6];
-    const int pair0 = blockIdx.x * 36 + wave * 3;
+    const int pair0 = bid * 36 + wave * 3;
     const uint4 *p1[3], *p3[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -1133,18 +1158,65 @@ __device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx)
     FFN_ISSUE(0) FFN_ISSUE(1)
     __builtin_amdgcn_sched_barrier(0);
     FFN_MARK(1);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // the 11 DMAs are in; round 0 of the weights still streams
+    if constexpr (XP) {
+        // hop 1 (wave 0): lane -> (row r = lane % 12, source s = lane / 12): sources s and s + 5 of the 9 (8 partials, then x'')
+        float *hop = stage + DF_D;                                 // [9][16] (rows 1.. of the staging area are free in this mode)
+        if (wave == 0) {
+            const int r = lane % 12, s0 = lane / 12;
+            const int orow = bid * 12 + r;
+            const bool act0 = lane < 60, act1 = lane < 48;
+            const u64 *pa = xp.gw + (size_t)(act0 ? s0 : 0) * DF_D + orow;
+            const u64 *pb = (s0 + 5 < 8 || !act1) ? xp.gw + (size_t)(act1 ? s0 + 5 : 0) * DF_D + orow : xp.gxin + orow;
+            const unsigned eb = (s0 + 5 < 8 || !act1) ? xp.w_epoch : xp.x_epoch;
+            u64 va = df_load_granule(pa), vb = df_load_granule(pb);
+            if (act0 && (unsigned)(va >> 32) != xp.w_epoch) va = (u64)__float_as_uint(df_wait_granule_e(pa, xp.w_epoch, a.err, a.spin_limit, 5u));
+            if (act1 && (unsigned)(vb >> 32) != eb) vb = (u64)__float_as_uint(df_wait_granule_e(pb, eb, a.err, a.spin_limit, 5u));
+            if (act0) hop[s0 * 16 + r] = __uint_as_float((unsigned)va);
+            if (act1) hop[(s0 + 5) * 16 + r] = __uint_as_float((unsigned)vb);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 12) {
+                float v = hop[8 * 16 + lane];
+#pragma unroll
+                for (int gi = 0; gi < 8; gi++) v += hop[gi * 16 + lane];        // x, then groups 0 .. 7: the memory prologue's order
+                df_store_granule(xp.gxp + bid * 12 + lane, a.epoch, v);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        FFN_ISSUE(2) FFN_ISSUE(3)
+        __builtin_amdgcn_sched_barrier(0);
+        // hop 2 (waves 1 .. 11): the x' sweep, 5 granules per thread, behind round 1 of the weights
+        if (wave > 0) {
+            const int i0 = (wave - 1) * 64 + lane;
+            u64 gv[5];
+#pragma unroll
+            for (int u = 0; u < 5; u++) gv[u] = df_load_granule(xp.gxp + min(i0 + 704 * u, DF_D - 1));
+#pragma unroll
+            for (int u = 0; u < 5; u++) {
+                const int idx = i0 + 704 * u;
+                if (idx < DF_D) {
+                    if ((unsigned)(gv[u] >> 32) != a.epoch) gv[u] = (u64)__float_as_uint(df_wait_granule_e(xp.gxp + idx, a.epoch, a.err, a.spin_limit, 6u));
+                    stage[idx] = __uint_as_float((unsigned)gv[u]);
+                }
+            }
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // the 11 DMAs are in; round 0 of the weights still streams
+    }
     __syncthreads();
     FFN_MARK(2);
     {
         float4 v = *reinterpret_cast<const float4 *>(stage + tid * 4);
+        if constexpr (!XP) {
 #pragma unroll
-        for (int gi = 1; gi <= 8; gi++) {
-            const float4 p = *reinterpret_cast<const float4 *>(stage + gi * DF_D + tid * 4);
-            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            for (int gi = 1; gi <= 8; gi++) {
+                const float4 p = *reinterpret_cast<const float4 *>(stage + gi * DF_D + tid * 4);
+                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+            *reinterpret_cast<float4 *>(stage + tid * 4) = v;          // x' stays in LDS for phase 2 (own elements: no hazard)
         }
-        *reinterpret_cast<float4 *>(stage + tid * 4) = v;          // x' stays in LDS for phase 2 (own elements: no hazard)
-        if (blockIdx.x == 0 && a.xprime_out) *reinterpret_cast<float4 *>(a.xprime_out + tid * 4) = v;
+        if (bid == 0 && a.xprime_out) *reinterpret_cast<float4 *>(a.xprime_out + tid * 4) = v;
         float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         ss = df_wave_sum<true>(ss);
         if (lane == 0) red[wave] = ss;
@@ -1167,7 +1239,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx)
         const float4 x1 = *reinterpret_cast<const float4 *>(xs + ((C) * 64 + lane) * 8 + 4);      \
         _Pragma("unroll") for (int m = 0; m < 2; m++)                                   \
             _Pragma("unroll") for (int r = 0; r < 3; r++) acc[m][r] = dot8_bf16(w[m][r][C], x0, x1, acc[m][r]); }
-    FFN_ISSUE(2) FFN_ISSUE(3)
+    if constexpr (!XP) { FFN_ISSUE(2) FFN_ISSUE(3) }
     __builtin_amdgcn_sched_barrier(0);
     FFN_DOT(0) FFN_DOT(1)
     __builtin_amdgcn_sched_barrier(0);
@@ -1191,7 +1263,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx)
     __syncthreads();
     uint4 w2r[18];
     {
-        const unsigned char *w2s = reinterpret_cast<const unsigned char *>(a.w2) + ((size_t)blockIdx.x * 12 * FFN_H + 768 * wave) * 2;
+        const unsigned char *w2s = reinterpret_cast<const unsigned char *>(a.w2) + ((size_t)bid * 12 * FFN_H + 768 * wave) * 2;
 #pragma unroll
         for (int c = 0; c < 18; c++) {
             const int m = c / 3, k = c - 3 * m;
@@ -1262,7 +1334,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx)
             float sum = 0.f;
 #pragma unroll
             for (int w12 = 0; w12 < 12; w12++) sum += part[w12 * 12 + tid];         // fixed order
-            const int orow = blockIdx.x * 12 + tid;
+            const int orow = bid * 12 + tid;
             const float xv = stage[orow] + sum;
             a.x_out[orow] = xv;
             if (gx) df_store_granule(gx + orow, a.epoch, xv);
@@ -1299,17 +1371,19 @@ constexpr int DA12_LDS_BYTES = 2 * DF_D * 4 + 4 * DF_TILE_BYTES + 1024 + 512;   
 // stores leave through the same queue as its loads), and the merge is the many-slices form: the (max, sum) pairs meet in LDS, every
 // slice's weight exp(m_s - M) / L is computed once per head, and a thread's 32 (head, dim) granules share one trip to L2 with them
 // while a slice is one tile (beyond that the members finish further apart and the early fetch would only be repeated).
+// gw (k_dec_stack): the Wo partial sums leave as {epoch, value} granules (gw[8][3072]) instead of a.wo_part, see ffn_body<XP>.
 template <bool XG, bool W8 = false, bool LONG = false>
-__device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned char *smem_raw, const u64 *gx, unsigned x_epoch) {
+__device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned char *smem_raw, const u64 *gx, unsigned x_epoch, u64 *gw = nullptr) {
     static_assert(!(LONG && W8), "the long-context form is bf16 only");
     float *xs = reinterpret_cast<float *>(smem_raw);                           // [3072] x, then [3072] norm weights (contiguous)
     float *nw = xs + DF_D;
     unsigned char *tiles = smem_raw + 2 * DF_D * 4;                            // [2 buffers][K tile | V tile]; later the Wo reduction scratch
     float *frq = reinterpret_cast<float *>(tiles + 4 * DF_TILE_BYTES);         // [256] inv_freq (64 valid)
     float *red = frq + 256;                                                    // [128]: wave sums, the 24 row results
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = df_tid(), lane = tid & 63;
+    const int bid = df_bid();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = LONG ? blockIdx.x / DF_BPG : blockIdx.x % DF_GROUPS, j = LONG ? blockIdx.x % DF_BPG : blockIdx.x / DF_GROUPS;
+    const int g = LONG ? bid / DF_BPG : bid % DF_GROUPS, j = LONG ? bid % DF_BPG : bid / DF_GROUPS;
     const unsigned epoch = a.epoch;
     const int pos = a.pos;
     unsigned long long df_stamp[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1745,7 +1819,10 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
             }
             sres += __shfl_xor(sres, 1, 4);
             sres += __shfl_xor(sres, 2, 4);
-            if (q == 0 && row < wo_n) a.wo_part[(size_t)g * DF_D + wo_row0 + row] = sres;
+            if (q == 0 && row < wo_n) {
+                if (gw) df_store_granule(gw + (size_t)g * DF_D + wo_row0 + row, epoch, sres);
+                else a.wo_part[(size_t)g * DF_D + wo_row0 + row] = sres;
+            }
         }
         DF_MARK(10);
     }
@@ -1771,6 +1848,63 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_attn12(const FfnArgs f, 
     ffn_body(f, smem, gx);
     __syncthreads();                        // every reader of the FFN block's LDS is done
     df_attn12_body<true, false, LONG>(a, reinterpret_cast<unsigned char *>(smem), gx, f.epoch);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_dec_stack (round 5) - layers' FFN and attention blocks of a decoder step as ONE launch: FFN(0), then for l = 1 .. L-1 the attention
+// block of layer l and its FFN block.  (Layer 0's attention block stays a launch of its own: it builds x from the adapter row and the
+// previous token's embedding, which the argmax kernel of the previous step has only just produced.)  Every hand-off inside is one of
+// the {epoch, value} granule sweeps of the kernels above, each queued behind weight bytes: h behind W2, x'' behind the first projection
+// pieces, and - new - x' in two hops behind rounds 0 and 1 of W1 / W3 (ffn_body<XP>).  The granule buffers are reused layer after
+// layer; a layer's tag is epoch0 + l.  Reuse is safe without any clearing because every buffer's producers of layer l + 1 depend,
+// through the all-to-all hand-offs in between, on every consumer of layer l having finished: see DESIGN.md 3.
+// ---------------------------------------------------------------------------------------------------------
+struct DecStackLayer {
+    const uint16_t *wqkv, *wo, *w1, *w3, *w2;
+    const float *n1, *n2, *ada;
+    float *kring, *vring;
+};
+struct DecStackArgs {
+    const DecStackLayer *layers;
+    int n_layers;
+    float eps;
+    const float *inv_freq;
+    int kv_cap, pos, window;
+    float scale;
+    const float *x0;           // [3072] residual stream in front of layer 0's attention output (written by its launch)
+    const float *wo_part;      // [8][3072] layer 0's Wo partial sums (memory, from its launch)
+    float *x_out;              // [3072] the stack's output
+    u64 *gq, *gp, *gh, *gx, *gw, *gxp;
+    unsigned epoch0;           // epoch of layer 0's attention launch; layer l uses epoch0 + l
+    int split_keys, nsplit;
+    unsigned *err;
+    unsigned long long spin_limit;
+};
+template <bool LONG>
+__global__ __launch_bounds__(FFN_THREADS, 1) void k_dec_stack(const DecStackArgs s) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    for (int l = 0; l < s.n_layers; l++) {
+        const DecStackLayer &L = s.layers[l];
+        if (l > 0) {
+            DecFuseArgs a{};
+            a.wqkv = L.wqkv; a.wo = L.wo; a.norm_w = L.n1; a.eps = s.eps; a.inv_freq = s.inv_freq;
+            a.kring = L.kring; a.vring = L.vring; a.kv_cap = s.kv_cap; a.pos = s.pos; a.window = s.window; a.scale = s.scale;
+            a.gq = s.gq; a.gp = s.gp; a.epoch = s.epoch0 + l; a.split_keys = s.split_keys; a.nsplit = s.nsplit;
+            a.err = s.err; a.spin_limit = s.spin_limit;
+            df_attn12_body<true, false, LONG>(a, reinterpret_cast<unsigned char *>(smem), s.gx, s.epoch0 + l - 1, s.gw);
+            __syncthreads();
+        }
+        FfnArgs f{};
+        f.w1 = L.w1; f.w3 = L.w3; f.w2 = L.w2; f.x = s.x0; f.wo_part = s.wo_part; f.norm_w = L.n2; f.ada = L.ada; f.eps = s.eps;
+        f.x_out = s.x_out; f.gh = s.gh; f.epoch = s.epoch0 + l; f.err = s.err; f.spin_limit = s.spin_limit;
+        if (l == 0) {
+            ffn_body<false>(f, smem, s.gx);
+        } else {
+            FfnXp xp{s.gw, s.gx, s.gxp, s.epoch0 + (unsigned)l, s.epoch0 + (unsigned)l - 1u};
+            ffn_body<true>(f, smem, s.gx, xp);
+        }
+        __syncthreads();                        // every reader of the FFN block's LDS is done
+    }
 }
 
 }  // namespace vox

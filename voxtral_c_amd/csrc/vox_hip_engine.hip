@@ -243,6 +243,10 @@ struct vox_hip_engine {
     u64 *d_gq = nullptr, *d_gp = nullptr, *d_gh = nullptr;
     int merge12 = 2;              // VOX_HIP_MERGE12: 0 = two launches per layer in the 8-wave shape (before), 1 = k_attn12 in place of k_dec_attn_fused where it applies (A/B of the shape), 2 = k_ffn_attn12
     u64 *d_gx = nullptr;          // [3072] x'' hand-off of k_ffn_attn12
+    int use_stack = 1;            // VOX_HIP_STACK=0 (A/B): one k_ffn_attn12 launch per layer (round 4) instead of ONE k_dec_stack launch for the layers' FFN / attention blocks
+    u64 *d_gw = nullptr, *d_gxp = nullptr;   // k_dec_stack: [8][3072] Wo partial sums, [3072] x' (hand-off granules)
+    DecStackLayer *d_stack_tab = nullptr;    // per-layer pointers of k_dec_stack (device copy of h_stack_tab)
+    std::vector<DecStackLayer> h_stack_tab;
     int merge12_long = 1;         // VOX_HIP_MERGE12_LONG=0 (A/B): beyond merge12_maxkeys two launches per layer in the 8-wave shape (round 4); 1 = k_ffn_attn12<LONG> (9 .. 32 key slices)
     int merge12_maxkeys = 1024;   // VOX_HIP_MERGE12_MAXKEYS: the merged launches up to this context length (8 key slices of two tiles beyond 512 keys; measured: 2048 = four tiles per member loses 2 % at 1900 keys)
     int wo_late = 1;              // VOX_HIP_FUSE_WO_LATE=0 (A/B, see DecFuseArgs)
@@ -696,7 +700,12 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  hipFuncSetAttribute((const void *)k_w2x_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, DA12_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_ffn_attn12<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_ffn_attn12<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
-                 dalloc(e, &e->d_gx, (size_t)DF_D) == 0 && hipMemset(e->d_gx, 0, (size_t)DF_D * 8) == hipSuccess;
+                 hipFuncSetAttribute((const void *)k_dec_stack<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_dec_stack<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
+                 dalloc(e, &e->d_gx, (size_t)DF_D) == 0 && hipMemset(e->d_gx, 0, (size_t)DF_D * 8) == hipSuccess &&
+                 dalloc(e, &e->d_gw, (size_t)8 * DF_D) == 0 && hipMemset(e->d_gw, 0, (size_t)8 * DF_D * 8) == hipSuccess &&
+                 dalloc(e, &e->d_gxp, (size_t)DF_D) == 0 && hipMemset(e->d_gxp, 0, (size_t)DF_D * 8) == hipSuccess &&
+                 dalloc(e, &e->d_stack_tab, (size_t)e->d.dec_layers) == 0;
             if (!ok) { (void)hipGetLastError(); fprintf(stderr, "vox_hip: fused decode kernels unavailable; launch-per-GEMV chain\n"); }
             e->use_fused = ok; e->fused_ok = ok;
             e->use_ffn = ok && !getenv("VOX_HIP_NO_FFN_FUSED");        // A/B: k_gemv_w13x + k_gemv_w2x instead of k_ffn_fused
@@ -706,6 +715,7 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
             if (getenv("VOX_HIP_MERGE12")) e->merge12 = atoi(getenv("VOX_HIP_MERGE12"));
             if (getenv("VOX_HIP_MERGE12_MAXKEYS")) e->merge12_maxkeys = atoi(getenv("VOX_HIP_MERGE12_MAXKEYS"));
             if (getenv("VOX_HIP_MERGE12_LONG")) e->merge12_long = atoi(getenv("VOX_HIP_MERGE12_LONG"));
+            if (getenv("VOX_HIP_STACK")) e->use_stack = atoi(getenv("VOX_HIP_STACK"));
             e->fp8_attn_bf16 = getenv("VOX_HIP_FP8_ATTN_BF16") != nullptr;
             e->fp8_lmhead_bf16 = getenv("VOX_HIP_FP8_LMHEAD_BF16") != nullptr;
             if (const char *pf = getenv("VOX_HIP_PF")) sscanf(pf, "%d,%d,%d", &e->pf_units, &e->pf_member_units, &e->pf_when);
@@ -1983,6 +1993,33 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             tap(2 * l, xin);              // (layer 0 of a stream step builds x inside the launch above and writes it to xin)
             // (fp8 mode keeps the two launches: with half the W2 bytes the 72 KB sweep and the dot products at the end are no longer
             //  hidden - measured 1.1055 against 1.0271 ms per step, gpurun_out/r4k)
+            if (l == 0 && shape12 && e->merge12 == 2 && e->use_stack && e->skip_kinds == 0 && !e->d_fuse_tl && d.dec_layers > 1) {
+                // k_dec_stack: every remaining block of the step - FFN(0), then attention + FFN of layers 1 .. L-1 - in ONE launch
+                std::vector<DecStackLayer> tab((size_t)d.dec_layers);
+                for (int k = 0; k < d.dec_layers; k++) {
+                    DecLayer &K = e->dec[k];
+                    tab[k] = DecStackLayer{K.wqkv, K.wo, K.w13, K.w13 + (size_t)DH * DD, K.w2, K.n1, K.n2, K.ada, K.kring, K.vring};
+                }
+                if (e->h_stack_tab.size() != tab.size() || memcmp(e->h_stack_tab.data(), tab.data(), tab.size() * sizeof(DecStackLayer)) != 0) {
+                    HC(hipMemcpyAsync(e->d_stack_tab, tab.data(), tab.size() * sizeof(DecStackLayer), hipMemcpyHostToDevice, s));
+                    HC(hipStreamSynchronize(s));          // (rare: the first step, or after the rings / ada vectors moved) the source is a local
+                    e->h_stack_tab = tab;
+                }
+                DecStackArgs sa{};
+                sa.layers = e->d_stack_tab; sa.n_layers = d.dec_layers; sa.eps = d.dec_eps; sa.inv_freq = e->dec_inv_freq;
+                sa.kv_cap = e->dec_ring_cap; sa.pos = kv_pos; sa.window = d.dec_window; sa.scale = scale;
+                sa.x0 = xin; sa.wo_part = e->d_wo_part; sa.x_out = xalt;
+                sa.gq = e->d_gq; sa.gp = e->d_gp; sa.gh = e->d_gh; sa.gx = e->d_gx; sa.gw = e->d_gw; sa.gxp = e->d_gxp;
+                sa.epoch0 = e->fuse_epoch; sa.split_keys = f_split; sa.nsplit = f_ns;
+                sa.err = e->d_fuse_err; sa.spin_limit = 500000ull;
+                e->fuse_epoch += (unsigned)d.dec_layers;
+                if (e->fuse_epoch > 0xFFFF0000u) e->fuse_epoch = 1;      // (tags are at most one step old: a restart of the counter cannot meet a stale one)
+                if (long12) hipLaunchKernelGGL(k_dec_stack<true>, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, sa);
+                else hipLaunchKernelGGL(k_dec_stack<false>, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, sa);
+                prof_mark(e, PK_W2);
+                std::swap(xin, xalt);
+                break;
+            }
             const bool merged_here = shape12 && e->merge12 == 2 && l + 1 < d.dec_layers;
             if (merged_here && (e->skip_kinds & (1u << PK_W2))) {      // timing experiment: the step without its k_ffn_attn12 launches
                 if (++e->fuse_epoch == 0) e->fuse_epoch = 1;
@@ -3106,6 +3143,7 @@ extern "C" unsigned vox_hip_active_paths(const vox_hip_engine_t *e) {
     if (fast_geom && e->use_fused && e->use_dpp && e->use_ffn && !e->use_fp8) m |= VOX_PATH_FFN_FUSED;
     if (e->use_rowsgemm && e->use_mfma) m |= VOX_PATH_ROWSGEMM;
     if (merged_static_ok(e)) m |= VOX_PATH_FFN_ATTN12;
+    if (merged_static_ok(e) && e->use_stack && e->d.dec_layers > 1) m |= VOX_PATH_DEC_STACK;
     return m;
 }
 

@@ -1118,8 +1118,10 @@ struct FfnXp {
     unsigned w_epoch, x_epoch;
 };
 // gx (optional): x'' also leaves as {epoch, value} granules (k_ffn_attn12: the attention block of the next layer in the same launch)
+// w: the caller's registers for the W1 / W3 pieces (an array indexed with constants only, so that it stays in registers across the
+// two bodies of k_dec_stack; a pointer to it would send it to scratch memory).
 template <bool XP = false>
-__device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx, const FfnXp &xp = FfnXp{}) {
+__device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx, uint4 (&w)[2][3][6], const FfnXp &xp = FfnXp{}) {
     float *stage = smem;                 // [9][3072]: x, wo_part[0..7]; after the prologue: row 0 = x', rows 1..3 = h
     float *nws = smem + 9 * DF_D;        // [3072] norm weights
     float *ads = nws + DF_D;             // [3072] ada
@@ -1144,7 +1146,6 @@ __device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx,
     glds16(a.norm_w + tid * 4, lds_addr(nws) + wofs);
     glds16(a.ada + tid * 4, lds_addr(ads) + wofs);
     __builtin_amdgcn_sched_barrier(0);
-    uint4 w[2][3][6];
     const int pair0 = bid * 36 + wave * 3;
     const uint4 *p1[3], *p3[3];
 #pragma unroll
@@ -1152,23 +1153,46 @@ __device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx,
         p1[r] = reinterpret_cast<const uint4 *>(a.w1 + (size_t)(pair0 + r) * DF_D) + lane;
         p3[r] = reinterpret_cast<const uint4 *>(a.w3 + (size_t)(pair0 + r) * DF_D) + lane;
     }
-#define FFN_ISSUE(C)                                                                    \
-    { _Pragma("unroll") for (int r = 0; r < 3; r++) w[0][r][C] = ld_stream(p1[r] + (C) * 64); \
-      _Pragma("unroll") for (int r = 0; r < 3; r++) w[1][r][C] = ld_stream(p3[r] + (C) * 64); }
+#define FFN_ISSUE_A(C) { _Pragma("unroll") for (int r = 0; r < 3; r++) w[0][r][C] = ld_stream(p1[r] + (C) * 64); }
+#define FFN_ISSUE_B(C) { _Pragma("unroll") for (int r = 0; r < 3; r++) w[1][r][C] = ld_stream(p3[r] + (C) * 64); }
+#define FFN_ISSUE(C) { FFN_ISSUE_A(C) FFN_ISSUE_B(C) }
     FFN_ISSUE(0) FFN_ISSUE(1)
     __builtin_amdgcn_sched_barrier(0);
     FFN_MARK(1);
     if constexpr (XP) {
+        // Schedule (per CU, 25 KB / us): pieces 0, 1 | hop-1 loads | pieces 2, 3 | sweep loads | piece 4.  A load returns behind
+        // everything queued before it and is looked up in L2 about 2 us earlier: hop 1 is looked up ~4 us after this workgroup left
+        // its attention block (the other workgroups leave theirs within ~2.5 us of each other), hop 2 ~10 us after, ~4 us after the
+        // owners published.  Piece 4 is queued before anybody waits, so the stream never runs dry while x' is in transit.
         // hop 1 (wave 0): lane -> (row r = lane % 12, source s = lane / 12): sources s and s + 5 of the 9 (8 partials, then x'')
         float *hop = stage + DF_D;                                 // [9][16] (rows 1.. of the staging area are free in this mode)
+        // (the addresses are derived again, from a laundered lane index, where a stale tag has to be waited for: kept live across the
+        //  weight issue below they cost the registers of half a weight piece)
+#define FFN_HOP_ADDR(LN)                                                                                         \
+        const int r = (LN) % 12, s0 = (LN) / 12;                                                                   \
+        const int orow = bid * 12 + r;                                                                             \
+        const bool act0 = (LN) < 60, act1 = (LN) < 48;                                                             \
+        const u64 *pa = xp.gw + (size_t)(act0 ? s0 : 0) * DF_D + orow;                                             \
+        const u64 *pb = (s0 + 5 < 8 || !act1) ? xp.gw + (size_t)(act1 ? s0 + 5 : 0) * DF_D + orow : xp.gxin + orow; \
+        const unsigned eb = (s0 + 5 < 8 || !act1) ? xp.w_epoch : xp.x_epoch;
+        u64 va = 0, vb = 0;
+        if (wave == 0) { FFN_HOP_ADDR(lane) (void)eb; va = df_load_granule(pa); vb = df_load_granule(pb); }
+        __builtin_amdgcn_sched_barrier(0);
+        FFN_ISSUE(2) FFN_ISSUE(3)
+        __builtin_amdgcn_sched_barrier(0);
+        // hop 2 (waves 1 .. 11): the x' sweep, 5 granules per thread
+        const int i0 = (wave - 1) * 64 + lane;
+        u64 gv[5] = {0, 0, 0, 0, 0};
+        if (wave > 0) {
+#pragma unroll
+            for (int u = 0; u < 5; u++) gv[u] = df_load_granule(xp.gxp + min(i0 + 704 * u, DF_D - 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        FFN_ISSUE_A(4)                  // (half a piece - 36 KB per CU, 1.4 us - is what the register budget allows and what the RMSNorm needs as cover)
+        __builtin_amdgcn_sched_barrier(0);
         if (wave == 0) {
-            const int r = lane % 12, s0 = lane / 12;
-            const int orow = bid * 12 + r;
-            const bool act0 = lane < 60, act1 = lane < 48;
-            const u64 *pa = xp.gw + (size_t)(act0 ? s0 : 0) * DF_D + orow;
-            const u64 *pb = (s0 + 5 < 8 || !act1) ? xp.gw + (size_t)(act1 ? s0 + 5 : 0) * DF_D + orow : xp.gxin + orow;
-            const unsigned eb = (s0 + 5 < 8 || !act1) ? xp.w_epoch : xp.x_epoch;
-            u64 va = df_load_granule(pa), vb = df_load_granule(pb);
+            const int lane2 = df_tid() & 63;
+            FFN_HOP_ADDR(lane2)
             if (act0 && (unsigned)(va >> 32) != xp.w_epoch) va = (u64)__float_as_uint(df_wait_granule_e(pa, xp.w_epoch, a.err, a.spin_limit, 5u));
             if (act1 && (unsigned)(vb >> 32) != eb) vb = (u64)__float_as_uint(df_wait_granule_e(pb, eb, a.err, a.spin_limit, 5u));
             if (act0) hop[s0 * 16 + r] = __uint_as_float((unsigned)va);
@@ -1182,16 +1206,7 @@ __device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx,
                 for (int gi = 0; gi < 8; gi++) v += hop[gi * 16 + lane];        // x, then groups 0 .. 7: the memory prologue's order
                 df_store_granule(xp.gxp + bid * 12 + lane, a.epoch, v);
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        FFN_ISSUE(2) FFN_ISSUE(3)
-        __builtin_amdgcn_sched_barrier(0);
-        // hop 2 (waves 1 .. 11): the x' sweep, 5 granules per thread, behind round 1 of the weights
-        if (wave > 0) {
-            const int i0 = (wave - 1) * 64 + lane;
-            u64 gv[5];
-#pragma unroll
-            for (int u = 0; u < 5; u++) gv[u] = df_load_granule(xp.gxp + min(i0 + 704 * u, DF_D - 1));
+        } else {
 #pragma unroll
             for (int u = 0; u < 5; u++) {
                 const int idx = i0 + 704 * u;
@@ -1241,14 +1256,27 @@ __device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx,
             _Pragma("unroll") for (int r = 0; r < 3; r++) acc[m][r] = dot8_bf16(w[m][r][C], x0, x1, acc[m][r]); }
     if constexpr (!XP) { FFN_ISSUE(2) FFN_ISSUE(3) }
     __builtin_amdgcn_sched_barrier(0);
-    FFN_DOT(0) FFN_DOT(1)
-    __builtin_amdgcn_sched_barrier(0);
-    FFN_ISSUE(4) FFN_ISSUE(5)
+    if constexpr (XP) {
+        FFN_ISSUE_B(4)
+        __builtin_amdgcn_sched_barrier(0);
+        FFN_DOT(0)
+        __builtin_amdgcn_sched_barrier(0);
+        FFN_ISSUE(5)
+        __builtin_amdgcn_sched_barrier(0);
+        FFN_DOT(1)
+    } else {
+        FFN_DOT(0) FFN_DOT(1)
+        __builtin_amdgcn_sched_barrier(0);
+        FFN_ISSUE(4) FFN_ISSUE(5)
+    }
     __builtin_amdgcn_sched_barrier(0);
     FFN_DOT(2) FFN_DOT(3)
     __builtin_amdgcn_sched_barrier(0);
     FFN_DOT(4) FFN_DOT(5)
+#undef FFN_HOP_ADDR
 #undef FFN_ISSUE
+#undef FFN_ISSUE_A
+#undef FFN_ISSUE_B
 #undef FFN_DOT
 #pragma unroll
     for (int m = 0; m < 2; m++)
@@ -1346,7 +1374,8 @@ __device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx,
 }
 __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_fused(const FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    ffn_body(a, smem, nullptr);
+    uint4 w[2][3][6];
+    ffn_body(a, smem, nullptr, w);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1742,40 +1771,46 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
 #undef DA12_GV_PTR
             }
         } else
-        if (tid < 512) {
+        {
             for (int s0 = 0; s0 < ns; s0 += 4) {
                 u64 gv[4][3];
                 const unsigned long long t0 = wall_clock64();
                 for (unsigned it = 0;; it++) {
                     bool ok = true;
+                    if (tid < 512) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const u64 *part = gp + (size_t)min(s0 + u, ns - 1) * DF_GP;
-                        gv[u][0] = df_load_granule(part + h * DF_HD + d);
-                        gv[u][1] = df_load_granule(part + 4 * DF_HD + 2 * h);
-                        gv[u][2] = df_load_granule(part + 4 * DF_HD + 2 * h + 1);
+                        for (int u = 0; u < 4; u++) {
+                            const u64 *part = gp + (size_t)min(s0 + u, ns - 1) * DF_GP;
+                            gv[u][0] = df_load_granule(part + h * DF_HD + d);
+                            gv[u][1] = df_load_granule(part + 4 * DF_HD + 2 * h);
+                            gv[u][2] = df_load_granule(part + 4 * DF_HD + 2 * h + 1);
+                        }
                     }
+                    if (tid < 512) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
+                        for (int u = 0; u < 4; u++)
 #pragma unroll
-                        for (int k = 0; k < 3; k++) ok = ok && (unsigned)(gv[u][k] >> 32) == epoch;
+                            for (int k = 0; k < 3; k++) ok = ok && (unsigned)(gv[u][k] >> 32) == epoch;
+                    }
                     if (ok) break;
                     if ((it & 15u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                     if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     __builtin_amdgcn_s_sleep(4);
                 }
+                if (tid < 512) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (s0 + u >= ns) break;
-                    const float v0 = __uint_as_float((unsigned)gv[u][0]), vm = __uint_as_float((unsigned)gv[u][1]), vl = __uint_as_float((unsigned)gv[u][2]);
-                    const float mn = fmaxf(M, vm);
-                    const float c0 = expf(M - mn), c1 = expf(vm - mn);
-                    L = L * c0 + vl * c1;
-                    O = O * c0 + v0 * c1;
-                    M = mn;
+                    for (int u = 0; u < 4; u++) {
+                        if (s0 + u >= ns) break;
+                        const float v0 = __uint_as_float((unsigned)gv[u][0]), vm = __uint_as_float((unsigned)gv[u][1]), vl = __uint_as_float((unsigned)gv[u][2]);
+                        const float mn = fmaxf(M, vm);
+                        const float c0 = expf(M - mn), c1 = expf(vm - mn);
+                        L = L * c0 + vl * c1;
+                        O = O * c0 + v0 * c1;
+                        M = mn;
+                    }
                 }
             }
-            att[h * DF_HD + d] = L > 0.f ? O / L : 0.f;
+            if (tid < 512) att[h * DF_HD + d] = L > 0.f ? O / L : 0.f;
         }
         DF_MARK(8);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the Wo rows (and the prefetch DMAs) have landed
@@ -1845,7 +1880,8 @@ constexpr int FA12_LDS_BYTES = FFN_LDS_BYTES > DA12_LDS_BYTES ? FFN_LDS_BYTES : 
 template <bool LONG>
 __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_attn12(const FfnArgs f, const DecFuseArgs a, u64 *gx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    ffn_body(f, smem, gx);
+    uint4 w[2][3][6];
+    ffn_body(f, smem, gx, w);
     __syncthreads();                        // every reader of the FFN block's LDS is done
     df_attn12_body<true, false, LONG>(a, reinterpret_cast<unsigned char *>(smem), gx, f.epoch);
 }
@@ -1883,6 +1919,7 @@ struct DecStackArgs {
 template <bool LONG>
 __global__ __launch_bounds__(FFN_THREADS, 1) void k_dec_stack(const DecStackArgs s) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint4 w[2][3][6];
     for (int l = 0; l < s.n_layers; l++) {
         const DecStackLayer &L = s.layers[l];
         if (l > 0) {
@@ -1898,10 +1935,10 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_dec_stack(const DecStackArgs
         f.w1 = L.w1; f.w3 = L.w3; f.w2 = L.w2; f.x = s.x0; f.wo_part = s.wo_part; f.norm_w = L.n2; f.ada = L.ada; f.eps = s.eps;
         f.x_out = s.x_out; f.gh = s.gh; f.epoch = s.epoch0 + l; f.err = s.err; f.spin_limit = s.spin_limit;
         if (l == 0) {
-            ffn_body<false>(f, smem, s.gx);
+            ffn_body<false>(f, smem, s.gx, w);
         } else {
             FfnXp xp{s.gw, s.gx, s.gxp, s.epoch0 + (unsigned)l, s.epoch0 + (unsigned)l - 1u};
-            ffn_body<true>(f, smem, s.gx, xp);
+            ffn_body<true>(f, smem, s.gx, w, xp);
         }
         __syncthreads();                        // every reader of the FFN block's LDS is done
     }

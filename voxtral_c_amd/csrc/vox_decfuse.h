@@ -1894,6 +1894,9 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_attn12(const FfnArgs f, 
 // pieces, and - new - x' in two hops behind rounds 0 and 1 of W1 / W3 (ffn_body<XP>).  The granule buffers are reused layer after
 // layer; a layer's tag is epoch0 + l.  Reuse is safe without any clearing because every buffer's producers of layer l + 1 depend,
 // through the all-to-all hand-offs in between, on every consumer of layer l having finished: see DESIGN.md 3.
+// Up to 8 key slices (1024 keys).  Beyond, the step stays one k_ffn_attn12<LONG> launch per layer: measured, the long form of this
+// kernel gains nothing there (-1 .. +1 %, profiles/r05_stack_ab.txt) - its attention block ends in a chain of three trips to L2
+// that no weight byte covers, and the boundary it saves is short next to that.
 // ---------------------------------------------------------------------------------------------------------
 struct DecStackLayer {
     const uint16_t *wqkv, *wo, *w1, *w3, *w2;
@@ -1916,7 +1919,6 @@ struct DecStackArgs {
     unsigned *err;
     unsigned long long spin_limit;
 };
-template <bool LONG>
 __global__ __launch_bounds__(FFN_THREADS, 1) void k_dec_stack(const DecStackArgs s) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint4 w[2][3][6];
@@ -1928,7 +1930,7 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_dec_stack(const DecStackArgs
             a.kring = L.kring; a.vring = L.vring; a.kv_cap = s.kv_cap; a.pos = s.pos; a.window = s.window; a.scale = s.scale;
             a.gq = s.gq; a.gp = s.gp; a.epoch = s.epoch0 + l; a.split_keys = s.split_keys; a.nsplit = s.nsplit;
             a.err = s.err; a.spin_limit = s.spin_limit;
-            df_attn12_body<true, false, LONG>(a, reinterpret_cast<unsigned char *>(smem), s.gx, s.epoch0 + l - 1, s.gw);
+            df_attn12_body<true, false, false>(a, reinterpret_cast<unsigned char *>(smem), s.gx, s.epoch0 + l - 1, s.gw);
             __syncthreads();
         }
         FfnArgs f{};

@@ -700,8 +700,7 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  hipFuncSetAttribute((const void *)k_w2x_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, DA12_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_ffn_attn12<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_ffn_attn12<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_dec_stack<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_dec_stack<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_dec_stack, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
                  dalloc(e, &e->d_gx, (size_t)DF_D) == 0 && hipMemset(e->d_gx, 0, (size_t)DF_D * 8) == hipSuccess &&
                  dalloc(e, &e->d_gw, (size_t)8 * DF_D) == 0 && hipMemset(e->d_gw, 0, (size_t)8 * DF_D * 8) == hipSuccess &&
                  dalloc(e, &e->d_gxp, (size_t)DF_D) == 0 && hipMemset(e->d_gxp, 0, (size_t)DF_D * 8) == hipSuccess &&
@@ -1993,7 +1992,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             tap(2 * l, xin);              // (layer 0 of a stream step builds x inside the launch above and writes it to xin)
             // (fp8 mode keeps the two launches: with half the W2 bytes the 72 KB sweep and the dot products at the end are no longer
             //  hidden - measured 1.1055 against 1.0271 ms per step, gpurun_out/r4k)
-            if (l == 0 && shape12 && e->merge12 == 2 && e->use_stack && e->skip_kinds == 0 && !e->d_fuse_tl && d.dec_layers > 1) {
+            if (l == 0 && shape12 && !long12 && e->merge12 == 2 && e->use_stack && e->skip_kinds == 0 && !e->d_fuse_tl && d.dec_layers > 1) {
                 // k_dec_stack: every remaining block of the step - FFN(0), then attention + FFN of layers 1 .. L-1 - in ONE launch
                 std::vector<DecStackLayer> tab((size_t)d.dec_layers);
                 for (int k = 0; k < d.dec_layers; k++) {
@@ -2014,8 +2013,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 sa.err = e->d_fuse_err; sa.spin_limit = 500000ull;
                 e->fuse_epoch += (unsigned)d.dec_layers;
                 if (e->fuse_epoch > 0xFFFF0000u) e->fuse_epoch = 1;      // (tags are at most one step old: a restart of the counter cannot meet a stale one)
-                if (long12) hipLaunchKernelGGL(k_dec_stack<true>, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, sa);
-                else hipLaunchKernelGGL(k_dec_stack<false>, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, sa);
+                hipLaunchKernelGGL(k_dec_stack, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, sa);
                 prof_mark(e, PK_W2);
                 std::swap(xin, xalt);
                 break;

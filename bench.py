@@ -38,6 +38,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (≈6.3 TB/s a
 # the W1;W3 + SwiGLU decode GEMV as rocprofv3 prints it: fused chain / launch-per-GEMV chain
 DOM_KERNEL_FFN, DOM_KERNEL_FUSED, DOM_KERNEL_CHAIN = "k_ffn_fused", "k_gemv_w13x", "k_gemv3<1, 3, 3, 6, 1, 3"
 DOM_KERNEL_MERGED = "k_ffn_attn12"
+DOM_KERNEL_STACK = "k_dec_stack"
 PK_NAMES_FUSED = {"gemv_qkv_rope_kv": "fused_qkv_attn_wo"}
 
 
@@ -209,6 +210,12 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True, graph_floor=
     n_merged = int(v.hip.vox_hip_merged_launches_per_step(model.engine, kv_len)) if ffn else 0
     if n_merged:
         DOM_KERNEL_SUBSTR = DOM_KERNEL_MERGED
+    # round 5: up to 1024 keys FFN(0) and the attention + FFN blocks of layers 1 .. L-1 are ONE launch (k_dec_stack)
+    v.hip.vox_hip_stack_layers.restype = C.c_int
+    v.hip.vox_hip_stack_layers.argtypes = [C.c_void_p, C.c_int]
+    n_stack = int(v.hip.vox_hip_stack_layers(model.engine, kv_len)) if n_merged else 0
+    if n_stack:
+        DOM_KERNEL_SUBSTR = DOM_KERNEL_STACK
     avg = (C.c_double * 9)(); cnt = (C.c_int * 9)()
     s_per_step_prof = v.hip.vox_hip_profile_decode(model.engine, 20, kv_len, avg, cnt)
     s_per_step = model.time_decoder_step(50, kv_len)
@@ -220,7 +227,7 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True, graph_floor=
     def _kname(nm):
         nm = PK_NAMES_FUSED.get(nm, nm) if fused else nm
         if n_merged and nm == "gemv_w2_resid":
-            return "fused_ffn_attn"
+            return "dec_stack" if n_stack else "fused_ffn_attn"
         return "fused_ffn" if (ffn and nm == "gemv_swiglu") else nm
     cached = {_kname(PK_NAMES[i]): round(avg_c[i], 2) for i in range(9) if cnt_c[i]}
     kernels = {}
@@ -231,20 +238,22 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True, graph_floor=
         kern_bytes["fused_ffn"] = kern_bytes["gemv_swiglu"] + kern_bytes["gemv_w2_resid"]
     if n_merged:   # ... and the next layer's qkv rows, KV window and wo rows: 232.8 MB + KV
         kern_bytes["fused_ffn_attn"] = kern_bytes["fused_ffn"] + kern_bytes["fused_qkv_attn_wo"]
+    if n_stack:    # L FFN blocks and L - 1 attention blocks in one launch
+        kern_bytes["dec_stack"] = n_stack * kern_bytes["fused_ffn"] + (n_stack - 1) * kern_bytes["fused_qkv_attn_wo"]
     for i, name in enumerate(PK_NAMES):
         if fused:
             name = PK_NAMES_FUSED.get(name, name)
         if ffn and name == "gemv_swiglu":
             name = "fused_ffn"
         if n_merged and name == "gemv_w2_resid":
-            name = "fused_ffn_attn"
+            name = "dec_stack" if n_stack else "fused_ffn_attn"
         if cnt[i]:
             ent = {"launches_per_token": cnt[i], "avg_us": round(avg[i], 2)}
             if name in kern_bytes:
                 ent["bytes"] = kern_bytes[name]
                 ent["GBps"] = round(kern_bytes[name] / (avg[i] * 1e-6) / 1e9, 1) if avg[i] > 0 else 0.0
             kernels[name] = ent
-    dom = "fused_ffn_attn" if n_merged else "fused_ffn" if ffn else "gemv_swiglu"
+    dom = "dec_stack" if n_stack else "fused_ffn_attn" if n_merged else "fused_ffn" if ffn else "gemv_swiglu"
     # Launch duration of the dominant kernel inside the chain: HIP events around N whole decode
     # steps with and without the 26 w1;w3 launches, on the engine stream; the difference / 26 is
     # what one launch costs in situ (boundary included, no event packets between kernels).  The
@@ -254,7 +263,7 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True, graph_floor=
     t_full, t_skip = C.c_double(), C.c_double()
     dom_us = None
     if v.hip.vox_hip_time_decoder_step_without(model.engine, 50, kv_len, 6 if n_merged else 5, C.byref(t_full), C.byref(t_skip)) == 0:
-        dom_us = (t_full.value - t_skip.value) / (n_merged if n_merged else dims.dec_layers) * 1e6
+        dom_us = (t_full.value - t_skip.value) / (1 if n_stack else n_merged if n_merged else dims.dec_layers) * 1e6
     if dom_us and dom_us > 0:
         dom_bytes = kern_bytes[dom] // (2 if weights == "fp8" else 1)
         dom_ach = round(dom_bytes / (dom_us * 1e-6) / 1e9, 1)
@@ -289,14 +298,18 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True, graph_floor=
     if graph_floor:        # (--no-graph-floor: rocprofv3's kernel tracing crashed inside the hipGraph capture of this probe, round 4)
         floor_us.update({f"graph_{g}": round(v.hip.vox_hip_time_empty_launches_graph(model.engine, 2000, g) * 1e6, 2) for g in (256, 768)})
     roofline = {
-        "bound": "hbm", "kernel": ("k_ffn_attn12 (decoder FFN block of layer l - W1;W3 GEMV, hand-off of h, W2 GEMV - and the attention block of layer l + 1 - "
+        "bound": "hbm", "kernel": (f"k_dec_stack (the FFN block of layer 0 and the attention + FFN blocks of layers 1 .. {n_stack - 1} of a decoder step as ONE launch: per layer "
+                                   "x'' hand-off, wq;wk;wv GEMV, RoPE, KV append, attention, wo GEMV, x' hand-off in two hops, W1;W3 GEMV, hand-off of h, W2 GEMV; "
+                                   "87% of the bytes of a token; around it: layer 0's attention launch, the logits GEMV, the argmax)" if n_stack else
+                                   "k_ffn_attn12 (decoder FFN block of layer l - W1;W3 GEMV, hand-off of h, W2 GEMV - and the attention block of layer l + 1 - "
                                    "x'' hand-off, wq;wk;wv GEMV, RoPE, KV append, attention, wo GEMV - as one launch; 25 launches = 84% of the bytes of a token)" if n_merged else
                                   "k_ffn_fused (decoder FFN block: W1;W3 GEMV, in-kernel hand-off of h, W2 GEMV; 64% of the weight bytes of a token)" if ffn else
                                   ("k_gemv_w13x" if fused else "k_gemv3<PRO_RMS,EPI_SWIGLU,3,6,1,3>") +
                                   " (decoder W1;W3 GEMV, 43% of the weight bytes of a token)"),
         "achieved": dom_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_ach / HBM_PEAK_GBS, 4),
         "bytes_per_launch": kern_bytes[dom] // (2 if weights == "fp8" else 1), "avg_us_per_launch": round(dom_us, 2),
-        "method": ("HIP events on the engine stream around 50 decode steps with and without the 25 launches of this kernel; (full - skipped) / 25 "
+        "method": "HIP events on the engine stream around 50 decode steps with and without the ONE launch of this kernel per step; full - skipped" if n_stack else
+                  ("HIP events on the engine stream around 50 decode steps with and without the 25 launches of this kernel; (full - skipped) / 25 "
                    "(the skipped runs keep layer 0's attention launch, the last layer's FFN launch, the logits GEMV and the argmax)") if n_merged else
                   "HIP events on the engine stream around 50 decode steps with and without the 26 launches of this kernel; "
                   "(full - skipped) / 26" + (" (the skipped runs leave out the whole FFN launch)" if ffn else ""),

@@ -252,6 +252,10 @@ int vox_hip_time_decoder_step_without(vox_hip_engine_t *e, int iters, int kv_len
 /* Launches of k_ffn_attn12 in a decode step at this KV length (0 = the step uses k_dec_attn_fused + k_ffn_fused per layer).  With a non-zero
  * answer, kind 6 of vox_hip_time_decoder_step_without leaves out exactly these launches. */
 int vox_hip_merged_launches_per_step(const vox_hip_engine_t *e, int kv_len);
+/* Round 5: layers whose blocks run inside the ONE k_dec_stack launch of a decode step at this KV length (FFN block of layer 0, attention
+ * and FFN blocks of layers 1 .. L-1; 0 = the stack kernel is not used there: beyond 1024 keys, fp8 mode, VOX_HIP_STACK=0).  With a
+ * non-zero answer, kind 6 of vox_hip_time_decoder_step_without leaves out exactly that launch. */
+int vox_hip_stack_layers(const vox_hip_engine_t *e, int kv_len);
 
 /* BASELINE config 5: quantise the decoder matrices and the tied embedding to fp8 e4m3 (one f32 scale
  * per output row) for the decode GEMVs; prefill and the encoder keep bf16.  Call after the uploads.

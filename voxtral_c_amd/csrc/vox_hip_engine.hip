@@ -1992,7 +1992,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             tap(2 * l, xin);              // (layer 0 of a stream step builds x inside the launch above and writes it to xin)
             // (fp8 mode keeps the two launches: with half the W2 bytes the 72 KB sweep and the dot products at the end are no longer
             //  hidden - measured 1.1055 against 1.0271 ms per step, gpurun_out/r4k)
-            if (l == 0 && shape12 && !long12 && e->merge12 == 2 && e->use_stack && e->skip_kinds == 0 && !e->d_fuse_tl && d.dec_layers > 1) {
+            if (l == 0 && shape12 && !long12 && e->merge12 == 2 && e->use_stack && !e->d_fuse_tl && d.dec_layers > 1) {
                 // k_dec_stack: every remaining block of the step - FFN(0), then attention + FFN of layers 1 .. L-1 - in ONE launch
                 std::vector<DecStackLayer> tab((size_t)d.dec_layers);
                 for (int k = 0; k < d.dec_layers; k++) {
@@ -2013,7 +2013,8 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 sa.err = e->d_fuse_err; sa.spin_limit = 500000ull;
                 e->fuse_epoch += (unsigned)d.dec_layers;
                 if (e->fuse_epoch > 0xFFFF0000u) e->fuse_epoch = 1;      // (tags are at most one step old: a restart of the counter cannot meet a stale one)
-                hipLaunchKernelGGL(k_dec_stack, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, sa);
+                if (!(e->skip_kinds & (1u << PK_W2)))        // (timing experiment, kind 6: the step without this launch)
+                    hipLaunchKernelGGL(k_dec_stack, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, sa);
                 prof_mark(e, PK_W2);
                 std::swap(xin, xalt);
                 break;
@@ -2751,6 +2752,13 @@ extern "C" int vox_hip_merged_launches_per_step(const vox_hip_engine_t *e, int k
     if (!e || !merged_static_ok(e)) return 0;
     const int kl = std::min(std::max(kv_len, 1), e->d.dec_window);
     return (kl <= std::max(512, e->merge12_maxkeys) || e->merge12_long) ? e->d.dec_layers - 1 : 0;
+}
+
+// Layers whose blocks run inside the ONE k_dec_stack launch of a decode step at this KV length (0 = the stack kernel is not used there).
+extern "C" int vox_hip_stack_layers(const vox_hip_engine_t *e, int kv_len) {
+    if (!e || !merged_static_ok(e) || !e->use_stack || e->d.dec_layers < 2) return 0;
+    const int kl = std::min(std::max(kv_len, 1), e->d.dec_window);
+    return kl <= std::max(512, e->merge12_maxkeys) ? e->d.dec_layers : 0;
 }
 
 // Per-kernel average durations of the decode step, measured with HIP events recorded on the

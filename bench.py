@@ -95,6 +95,28 @@ def headline_audio(seconds, mode="batch"):
     return tiled, None, None, f"the 30 s night1968 clip of tests/golden/stream_full_batch.npz tiled / cut to {seconds:g} s"
 
 
+def prefix_parity_block(tokens, seconds, slack=32):
+    """No golden of exactly this length: the clip is a prefix of the tiled 600 s / 300 s inputs, and encoder and decoder are causal,
+    so all ids but the last few (right padding and flush of THIS clip's end) must equal the longer golden's first ids."""
+    for name in ("stream_full_batch600.npz", "stream_full_batch300.npz"):
+        path = os.path.join(ROOT, "tests", "golden", name)
+        try:
+            gl = np.load(path, allow_pickle=True)
+            total = int(gl["audio_total_samples"]) if "audio_total_samples" in gl.files else len(gl["audio_i16"])
+        except Exception:
+            continue
+        if total < int(round(seconds * 16000)):
+            continue
+        ref = gl["tokens"]
+        t = np.asarray(tokens)
+        n = max(0, min(len(t) - slack, len(ref)))
+        mism = int((t[:n] != ref[:n]).sum())
+        first = next((int(i) for i in range(n) if t[i] != ref[i]), None)
+        return {"checked": n > 0, "steps": int(n), "mismatches": mism, "first_mismatch": first, "steps_run": int(len(t)),
+                "golden": f"tests/golden/{name}: its first {n} ids (this clip is a prefix of that input; the last {slack} steps see this clip's own end and are not compared)"}
+    return {"checked": False, "reason": "no golden for this length"}
+
+
 def parity_block(tokens, g, golden_name=None):
     """Token ids of the timed pass against the reference's own run (golden generated from oracle/_ref)."""
     if g is None:

@@ -165,6 +165,12 @@ def test_bench_self_launches_two_ranks_and_matches_the_reference_golden():
     assert out["decoder_steps_per_pass"] == 2 * 386
     assert out["replica"]["parity_checked_ranks"] == 2 and out["replica"]["parity_mismatches_all_ranks"] == 0
     assert out["replica"]["value"] > 0 and out["value"] > 0
+    # round 5: the same line carries BASELINE config 4 as a second phase - ONE clip of 2 x 75 s, encoder sharded over both ranks,
+    # decoder on rank 0 - checked against the first ids of the reference's 600 s run (the 150 s clip is a prefix of that input)
+    c4 = out["config4"]
+    assert c4["completed"] and c4["audio_seconds"] == 150.0 and c4["value"] > 0 and c4["decoder_steps"] > 1800, c4
+    assert c4["parity"]["checked"] and c4["parity"]["mismatches"] == 0 and c4["parity"]["steps"] > 1780, c4["parity"]
+    assert set(c4["phases_ms"]) >= {"encode", "prefill", "decode"}
 
 
 def test_bench_reports_no_value_when_the_sharded_pass_fails():

@@ -84,6 +84,47 @@ def _wav(samples_i16, rate=16000, channels=1, data_size=None):
     return hdr + b"LIST" + struct.pack("<I", 3) + b"abc\0" + b"data" + struct.pack("<I", ds) + raw
 
 
+def test_tokenizer_on_the_real_tekken_layout_matches_the_reference(ref_tiny):
+    """tests/golden/tekken_real_layout.json (tools/make_tekken_fixture.py): pretty-printed, "config" with a regex full of
+    backslashes first, a token_str to skip in every vocab entry (\\u escapes, surrogate pairs, escaped quotes, braces / brackets /
+    commas inside strings, null), arbitrary bytes in token_bytes (NUL, half UTF-8 sequences, 120-byte tokens), special tokens with
+    \\u escapes and is_control, nested objects after the arrays.  Every id is decoded by the host library and by the reference's own
+    tokenizer (voxtral_tokenizer.c:186-360, compiled from /root/reference): the bytes must be identical, id by id."""
+    import base64
+    import json
+    import voxtral_c_amd as v
+    path = os.path.join(ROOT, "tests", "golden", "tekken_real_layout.json")
+    doc = json.load(open(path, encoding="utf-8"))
+    libs = []
+    for L in (v.lib, ref_tiny.lib):
+        L.vox_tokenizer_load.restype = C.c_void_p
+        L.vox_tokenizer_load.argtypes = [C.c_char_p]
+        L.vox_tokenizer_decode.restype = C.c_char_p
+        L.vox_tokenizer_decode.argtypes = [C.c_void_p, C.c_int]
+        L.vox_tokenizer_free.argtypes = [C.c_void_p]
+        t = L.vox_tokenizer_load(path.encode())
+        assert t
+        libs.append((L, t))
+    n_vocab = len(doc["vocab"])
+    n_diff = 0
+    for tid in list(range(-2, 1000 + n_vocab + 8)) + [131071, 131072, 1 << 30]:
+        got, want = libs[0][0].vox_tokenizer_decode(libs[0][1], tid), libs[1][0].vox_tokenizer_decode(libs[1][1], tid)
+        if got != want:
+            n_diff += 1
+            assert n_diff < 5, (tid, got, want)
+    assert n_diff == 0
+    # and the reference itself says what the file says (C strings: a token's bytes up to its first NUL)
+    host, t = libs[0]
+    assert host.vox_tokenizer_decode(t, 32) == b"[STREAMING_PAD]"
+    assert host.vox_tokenizer_decode(t, 40) == '<caf\u00e9 "q" \\ x>'.encode()
+    assert host.vox_tokenizer_decode(t, 41) == "\u65e5\u672c".encode()
+    for r in (0, 5, 7, 19, 21, 24, 26, 28, 30, 45, 300, 2999):
+        raw = base64.b64decode(doc["vocab"][r]["token_bytes"])
+        assert host.vox_tokenizer_decode(t, 1000 + r) == raw.split(b"\x00")[0], r
+    for L, t in libs:
+        L.vox_tokenizer_free(t)
+
+
 def test_wav_parser_cases(tmp_path):
     import voxtral_c_amd as v
     x = (np.sin(np.arange(3200) * 0.05) * 12000).astype(np.int16)

@@ -260,8 +260,8 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True, graph_floor=
         kern_bytes["fused_ffn"] = kern_bytes["gemv_swiglu"] + kern_bytes["gemv_w2_resid"]
     if n_merged:   # ... and the next layer's qkv rows, KV window and wo rows: 232.8 MB + KV
         kern_bytes["fused_ffn_attn"] = kern_bytes["fused_ffn"] + kern_bytes["fused_qkv_attn_wo"]
-    if n_stack:    # L FFN blocks and L - 1 attention blocks in one launch
-        kern_bytes["dec_stack"] = n_stack * kern_bytes["fused_ffn"] + (n_stack - 1) * kern_bytes["fused_qkv_attn_wo"]
+    if n_stack:    # the attention and FFN blocks of all L layers in one launch (layer 0's attention block builds x from the adapter row and the previous token's embedding)
+        kern_bytes["dec_stack"] = n_stack * (kern_bytes["fused_ffn"] + kern_bytes["fused_qkv_attn_wo"])
     for i, name in enumerate(PK_NAMES):
         if fused:
             name = PK_NAMES_FUSED.get(name, name)
@@ -320,9 +320,9 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True, graph_floor=
     if graph_floor:        # (--no-graph-floor: rocprofv3's kernel tracing crashed inside the hipGraph capture of this probe, round 4)
         floor_us.update({f"graph_{g}": round(v.hip.vox_hip_time_empty_launches_graph(model.engine, 2000, g) * 1e6, 2) for g in (256, 768)})
     roofline = {
-        "bound": "hbm", "kernel": (f"k_dec_stack (the FFN block of layer 0 and the attention + FFN blocks of layers 1 .. {n_stack - 1} of a decoder step as ONE launch: per layer "
+        "bound": "hbm", "kernel": (f"k_dec_stack (the attention and FFN blocks of all {n_stack} layers of a decoder step as ONE launch: embedding gather, then per layer "
                                    "x'' hand-off, wq;wk;wv GEMV, RoPE, KV append, attention, wo GEMV, x' hand-off in two hops, W1;W3 GEMV, hand-off of h, W2 GEMV; "
-                                   "87% of the bytes of a token; around it: layer 0's attention launch, the logits GEMV, the argmax)" if n_stack else
+                                   "88% of the bytes of a token; behind it: the logits GEMV and the argmax)" if n_stack else
                                    "k_ffn_attn12 (decoder FFN block of layer l - W1;W3 GEMV, hand-off of h, W2 GEMV - and the attention block of layer l + 1 - "
                                    "x'' hand-off, wq;wk;wv GEMV, RoPE, KV append, attention, wo GEMV - as one launch; 25 launches = 84% of the bytes of a token)" if n_merged else
                                   "k_ffn_fused (decoder FFN block: W1;W3 GEMV, in-kernel hand-off of h, W2 GEMV; 64% of the weight bytes of a token)" if ffn else

@@ -1116,6 +1116,8 @@ struct FfnXp {
     const u64 *gxin;           // [3072] x'' of the previous FFN block
     u64 *gxp;                  // [3072] x' of this block (tagged a.epoch)
     unsigned w_epoch, x_epoch;
+    const float *x_adapter;    // layer 0 (gxin == nullptr): x = x_adapter[row] + bf16(x_emb[row]), the step's embedding
+    const uint16_t *x_emb;
 };
 // gx (optional): x'' also leaves as {epoch, value} granules (k_ffn_attn12: the attention block of the next layer in the same launch)
 // w: the caller's registers for the W1 / W3 pieces (an array indexed with constants only, so that it stays in registers across the
@@ -1176,7 +1178,13 @@ __device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx,
         const u64 *pb = (s0 + 5 < 8 || !act1) ? xp.gw + (size_t)(act1 ? s0 + 5 : 0) * DF_D + orow : xp.gxin + orow; \
         const unsigned eb = (s0 + 5 < 8 || !act1) ? xp.w_epoch : xp.x_epoch;
         u64 va = 0, vb = 0;
-        if (wave == 0) { FFN_HOP_ADDR(lane) (void)eb; va = df_load_granule(pa); vb = df_load_granule(pb); }
+        float xemb = 0.f;
+        if (wave == 0) {
+            FFN_HOP_ADDR(lane) (void)eb;
+            va = df_load_granule(pa);
+            if (s0 == 3 && !xp.gxin) xemb = xp.x_adapter[orow] + bf16_to_f32(xp.x_emb[orow]);      // layer 0: source 8 is the embedding itself
+            else vb = df_load_granule(pb);
+        }
         __builtin_amdgcn_sched_barrier(0);
         FFN_ISSUE(2) FFN_ISSUE(3)
         __builtin_amdgcn_sched_barrier(0);
@@ -1194,7 +1202,8 @@ __device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx,
             const int lane2 = df_tid() & 63;
             FFN_HOP_ADDR(lane2)
             if (act0 && (unsigned)(va >> 32) != xp.w_epoch) va = (u64)__float_as_uint(df_wait_granule_e(pa, xp.w_epoch, a.err, a.spin_limit, 5u));
-            if (act1 && (unsigned)(vb >> 32) != eb) vb = (u64)__float_as_uint(df_wait_granule_e(pb, eb, a.err, a.spin_limit, 5u));
+            if (s0 == 3 && !xp.gxin) vb = (u64)__float_as_uint(xemb);
+            else if (act1 && (unsigned)(vb >> 32) != eb) vb = (u64)__float_as_uint(df_wait_granule_e(pb, eb, a.err, a.spin_limit, 5u));
             if (act0) hop[s0 * 16 + r] = __uint_as_float((unsigned)va);
             if (act1) hop[(s0 + 5) * 16 + r] = __uint_as_float((unsigned)vb);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1401,8 +1410,11 @@ constexpr int DA12_LDS_BYTES = 2 * DF_D * 4 + 4 * DF_TILE_BYTES + 1024 + 512;   
 // slice's weight exp(m_s - M) / L is computed once per head, and a thread's 32 (head, dim) granules share one trip to L2 with them
 // while a slice is one tile (beyond that the members finish further apart and the early fetch would only be repeated).
 // gw (k_dec_stack): the Wo partial sums leave as {epoch, value} granules (gw[8][3072]) instead of a.wo_part, see ffn_body<XP>.
-template <bool XG, bool W8 = false, bool LONG = false>
+// EMB (k_dec_stack, layer 0): x = adapter[st->adapter_row] + tok_emb[st->token] (voxtral.c:1057-1061), built here as k_dec_attn_fused<EMBED>
+// builds it: the adapter row comes by LDS-DMA where x would, the embedding row is added on top.
+template <bool XG, bool W8 = false, bool LONG = false, bool EMB = false>
 __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned char *smem_raw, const u64 *gx, unsigned x_epoch, u64 *gw = nullptr) {
+    static_assert(!(EMB && XG), "layer 0 has no x'' in front of it");
     static_assert(!(LONG && W8), "the long-context form is bf16 only");
     float *xs = reinterpret_cast<float *>(smem_raw);                           // [3072] x, then [3072] norm weights (contiguous)
     float *nw = xs + DF_D;
@@ -1443,9 +1455,13 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
     if constexpr (XG) {
         glds16(a.norm_w + tid * 4, lds_addr(nw) + (unsigned)wave * 1024u);
     } else {
+        const float *xsrc = a.x;
+        if constexpr (EMB) xsrc = a.adapter + (size_t)a.st->adapter_row * DF_D;
 #pragma unroll
-        for (int p = 0; p < 2; p++) glds16((p ? a.norm_w : a.x) + tid * 4, lds_addr(xs) + (unsigned)(p * 12288 + wave * 1024));
+        for (int p = 0; p < 2; p++) glds16((p ? a.norm_w : xsrc) + tid * 4, lds_addr(xs) + (unsigned)(p * 12288 + wave * 1024));
     }
+    uint2 emb4 = make_uint2(0u, 0u);          // EMB: this thread's 4 embedding values (bf16), requested in front of the weights
+    if constexpr (EMB) emb4 = *reinterpret_cast<const uint2 *>(a.tok_emb + (size_t)a.st->token * DF_D + tid * 4);
     DF_MARK(11);
     __builtin_amdgcn_s_barrier();          // every wave's share of the vectors is in the CU's queue before anybody's weights (see k_dec_attn_fused)
     DF_MARK(12);
@@ -1506,6 +1522,11 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NPW - XSP)) : "memory");    // the vector DMAs are older than everything else; the later pieces may still stream
     } else {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");             // only the weight loads are younger than the activation DMAs
+        if constexpr (EMB) {     // a thread's 16 bytes of the adapter row were brought in by its own DMA lane
+            float4 v = *reinterpret_cast<const float4 *>(xs + tid * 4);
+            v.x += bf16_lo(emb4.x); v.y += bf16_hi(emb4.x); v.z += bf16_lo(emb4.y); v.w += bf16_hi(emb4.y);
+            *reinterpret_cast<float4 *>(xs + tid * 4) = v;
+        }
     }
     __syncthreads();
     DF_MARK(2);
@@ -1912,6 +1933,9 @@ struct DecStackArgs {
     float scale;
     const float *x0;           // [3072] residual stream in front of layer 0's attention output (written by its launch)
     const float *wo_part;      // [8][3072] layer 0's Wo partial sums (memory, from its launch)
+    // embed != 0: layer 0's attention block runs in here too, on x = adapter[st->adapter_row] + tok_emb[st->token] (then x0 / wo_part are unused)
+    int embed;
+    const float *adapter; const uint16_t *tok_emb; const DecState *st;
     float *x_out;              // [3072] the stack's output
     u64 *gq, *gp, *gh, *gx, *gw, *gxp;
     unsigned epoch0;           // epoch of layer 0's attention launch; layer l uses epoch0 + l
@@ -1924,22 +1948,28 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_dec_stack(const DecStackArgs
     uint4 w[2][3][6];
     for (int l = 0; l < s.n_layers; l++) {
         const DecStackLayer &L = s.layers[l];
-        if (l > 0) {
+        if (l > 0 || s.embed) {
             DecFuseArgs a{};
             a.wqkv = L.wqkv; a.wo = L.wo; a.norm_w = L.n1; a.eps = s.eps; a.inv_freq = s.inv_freq;
             a.kring = L.kring; a.vring = L.vring; a.kv_cap = s.kv_cap; a.pos = s.pos; a.window = s.window; a.scale = s.scale;
             a.gq = s.gq; a.gp = s.gp; a.epoch = s.epoch0 + l; a.split_keys = s.split_keys; a.nsplit = s.nsplit;
             a.err = s.err; a.spin_limit = s.spin_limit;
-            df_attn12_body<true, false, false>(a, reinterpret_cast<unsigned char *>(smem), s.gx, s.epoch0 + l - 1, s.gw);
+            if (l == 0) {
+                a.adapter = s.adapter; a.tok_emb = s.tok_emb; a.st = s.st;
+                df_attn12_body<false, false, false, true>(a, reinterpret_cast<unsigned char *>(smem), nullptr, 0u, s.gw);
+            } else {
+                df_attn12_body<true, false, false>(a, reinterpret_cast<unsigned char *>(smem), s.gx, s.epoch0 + l - 1, s.gw);
+            }
             __syncthreads();
         }
         FfnArgs f{};
         f.w1 = L.w1; f.w3 = L.w3; f.w2 = L.w2; f.x = s.x0; f.wo_part = s.wo_part; f.norm_w = L.n2; f.ada = L.ada; f.eps = s.eps;
         f.x_out = s.x_out; f.gh = s.gh; f.epoch = s.epoch0 + l; f.err = s.err; f.spin_limit = s.spin_limit;
-        if (l == 0) {
+        if (l == 0 && !s.embed) {
             ffn_body<false>(f, smem, s.gx, w);
         } else {
-            FfnXp xp{s.gw, s.gx, s.gxp, s.epoch0 + (unsigned)l, s.epoch0 + (unsigned)l - 1u};
+            FfnXp xp{s.gw, l ? s.gx : nullptr, s.gxp, s.epoch0 + (unsigned)l, s.epoch0 + (unsigned)l - 1u, nullptr, nullptr};
+            if (l == 0) { xp.x_adapter = s.adapter + (size_t)s.st->adapter_row * DF_D; xp.x_emb = s.tok_emb + (size_t)s.st->token * DF_D; }
             ffn_body<true>(f, smem, s.gx, w, xp);
         }
         __syncthreads();                        // every reader of the FFN block's LDS is done

@@ -1932,9 +1932,44 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     const bool shape12_f8 = fused && e->merge12 == 2 && e->use_fp8 && !e->fp8_attn_bf16 && !e->sim_on && f_ns <= 8 && spread_env0 <= 0 && (e->skip_kinds & ~(1u << PK_SWIGLU)) == 0 &&
                             tap_i < 0 && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0)) && !getenv("VOX_HIP_FUSE_ATTN_PER_HEAD") && !getenv("VOX_HIP_OLD_W2");
     bool attn_done = false;           // this layer's attention block ran at the end of the previous layer's launch (k_ffn_attn12)
+    // k_dec_stack: every block of the step's layers in ONE launch - with the embedding gather (embed = 1: attention(0) included) or behind
+    // layer 0's own attention launch (embed = 0: the first step after a prefill, whose x is in memory)
+    const bool stack_here = shape12 && !long12 && e->merge12 == 2 && e->use_stack && !e->d_fuse_tl && d.dec_layers > 1;
+    auto launch_stack = [&](int embed) -> int {
+        std::vector<DecStackLayer> tab((size_t)d.dec_layers);
+        for (int k = 0; k < d.dec_layers; k++) {
+            DecLayer &K = e->dec[k];
+            tab[k] = DecStackLayer{K.wqkv, K.wo, K.w13, K.w13 + (size_t)DH * DD, K.w2, K.n1, K.n2, K.ada, K.kring, K.vring};
+        }
+        if (e->h_stack_tab.size() != tab.size() || memcmp(e->h_stack_tab.data(), tab.data(), tab.size() * sizeof(DecStackLayer)) != 0) {
+            HC(hipMemcpyAsync(e->d_stack_tab, tab.data(), tab.size() * sizeof(DecStackLayer), hipMemcpyHostToDevice, s));
+            HC(hipStreamSynchronize(s));          // (rare: the first step, or after the rings / ada vectors moved) the source is a local
+            e->h_stack_tab = tab;
+        }
+        DecStackArgs sa{};
+        sa.layers = e->d_stack_tab; sa.n_layers = d.dec_layers; sa.eps = d.dec_eps; sa.inv_freq = e->dec_inv_freq;
+        sa.kv_cap = e->dec_ring_cap; sa.pos = kv_pos; sa.window = d.dec_window; sa.scale = scale;
+        sa.x0 = xin; sa.wo_part = e->d_wo_part; sa.x_out = xalt;
+        sa.embed = embed; sa.adapter = e->adapter; sa.tok_emb = e->tok_emb; sa.st = e->d_st;
+        sa.gq = e->d_gq; sa.gp = e->d_gp; sa.gh = e->d_gh; sa.gx = e->d_gx; sa.gw = e->d_gw; sa.gxp = e->d_gxp;
+        if (embed && ++e->fuse_epoch == 0) e->fuse_epoch = 1;          // (embed = 0: layer 0's attention launch took this epoch already)
+        sa.epoch0 = e->fuse_epoch; sa.split_keys = f_split; sa.nsplit = f_ns;
+        sa.err = e->d_fuse_err; sa.spin_limit = 500000ull;
+        e->fuse_epoch += (unsigned)d.dec_layers;
+        if (e->fuse_epoch > 0xFFFF0000u) e->fuse_epoch = 1;      // (tags are at most one step old: a restart of the counter cannot meet a stale one)
+        if (!(e->skip_kinds & (1u << PK_W2)))        // (timing experiment, kind 6: the step without this launch)
+            hipLaunchKernelGGL(k_dec_stack, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, sa);
+        prof_mark(e, PK_W2);
+        std::swap(xin, xalt);
+        return 0;
+    };
     for (int l = 0; l < d.dec_layers; l++) {
         DecLayer &L = e->dec[l];
         if (fused) {
+            if (l == 0 && stack_here && build_embed && !(e->skip_kinds & (1u << PK_QKV))) {
+                if (launch_stack(1)) return -1;
+                break;
+            }
             if (!attn_done && !(e->skip_kinds & (1u << PK_QKV))) {
                 // attention_norm -> wq/wk/wv -> RoPE -> KV append -> attention -> wo (K-split partials): one launch
                 DecFuseArgs a{};
@@ -1992,31 +2027,8 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             tap(2 * l, xin);              // (layer 0 of a stream step builds x inside the launch above and writes it to xin)
             // (fp8 mode keeps the two launches: with half the W2 bytes the 72 KB sweep and the dot products at the end are no longer
             //  hidden - measured 1.1055 against 1.0271 ms per step, gpurun_out/r4k)
-            if (l == 0 && shape12 && !long12 && e->merge12 == 2 && e->use_stack && !e->d_fuse_tl && d.dec_layers > 1) {
-                // k_dec_stack: every remaining block of the step - FFN(0), then attention + FFN of layers 1 .. L-1 - in ONE launch
-                std::vector<DecStackLayer> tab((size_t)d.dec_layers);
-                for (int k = 0; k < d.dec_layers; k++) {
-                    DecLayer &K = e->dec[k];
-                    tab[k] = DecStackLayer{K.wqkv, K.wo, K.w13, K.w13 + (size_t)DH * DD, K.w2, K.n1, K.n2, K.ada, K.kring, K.vring};
-                }
-                if (e->h_stack_tab.size() != tab.size() || memcmp(e->h_stack_tab.data(), tab.data(), tab.size() * sizeof(DecStackLayer)) != 0) {
-                    HC(hipMemcpyAsync(e->d_stack_tab, tab.data(), tab.size() * sizeof(DecStackLayer), hipMemcpyHostToDevice, s));
-                    HC(hipStreamSynchronize(s));          // (rare: the first step, or after the rings / ada vectors moved) the source is a local
-                    e->h_stack_tab = tab;
-                }
-                DecStackArgs sa{};
-                sa.layers = e->d_stack_tab; sa.n_layers = d.dec_layers; sa.eps = d.dec_eps; sa.inv_freq = e->dec_inv_freq;
-                sa.kv_cap = e->dec_ring_cap; sa.pos = kv_pos; sa.window = d.dec_window; sa.scale = scale;
-                sa.x0 = xin; sa.wo_part = e->d_wo_part; sa.x_out = xalt;
-                sa.gq = e->d_gq; sa.gp = e->d_gp; sa.gh = e->d_gh; sa.gx = e->d_gx; sa.gw = e->d_gw; sa.gxp = e->d_gxp;
-                sa.epoch0 = e->fuse_epoch; sa.split_keys = f_split; sa.nsplit = f_ns;
-                sa.err = e->d_fuse_err; sa.spin_limit = 500000ull;
-                e->fuse_epoch += (unsigned)d.dec_layers;
-                if (e->fuse_epoch > 0xFFFF0000u) e->fuse_epoch = 1;      // (tags are at most one step old: a restart of the counter cannot meet a stale one)
-                if (!(e->skip_kinds & (1u << PK_W2)))        // (timing experiment, kind 6: the step without this launch)
-                    hipLaunchKernelGGL(k_dec_stack, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, sa);
-                prof_mark(e, PK_W2);
-                std::swap(xin, xalt);
+            if (l == 0 && stack_here) {       // (layer 0's attention block ran as a launch of its own: the first step after a prefill)
+                if (launch_stack(0)) return -1;
                 break;
             }
             const bool merged_here = shape12 && e->merge12 == 2 && l + 1 < d.dec_layers;

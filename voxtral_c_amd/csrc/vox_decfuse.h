@@ -1942,7 +1942,15 @@ struct DecStackArgs {
     int split_keys, nsplit;
     unsigned *err;
     unsigned long long spin_limit;
+    unsigned long long *tl;    // k_dec_stack<true> only (tuning): per-workgroup timeline of layer tl_layer's two blocks
+    int tl_layer;
 };
+// Measured and not kept (profiles/r05_stack_parked_piece.patch, r05_stack_timeline_pre_p0_kv232.txt): the attention block parking piece 0
+// of the following FFN block's rows in LDS by LDS-DMA once its partial sweep is in, to stream during the merge and the Wo product.
+// A CU's stores leave through the same queue as its loads: the Wo partial sums (gw) then became visible only behind those 72 KB,
+// every owner's hop 1 waited for them, and the block took 20 us instead of 16.3 (step +1 .. +3 %).  The only free slot for bulk
+// requests is behind a block's LAST hand-off - where every block of this kernel already issues its weights.
+template <bool TL>
 __global__ __launch_bounds__(FFN_THREADS, 1) void k_dec_stack(const DecStackArgs s) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint4 w[2][3][6];
@@ -1954,6 +1962,7 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_dec_stack(const DecStackArgs
             a.kring = L.kring; a.vring = L.vring; a.kv_cap = s.kv_cap; a.pos = s.pos; a.window = s.window; a.scale = s.scale;
             a.gq = s.gq; a.gp = s.gp; a.epoch = s.epoch0 + l; a.split_keys = s.split_keys; a.nsplit = s.nsplit;
             a.err = s.err; a.spin_limit = s.spin_limit;
+            if constexpr (TL) a.tl = (l == s.tl_layer) ? s.tl : nullptr;
             if (l == 0) {
                 a.adapter = s.adapter; a.tok_emb = s.tok_emb; a.st = s.st;
                 df_attn12_body<false, false, false, true>(a, reinterpret_cast<unsigned char *>(smem), nullptr, 0u, s.gw);
@@ -1965,6 +1974,7 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_dec_stack(const DecStackArgs
         FfnArgs f{};
         f.w1 = L.w1; f.w3 = L.w3; f.w2 = L.w2; f.x = s.x0; f.wo_part = s.wo_part; f.norm_w = L.n2; f.ada = L.ada; f.eps = s.eps;
         f.x_out = s.x_out; f.gh = s.gh; f.epoch = s.epoch0 + l; f.err = s.err; f.spin_limit = s.spin_limit;
+        if constexpr (TL) f.tl = (l == s.tl_layer && s.tl) ? s.tl + TL_STRIDE * 1024 : nullptr;
         if (l == 0 && !s.embed) {
             ffn_body<false>(f, smem, s.gx, w);
         } else {

@@ -700,7 +700,8 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  hipFuncSetAttribute((const void *)k_w2x_attn12, hipFuncAttributeMaxDynamicSharedMemorySize, DA12_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_ffn_attn12<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_ffn_attn12<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_dec_stack, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_dec_stack<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_dec_stack<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FA12_LDS_BYTES) == hipSuccess &&
                  dalloc(e, &e->d_gx, (size_t)DF_D) == 0 && hipMemset(e->d_gx, 0, (size_t)DF_D * 8) == hipSuccess &&
                  dalloc(e, &e->d_gw, (size_t)8 * DF_D) == 0 && hipMemset(e->d_gw, 0, (size_t)8 * DF_D * 8) == hipSuccess &&
                  dalloc(e, &e->d_gxp, (size_t)DF_D) == 0 && hipMemset(e->d_gxp, 0, (size_t)DF_D * 8) == hipSuccess &&
@@ -1934,7 +1935,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     bool attn_done = false;           // this layer's attention block ran at the end of the previous layer's launch (k_ffn_attn12)
     // k_dec_stack: every block of the step's layers in ONE launch - with the embedding gather (embed = 1: attention(0) included) or behind
     // layer 0's own attention launch (embed = 0: the first step after a prefill, whose x is in memory)
-    const bool stack_here = shape12 && !long12 && e->merge12 == 2 && e->use_stack && !e->d_fuse_tl && d.dec_layers > 1;
+    const bool stack_here = shape12 && !long12 && e->merge12 == 2 && e->use_stack && d.dec_layers > 1;
     auto launch_stack = [&](int embed) -> int {
         std::vector<DecStackLayer> tab((size_t)d.dec_layers);
         for (int k = 0; k < d.dec_layers; k++) {
@@ -1957,8 +1958,10 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
         sa.err = e->d_fuse_err; sa.spin_limit = 500000ull;
         e->fuse_epoch += (unsigned)d.dec_layers;
         if (e->fuse_epoch > 0xFFFF0000u) e->fuse_epoch = 1;      // (tags are at most one step old: a restart of the counter cannot meet a stale one)
-        if (!(e->skip_kinds & (1u << PK_W2)))        // (timing experiment, kind 6: the step without this launch)
-            hipLaunchKernelGGL(k_dec_stack, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, sa);
+        sa.tl = e->d_fuse_tl; sa.tl_layer = tl_layer;
+        if (e->skip_kinds & (1u << PK_W2)) {}        // (timing experiment, kind 6: the step without this launch)
+        else if (e->d_fuse_tl) hipLaunchKernelGGL(k_dec_stack<true>, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, sa);      // VOX_HIP_FUSE_TL: the instrumented build
+        else hipLaunchKernelGGL(k_dec_stack<false>, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, sa);
         prof_mark(e, PK_W2);
         std::swap(xin, xalt);
         return 0;

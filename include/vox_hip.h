@@ -199,7 +199,7 @@ int vox_hip_encoder_state_push(vox_hip_engine_t *src, vox_hip_engine_t *dst);
 /* Round 4.  vox_hip_shard_end_push and vox_hip_encoder_state_push no longer make the owner's stream wait for the other engine
  * at once: the owner's DECODER waits (on its stream) for a shard's adapter rows right in front of the first step that reads
  * them, its ENCODER side waits for the handed-over state before it touches encoder state again - so decoding starts on the first
- * shard's rows while later shards still encode.  VOX_MULTI_NO_OVERLAP=1 restores the immediate waits (A/B).
+ * shard's rows while later shards still encode.  VOX_HIP_DISABLE=multi_overlap restores the immediate waits.
  * vox_hip_encoder_aligned: 1 if the stream's encoder state sits on a token boundary (a sharded chunk may start from it);
  * vox_hip_encoder_pos: encoder positions done so far; vox_hip_pending_fences: waits not yet placed (tests). */
 int vox_hip_encoder_aligned(const vox_hip_engine_t *e);
@@ -253,9 +253,13 @@ int vox_hip_time_decoder_step_without(vox_hip_engine_t *e, int iters, int kv_len
  * answer, kind 6 of vox_hip_time_decoder_step_without leaves out exactly these launches. */
 int vox_hip_merged_launches_per_step(const vox_hip_engine_t *e, int kv_len);
 /* Round 5: layers whose blocks run inside the ONE k_dec_stack launch of a decode step at this KV length (FFN block of layer 0, attention
- * and FFN blocks of layers 1 .. L-1; 0 = the stack kernel is not used there: beyond 1024 keys, fp8 mode, VOX_HIP_STACK=0).  With a
+ * and FFN blocks of layers 1 .. L-1; 0 = the stack kernel is not used there: beyond 1024 keys, fp8 mode, VOX_HIP_DISABLE=stack).  With a
  * non-zero answer, kind 6 of vox_hip_time_decoder_step_without leaves out exactly that launch. */
 int vox_hip_stack_layers(const vox_hip_engine_t *e, int kv_len);
+/* 1 if `name` is listed in VOX_HIP_DISABLE (comma-separated): the one switch of the fallback ladder - every name turns one production
+ * kernel family off so that the next older HIP path runs instead (never a CPU path).  The names are listed at vox_disabled() in
+ * csrc/vox_hip_engine.hip. */
+int vox_hip_switch_disabled(const char *name);
 
 /* BASELINE config 5: quantise the decoder matrices and the tied embedding to fp8 e4m3 (one f32 scale
  * per output row) for the decode GEMVs; prefill and the encoder keep bf16.  Call after the uploads.
@@ -270,7 +274,7 @@ int vox_hip_simulate_block_fp8(vox_hip_engine_t *e, int block, int lm_head);
 /* Which kernel families are live (bit set = the production variant).  The start-up self-tests compare
  * each MFMA / DPP kernel with a plain HIP cross-check; a mismatch makes vox_hip_engine_create (and so
  * vox_load) FAIL unless VOX_HIP_ALLOW_FALLBACK=1, in which case the bit is cleared.  The A/B switches
- * VOX_HIP_NO_* clear bits too.  VOX_PATH_GEMV3 is reported only for the 4B decoder shapes the kernel
+ * names in VOX_HIP_DISABLE clear bits too.  VOX_PATH_GEMV3 is reported only for the 4B decoder shapes the kernel
  * is specialised for (other geometries run the generic k_gemv). */
 enum vox_hip_path {
     VOX_PATH_GEMM_MFMA_BF16X3 = 1u << 0,   /* large-M GEMM: 3-term bf16 split on v_mfma_f32_32x32x16_bf16 */

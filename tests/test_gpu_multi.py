@@ -97,7 +97,7 @@ def test_in_library_later_chunks_are_sharded_too_and_decoding_overlaps(preset, s
     through all engines (three feeds of a third of the clip each, processing interval 2 s: three sharded chunks, the second and
     third continuing from the stream engine's K/V rings and conv history), and the stream engine's decoder no longer waits for
     the whole wavefront: it waits for a shard's adapter rows right in front of the first step that reads them.  Ids = the single
-    engine's; VOX_MULTI_NO_OVERLAP=1 (the round-3 waits) gives the same ids."""
+    engine's; VOX_HIP_DISABLE=multi_overlap (the round-3 waits) gives the same ids."""
     import ctypes as C
     import voxtral_c_amd as v
     v.hip.vox_hip_pending_fences.argtypes = [C.c_void_p]
@@ -111,7 +111,7 @@ def test_in_library_later_chunks_are_sharded_too_and_decoding_overlaps(preset, s
     for no_overlap in (False, True):
         os.environ["VOX_DEVICES"] = devices
         if no_overlap:
-            os.environ["VOX_MULTI_NO_OVERLAP"] = "1"
+            os.environ["VOX_HIP_DISABLE"] = "multi_overlap"
         try:
             with v.Model(model_dir(preset), **win) as mm:
                 got = mm.transcribe(audio, feed_sizes=feeds)["tokens"]
@@ -119,7 +119,7 @@ def test_in_library_later_chunks_are_sharded_too_and_decoding_overlaps(preset, s
                 assert v.hip.vox_hip_pending_fences(mm.engine) == 0
         finally:
             del os.environ["VOX_DEVICES"]
-            os.environ.pop("VOX_MULTI_NO_OVERLAP", None)
+            os.environ.pop("VOX_HIP_DISABLE", None)
         assert len(want) > 300 and np.array_equal(got, want), (no_overlap, len(got), len(want))
         assert n_sharded == 3, n_sharded
 

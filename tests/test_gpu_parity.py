@@ -604,7 +604,7 @@ def test_fast_decode_kernels_at_long_context_and_ring_wrap(vox, n_prompt, window
     cases pin to the reference."""
     kw = dict(dec_window=window) if window else {}
     f0, t0, l0 = _decode_after_long_prefill(vox, n_prompt, n_steps, 5, **kw)
-    f1, t1, l1 = _decode_after_long_prefill(vox, n_prompt, n_steps, 5, env={"VOX_HIP_NO_GEMV2": "1"}, **kw)
+    f1, t1, l1 = _decode_after_long_prefill(vox, n_prompt, n_steps, 5, env={"VOX_HIP_DISABLE": "fast"}, **kw)
     same = int(np.argmax(t0 != t1)) if (t0 != t1).any() else n_steps      # steps before the paths could diverge
     err = float(np.abs(l0[:same + 1 if same < n_steps else same] - l1[:same + 1 if same < n_steps else same]).max())
     diag(f"fast_vs_generic_{n_prompt}_{window}", err=err, first=[int(f0), int(f1)], same_steps=same)
@@ -615,7 +615,7 @@ def test_fast_decode_kernels_at_long_context_and_ring_wrap(vox, n_prompt, window
 
 def test_fused_decode_step_matches_the_launch_per_gemv_chain(vox):
     """k_dec_attn_fused + k_gemv_w13x (3 launches per layer, in-kernel hand-offs inside a KV-head group) against
-    the 5-launch chain it replaces (VOX_HIP_NO_FUSED=1), full geometry: same ids, logits equal up to the changed
+    the 5-launch chain it replaces (VOX_HIP_DISABLE=fused), full geometry: same ids, logits equal up to the changed
     summation order of the K-split output projection and of the partial merge.  The golden tests pin the fused
     path to the reference; this pins it to the chain on an input with no golden, with the batched launch pattern
     (no per-step host sync) and with per-step recording."""
@@ -625,13 +625,13 @@ def test_fused_decode_step_matches_the_launch_per_gemv_chain(vox):
         a = m.transcribe(audio, record_logits=256)
         b = m.transcribe(audio)
         assert "dec_fused" in m.active_paths()[1], "a hand-off timed out: the engine fell back to the chain"
-    os.environ["VOX_HIP_NO_FUSED"] = "1"
+    os.environ["VOX_HIP_DISABLE"] = "fused"
     try:
         with vox.Model(model_dir("full")) as m2:
             assert "dec_fused" not in m2.active_paths()[1]
             c = m2.transcribe(audio, record_logits=256)
     finally:
-        del os.environ["VOX_HIP_NO_FUSED"]
+        del os.environ["VOX_HIP_DISABLE"]
     n = min(len(a["tokens"]), len(c["tokens"]))
     same = int(np.argmax(a["tokens"][:n] != c["tokens"][:n])) if (a["tokens"][:n] != c["tokens"][:n]).any() else n
     err = float(np.abs(a["logits"][:same + 1] - c["logits"][:same + 1]).max())
@@ -643,18 +643,18 @@ def test_fused_decode_step_matches_the_launch_per_gemv_chain(vox):
 
 def test_fp8_fused_decode_step_matches_the_fp8_chain(vox):
     """Round 4: in fp8 mode k_dec_attn_fused<W8> streams the row-scaled e4m3 copies of wq;wk;wv and wo (two Wo rows per load,
-    16 weights per lane) - the same bytes the launch-per-GEMV chain reads in fp8 mode (VOX_HIP_NO_FUSED=1).  70 s of audio:
+    16 weights per lane) - the same bytes the launch-per-GEMV chain reads in fp8 mode (VOX_HIP_DISABLE=fused).  70 s of audio:
     the first ~470 steps run with attention members that carry no Wo rows (<= 8 key slices), the rest with every member
     streaming 12 Wo rows under its first K/V tile.  The chain's ids are teacher-forced so that every step sees the same inputs;
     logits must agree up to summation order, argmax may differ at numerical near-ties only."""
     audio = synth_speech(70.0, 321)
-    os.environ["VOX_HIP_NO_FUSED"] = "1"
+    os.environ["VOX_HIP_DISABLE"] = "fused"
     try:
         with vox.Model(model_dir("full"), weights="fp8") as m2:
             assert "dec_fused" not in m2.active_paths()[1]
             c = m2.transcribe(audio, record_logits=900)
     finally:
-        del os.environ["VOX_HIP_NO_FUSED"]
+        del os.environ["VOX_HIP_DISABLE"]
     with vox.Model(model_dir("full"), weights="fp8") as m:
         assert "dec_fused" in m.active_paths()[1]
         a = m.transcribe(audio, record_logits=900, force_tokens=c["tokens"])
@@ -675,27 +675,27 @@ def test_merged_ffn_attention_launch_matches_the_two_launch_path(vox):
     cross all four member shapes in the middle of a decode: one-tile members up to 512 keys, two-tile members (8 key slices of 128
     keys) up to 1024, then the LONG form - 17 .. 32 one-tile slices up to 2048 keys (members spread over the XCDs, every workgroup
     carries Wo rows, many-slices merge with the value granules fetched early), two-tile slices beyond (value granules fetched after
-    the (max, sum) pairs).  Reference = the same engine with VOX_HIP_MERGE12=0 (two launches per layer throughout), its ids
+    the (max, sum) pairs).  Reference = the same engine with VOX_HIP_DISABLE=merge12 (two launches per layer throughout), its ids
     teacher-forced: logits equal up to the summation order of the RMSNorm and of the Wo rows' K slices, argmax different at
-    numerical near-ties only.  VOX_HIP_MERGE12_LONG=0 is the round-4 behaviour (two launches per layer beyond 1024 keys)."""
+    numerical near-ties only.  VOX_HIP_DISABLE=merge12_long is the round-4 behaviour (two launches per layer beyond 1024 keys)."""
     audio = synth_speech(180.0, 99)
-    os.environ["VOX_HIP_MERGE12"] = "0"
+    os.environ["VOX_HIP_DISABLE"] = "merge12"
     try:
         with vox.Model(model_dir("full")) as m2:
             assert "ffn_attn12" not in m2.active_paths()[1]
             c = m2.transcribe(audio, record_logits=2400)
     finally:
-        del os.environ["VOX_HIP_MERGE12"]
+        del os.environ["VOX_HIP_DISABLE"]
     import ctypes as C
     vox.hip.vox_hip_merged_launches_per_step.restype = C.c_int
     vox.hip.vox_hip_merged_launches_per_step.argtypes = [C.c_void_p, C.c_int]
-    os.environ["VOX_HIP_MERGE12_LONG"] = "0"
+    os.environ["VOX_HIP_DISABLE"] = "merge12_long"
     try:
         with vox.Model(model_dir("full")) as m4:
             per_step = [vox.hip.vox_hip_merged_launches_per_step(m4.engine, kv) for kv in (1, 1024, 1025, 8000)]
             assert per_step == [25, 25, 0, 0], per_step
     finally:
-        del os.environ["VOX_HIP_MERGE12_LONG"]
+        del os.environ["VOX_HIP_DISABLE"]
     with vox.Model(model_dir("full")) as m:
         assert "ffn_attn12" in m.active_paths()[1]
         per_step = [vox.hip.vox_hip_merged_launches_per_step(m.engine, kv) for kv in (1, 232, 512, 513, 1024, 1025, 2048, 2049, 8000, 8192)]
@@ -705,14 +705,14 @@ def test_merged_ffn_attention_launch_matches_the_two_launch_path(vox):
         assert "dec_fused" in m.active_paths()[1], "a hand-off timed out: the engine fell back to the chain"
         free = m.transcribe(audio)
     # round 5: the default engine runs FFN(0) and layers 1 .. 25 as ONE launch (k_dec_stack: x' handed over in two granule hops);
-    # VOX_HIP_STACK=0 = one k_ffn_attn12 launch per layer.  Same arithmetic: the logits must agree to rounding.
-    os.environ["VOX_HIP_STACK"] = "0"
+    # VOX_HIP_DISABLE=stack = one k_ffn_attn12 launch per layer.  Same arithmetic: the logits must agree to rounding.
+    os.environ["VOX_HIP_DISABLE"] = "stack"
     try:
         with vox.Model(model_dir("full")) as m5:
             assert "dec_stack" not in m5.active_paths()[1] and "ffn_attn12" in m5.active_paths()[1]
             b5 = m5.transcribe(audio, record_logits=2400, force_tokens=c["tokens"])
     finally:
-        del os.environ["VOX_HIP_STACK"]
+        del os.environ["VOX_HIP_DISABLE"]
     k5 = min(len(a["logits"]), len(b5["logits"]))
     err5 = max(float(np.abs(np.asarray(a["logits"][i:i + 256]) - np.asarray(b5["logits"][i:i + 256])).max()) for i in range(0, k5, 256))
     diag("stack_vs_launch_per_layer", logit_rows=k5, max_logit_diff=err5, ids_equal=bool(np.array_equal(np.asarray(a["tokens"]), np.asarray(b5["tokens"]))))
@@ -738,12 +738,12 @@ def test_fused_decode_step_matches_the_chain_at_long_context(vox):
     batch of up to 32 granules per thread).  The chain's ids are teacher-forced into the fused run so that every step sees the
     same inputs; the two argmax sequences may then differ only at numerical near-ties (different summation order)."""
     audio = synth_speech(200.0, 77)
-    os.environ["VOX_HIP_NO_FUSED"] = "1"
+    os.environ["VOX_HIP_DISABLE"] = "fused"
     try:
         with vox.Model(model_dir("full")) as m2:
             c = m2.transcribe(audio, record_logits=64)
     finally:
-        del os.environ["VOX_HIP_NO_FUSED"]
+        del os.environ["VOX_HIP_DISABLE"]
     with vox.Model(model_dir("full")) as m:
         a = m.transcribe(audio, record_logits=64, force_tokens=c["tokens"])
         assert "dec_fused" in m.active_paths()[1], "a hand-off timed out: the engine fell back to the chain"
@@ -783,30 +783,30 @@ def test_production_kernels_are_the_ones_running(vox, small):
     mask, names = small.active_paths()
     diag("active_paths", mask=int(mask), names=names)
     assert mask == vox.PATH_ALL_BF16, names
-    os.environ["VOX_HIP_NO_BF16X3"] = "1"
+    os.environ["VOX_HIP_DISABLE"] = "bf16x3"
     try:
         with vox.Model(model_dir("tiny"), enc_window=48, dec_window=64) as m:
             mk, _ = m.active_paths()
     finally:
-        del os.environ["VOX_HIP_NO_BF16X3"]
+        del os.environ["VOX_HIP_DISABLE"]
     assert not (mk & vox.PATHS["gemm_mfma_bf16x3"]) and (mk & vox.PATHS["gemm_mfma_f32"])
     assert not (mk & vox.PATHS["gemv3"])          # tiny geometry: the generic GEMV, reported as such
 
 
-@pytest.mark.parametrize("switch", ["VOX_HIP_NO_STAGED_UPLOAD", "VOX_HIP_NO_PLANES", "VOX_HIP_GP_NO_EPI", "VOX_HIP_NO_ATTN_SMALL"])
+@pytest.mark.parametrize("switch", ["staged_upload", "planes", "epi", "attn_small"])
 def test_ab_switches_give_the_same_ids(vox, small, switch):
-    """Each A/B switch selects the older HIP path of one component (plain hipMemcpy ingest, f32-activation GEMM, separate RoPE /
+    """Each name in VOX_HIP_DISABLE selects the older HIP path of one component (plain hipMemcpy ingest, f32-activation GEMM, separate RoPE /
     SiLU launches, MFMA attention for small chunks); ids must not depend on it, logits only up to summation order."""
     audio = synth_speech(22.0, 99)
     feeds = [8000] * (len(audio) // 8000 + 1)          # 0.5 s feeds after a large first chunk: both encoder paths run
     feeds[0] = 16000 * 12
     a = small.transcribe(audio, feed_sizes=feeds, interval=0.5, record_logits=32)
-    os.environ[switch] = "1"
+    os.environ["VOX_HIP_DISABLE"] = switch
     try:
         with vox.Model(model_dir("small")) as m2:
             b = m2.transcribe(audio, feed_sizes=feeds, interval=0.5, record_logits=32)
     finally:
-        del os.environ[switch]
+        del os.environ["VOX_HIP_DISABLE"]
     assert np.array_equal(a["tokens"], b["tokens"]), switch
     assert float(np.abs(a["logits"] - b["logits"]).max()) < 2e-4
 
@@ -992,18 +992,18 @@ def test_rowsgemm_matches_the_scalar_reference_kernel(tiny, M, K, N):
 def test_few_rows_paths_agree_with_the_large_m_paths(vox):
     """The same encoder chunks (1 .. 128 rows, after a big first chunk and on a cold window) and the same decoder prefills
     (1 .. 128 rows, then three greedy steps) on two engines of one process: one with the k_rowsgemm path switched off
-    (VOX_HIP_NO_ROWSGEMM: <= 32 rows on k_skinny, more on the 128 x 128 GEMM tiles), one with it on for every size
-    (VOX_HIP_RG_SMALL).  Same arithmetic up to summation order: 2e-5 relative."""
-    os.environ["VOX_HIP_NO_ROWSGEMM"] = "1"
+    (VOX_HIP_DISABLE=rowsgemm: <= 32 rows on k_skinny, more on the 128 x 128 GEMM tiles), one with it on for every size
+    (VOX_HIP_DISABLE=skinny).  Same arithmetic up to summation order: 2e-5 relative."""
+    os.environ["VOX_HIP_DISABLE"] = "rowsgemm"
     try:
         ma = vox.Model(model_dir("small"))
     finally:
-        del os.environ["VOX_HIP_NO_ROWSGEMM"]
-    os.environ["VOX_HIP_RG_SMALL"] = "1"
+        del os.environ["VOX_HIP_DISABLE"]
+    os.environ["VOX_HIP_DISABLE"] = "skinny"
     try:
         mb = vox.Model(model_dir("small"))
     finally:
-        del os.environ["VOX_HIP_RG_SMALL"]
+        del os.environ["VOX_HIP_DISABLE"]
     d = ma.dims
     worst = 0.0
     try:

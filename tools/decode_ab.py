@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Decode-step time for a list of environment variants, alternating, in ONE process on ONE box (the engine reads its
-switches at creation, so every variant gets a fresh Model).  Round 4: the L2-prefetch knobs VOX_HIP_PF / PF13 / PF2.
-usage: pf_sweep.py [--reps R] [--iters N] [--kv a,b,..] [--profile] name:ENV=v,ENV2=w ...   ('base:' = no switches)"""
+switches at creation, so every variant gets a fresh Model), e.g. "stack:" "per_layer:VOX_HIP_DISABLE=stack".
+usage: decode_ab.py [--reps R] [--iters N] [--kv a,b,..] [--profile] name:ENV=v,ENV2=w ...   ('base:' = no switches)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -3,7 +3,7 @@
 each quantisation variant is from that: free-running first divergence and teacher-forced agreement (the bf16 ids forced, so every
 step sees the same inputs) against the bf16 run, next to the margin-conditioned figure of tests/test_gpu_parity.py.
 Variants: the shipped fp8 mode (one f32 scale per output row, real e4m3 streaming kernels), the same with the LM head kept on
-the bf16 embedding (VOX_HIP_FP8_LMHEAD_BF16), and block-scaled variants simulated exactly on the bf16 kernels with power-of-two
+the bf16 embedding (VOX_HIP_DISABLE=fp8_lmhead), and block-scaled variants simulated exactly on the bf16 kernels with power-of-two
 scales (vox_hip_simulate_block_fp8: per row, per 128, per 32 weights; LM head quantised or not).
 usage: fp8_agreement.py out.json"""
 import ctypes as C, json, os, sys
@@ -49,8 +49,8 @@ with v.Model(d) as m:
     assert np.array_equal(np.asarray(m.transcribe(audio)["tokens"]), ta)
 
 for name, env in (("fp8 mode as shipped: e4m3 + f32 scale per row, all decode GEMVs + LM head", {}),
-                  ("fp8 mode, LM head on the bf16 embedding", {"VOX_HIP_FP8_LMHEAD_BF16": "1"}),
-                  ("fp8 mode, qkv / wo on the bf16 matrices (round 3)", {"VOX_HIP_FP8_ATTN_BF16": "1"})):
+                  ("fp8 mode, LM head on the bf16 embedding", {"VOX_HIP_DISABLE": "fp8_lmhead"}),
+                  ("fp8 mode, qkv / wo on the bf16 matrices (round 3)", {"VOX_HIP_DISABLE": "fp8_attn"})):
     os.environ.update(env)
     with v.Model(d, weights="fp8") as m8:
         rows[name] = score(m8.transcribe(audio), m8.transcribe(audio, record_logits=512, force_tokens=ta), m8.time_decoder_step(50, 232))

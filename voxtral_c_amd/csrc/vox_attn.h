@@ -42,7 +42,7 @@ struct AttnArgs {
     int window;
     const DecState *st;             // decoder step: qpos0 = st->pos (when non-null)
     // split-K (decoder)
-    int xcd_map;                    // k_attn_enc_mfma: remap (tile, head) so that a head's query tiles share an XCD (see there)
+    int xcd_map;                    // k_attn_enc_bf16: remap (tile, head) so that a head's query tiles share an XCD (see there)
     int split_keys;                 // keys per blockIdx.y
     float *part_o, *part_ml;        // [n_q][n_heads][nsplit][HD], [..][2]
     int force_partials;             // write partials even when nsplit == 1 (merged by the Wo GEMV prologue)
@@ -170,214 +170,19 @@ __global__ __launch_bounds__(128) void k_attn_rows(const AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// k_attn_enc_mfma — encoder attention (MHA, head_dim 64) on the f32 matrix pipe.
+// k_attn_enc_bf16 (round 4) - encoder attention (MHA, head_dim 64) on the bf16 matrix pipe.
 //
-// v_mfma_f32_32x32x2_f32 keeps the oracle's f32 x f32 products exact.  A wave owns 32
-// consecutive queries of one head; a block = 4 waves = 128 queries, sharing 32-key K/V tiles
-// staged in LDS.  Both products are computed TRANSPOSED so that a lane always owns one query
-// (col = lane&31 of the MFMA result) and the online softmax needs no cross-lane traffic
-// except one exchange between the two 32-lane halves:
+// A wave owns 32 consecutive queries of one head; a block = 4 waves = 128 queries, sharing 32-key K/V tiles staged in LDS.  Both
+// products are computed TRANSPOSED so that a lane always owns one query (col = lane & 31 of the MFMA result) and the online softmax
+// needs no cross-lane traffic except one exchange between the two 32-lane halves:
 //     S^T[key][query] = K[key][:] . Q[query][:]      A = K tile (LDS), B = Q (registers)
 //     O^T[dim][query] += V^T[dim][key] . P^T[key][query]
-// P^T comes out of the first product in the C layout (lane = query, register r <-> key
-// (r&3) + 8*(r>>2) + 4*(lane>>5)), which is exactly what the second product wants as its B
-// operand one register per MFMA step; V is stored transposed in LDS so that the matching A
-// operand (4 consecutive keys of one dim) is a single ds_read_b128.
-// LDS rows are padded (K: 68 floats, V^T: 36 floats) => the 16 lanes of a ds_read_b128
-// service group hit 16 distinct 16-byte slots.
-// Per 32x32 (query, key) tile and wave: 32 + 32 MFMAs = the f32 MFMA peak (256 FLOP/clk/CU)
-// if nothing else stalls; softmax is ~16 expf per lane and tile next to 4096 MFMA cycles.
-// grid = (ceil(n_q/128), heads, key splits); partials as in k_attn_rows.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_attn_enc_mfma(const AttnArgs a) {
-    constexpr int HD = 64, TK = 32, KLD = HD + 4, VLD = TK + 4;
-    __shared__ __attribute__((aligned(16))) float Ks[TK * KLD];
-    __shared__ __attribute__((aligned(16))) float Vt[HD * VLD];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lg = lane >> 5;
-    // (head, query tile) from the launch-order index so that all query tiles of a head run on ONE XCD (workgroups go to the XCDs
-    // round robin in launch order, x fastest): neighbouring tiles of a head read almost the same 750-key window of its K / V, and
-    // with blockIdx = (tile, head) a head's 13 tiles were spread over all eight L2s, each of which fetched the head's K / V for itself.
-    int h = blockIdx.y, qtile = blockIdx.x;
-    if (a.xcd_map && (gridDim.y & 7) == 0) {
-        const int lid = blockIdx.x + gridDim.x * blockIdx.y, k = lid >> 3, hpx = gridDim.y >> 3;
-        h = (lid & 7) + 8 * (k % hpx);
-        qtile = k / hpx;
-    }
-    const int q_first = qtile * 128;
-    const int qi = q_first + wave * 32 + li;            // this lane's query
-    const bool qvalid = qi < a.n_q;
-    const int P = a.qpos0 + qi;
-    const int last_key = a.last_key;
-
-    // block-wide key range (and its split over blockIdx.z)
-    const int q_last = min(q_first + 127, a.n_q - 1);
-    int blo = a.qpos0 + q_first - a.window + 1; if (blo < 0) blo = 0;
-    int bhi = a.qpos0 + q_last; if (bhi > last_key) bhi = last_key;
-    const int nsplit = gridDim.z;
-    if (nsplit > 1) {
-        const int tiles = (bhi - blo + TK) / TK;
-        const int per = (tiles + nsplit - 1) / nsplit;
-        const int lo2 = blo + (int)blockIdx.z * per * TK;
-        const int hi2 = lo2 + per * TK - 1;
-        blo = lo2;
-        if (hi2 < bhi) bhi = hi2;
-    }
-    // this lane's own key range, and the wave's
-    int lo_i = P - a.window + 1; if (lo_i < blo) lo_i = blo;
-    int hi_i = P < bhi ? P : bhi;
-    if (!qvalid) { lo_i = 1; hi_i = 0; }
-    const int wq0 = a.qpos0 + q_first + wave * 32;
-    const int w_lo = max(wq0 - a.window + 1, blo), w_hi = min(wq0 + 31, bhi);
-
-    // Q fragment: this lane's query, dims [lg*32, lg*32+32)
-    float qf[32];
-    {
-        const float *qp = a.q + (size_t)(qvalid ? qi : 0) * a.ldq + h * HD + lg * 32;
-#pragma unroll
-        for (int d = 0; d < 32; d += 4) {
-            float4 t = *reinterpret_cast<const float4 *>(qp + d);
-            if (!qvalid) t = make_float4(0.f, 0.f, 0.f, 0.f);
-            qf[d] = t.x; qf[d + 1] = t.y; qf[d + 2] = t.z; qf[d + 3] = t.w;
-        }
-    }
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; r++) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m = -1e30f, l = 0.f;
-
-    // staging: 32 rows x 16 float4 for K and for V -> 2 + 2 per thread
-    float4 rk[2], rv[2];
-    auto load_tile = [&](int t0) {
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int idx = tid + i * 256, r = idx >> 4, c = (idx & 15) * 4;
-            const int pos = t0 + r;
-            float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
-            if (pos <= bhi) {
-                if (pos >= a.posB0) {
-                    const size_t off = (size_t)(pos - a.posB0) * a.ldB + h * HD + c;
-                    kk = *reinterpret_cast<const float4 *>(a.kB + off);
-                    vv = *reinterpret_cast<const float4 *>(a.vB + off);
-                } else {
-                    const size_t off = (size_t)(pos % a.capA) * a.ldA + h * HD + c;
-                    kk = *reinterpret_cast<const float4 *>(a.kA + off);
-                    vv = *reinterpret_cast<const float4 *>(a.vA + off);
-                }
-            }
-            rk[i] = kk; rv[i] = vv;
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int idx = tid + i * 256, r = idx >> 4, c = (idx & 15) * 4;
-            *reinterpret_cast<float4 *>(Ks + r * KLD + c) = rk[i];
-            Vt[(c + 0) * VLD + r] = rv[i].x; Vt[(c + 1) * VLD + r] = rv[i].y;
-            Vt[(c + 2) * VLD + r] = rv[i].z; Vt[(c + 3) * VLD + r] = rv[i].w;
-        }
-    };
-
-    if (blo <= bhi) {
-        load_tile(blo);
-        store_tile();
-    }
-    __syncthreads();
-    for (int t0 = blo; t0 <= bhi; t0 += TK) {
-        const bool more = t0 + TK <= bhi;
-        if (more) load_tile(t0 + TK);
-        if (t0 + TK - 1 >= w_lo && t0 <= w_hi) {             // wave-uniform
-            // ---- S^T = K . Q^T ------------------------------------------------------------
-            f32x16 sc;
-#pragma unroll
-            for (int r = 0; r < 16; r++) sc[r] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float4 kf = *reinterpret_cast<const float4 *>(Ks + li * KLD + lg * 32 + 4 * j);
-                sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[4 * j + 0], sc, 0, 0, 0);
-                sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[4 * j + 1], sc, 0, 0, 0);
-                sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[4 * j + 2], sc, 0, 0, 0);
-                sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[4 * j + 3], sc, 0, 0, 0);
-            }
-            // ---- online softmax for this lane's query ---------------------------------------
-            float mt = -1e30f;
-            bool ok[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int kp = t0 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-                ok[r] = (kp >= lo_i) && (kp <= hi_i);
-                sc[r] = sc[r] * a.scale;
-                if (ok[r]) mt = fmaxf(mt, sc[r]);
-            }
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            const float mn = fmaxf(m, mt);
-            const float corr = expf(m - mn);
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float p = ok[r] ? expf(sc[r] - mn) : 0.f;
-                sc[r] = p;
-                ps += p;
-            }
-            l = l * corr + ps;
-            m = mn;
-#pragma unroll
-            for (int r = 0; r < 16; r++) { o0[r] *= corr; o1[r] *= corr; }
-            // ---- O^T += V^T . P^T -----------------------------------------------------------
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) {
-                const float4 v0 = *reinterpret_cast<const float4 *>(Vt + li * VLD + 8 * q4 + 4 * lg);
-                const float4 v1 = *reinterpret_cast<const float4 *>(Vt + (32 + li) * VLD + 8 * q4 + 4 * lg);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0.x, sc[4 * q4 + 0], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1.x, sc[4 * q4 + 0], o1, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0.y, sc[4 * q4 + 1], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1.y, sc[4 * q4 + 1], o1, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0.z, sc[4 * q4 + 2], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1.z, sc[4 * q4 + 2], o1, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0.w, sc[4 * q4 + 3], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1.w, sc[4 * q4 + 3], o1, 0, 0, 0);
-            }
-        }
-        __syncthreads();
-        if (more) {
-            store_tile();
-            __syncthreads();
-        }
-    }
-
-    // ---- finish: the two lane halves hold disjoint keys (same m) and disjoint dims ---------
-    l += __shfl_xor(l, 32, 64);
-    if (!qvalid) return;
-    if (nsplit > 1) {
-        const size_t pidx = ((size_t)qi * a.n_heads + h) * nsplit + blockIdx.z;
-        float *po = a.part_o + pidx * HD;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; q4++) {
-            const int d = 8 * q4 + 4 * lg;
-            *reinterpret_cast<float4 *>(po + d) = make_float4(o0[4 * q4], o0[4 * q4 + 1], o0[4 * q4 + 2], o0[4 * q4 + 3]);
-            *reinterpret_cast<float4 *>(po + 32 + d) = make_float4(o1[4 * q4], o1[4 * q4 + 1], o1[4 * q4 + 2], o1[4 * q4 + 3]);
-        }
-        if (lg == 0) { a.part_ml[pidx * 2] = m; a.part_ml[pidx * 2 + 1] = l; }
-    } else {
-        float *op = a.out + (size_t)qi * a.ldo + h * HD;
-        const float inv = l > 0.f ? 1.0f / l : 0.f;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; q4++) {
-            const int d = 8 * q4 + 4 * lg;
-            *reinterpret_cast<float4 *>(op + d) =
-                make_float4(o0[4 * q4] * inv, o0[4 * q4 + 1] * inv, o0[4 * q4 + 2] * inv, o0[4 * q4 + 3] * inv);
-            *reinterpret_cast<float4 *>(op + 32 + d) =
-                make_float4(o1[4 * q4] * inv, o1[4 * q4 + 1] * inv, o1[4 * q4 + 2] * inv, o1[4 * q4 + 3] * inv);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// k_attn_enc_bf16 (round 4) - the same attention on the bf16 matrix pipe.
-// k_attn_enc_mfma above feeds f32 operands to v_mfma_f32_32x32x2_f32: exact, but that instruction runs at the f32 VECTOR rate
-// (1/16 of the bf16 MFMA rate): 64 of them per 32 x 32 (query, key) tile and wave = 4096 cycles, 34.8 % of that pipe's peak in
-// the 30 s clip's big pass (profiles/r03_pmc_encoder_mfma.json) and the largest single item of the encoder pass (5.8 of 21.7 ms).
+// P^T comes out of the first product in the C layout, which is what the second product wants as its B operand; V is stored
+// transposed in LDS so that the matching A operand is one LDS read.  grid = (ceil(n_q / 128), heads, key splits); partials as in
+// k_attn_rows.  (Rounds 1 - 3 ran this formulation on v_mfma_f32_32x32x2_f32 - exact f32 x f32 products, but that instruction runs
+// at the f32 VECTOR rate, 1/16 of the bf16 MFMA rate: 64 of them per 32 x 32 (query, key) tile and wave = 4096 cycles, 34.8 % of
+// that pipe's peak in the 30 s clip's big pass and the largest single item of the encoder pass, 5.8 of 21.7 ms.  That kernel,
+// k_attn_enc_mfma, was removed in round 5; a failed start-up self-test of this one falls back to k_attn_rows.)
 // Here every f32 operand is split EXACTLY into three bf16 terms (hi = trunc16(x), mid = trunc16(x - hi), lo = x - hi - mid:
 // 24 = 3 x 8 significand bits, vox_gemm.h) and a product a . b is the six bf16 MFMAs hh + hm + mh + hl + lh + mm; the dropped
 // terms (ml, lm, ll) are below 2^-24 of the product.  Per tile and wave: 4 k-steps x 6 for S^T = K . Q^T and 2 k-steps x 2 halves
@@ -424,7 +229,7 @@ __global__ __launch_bounds__(256) void k_attn_enc_bf16(const AttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lg = lane >> 5;
     int h = blockIdx.y, qtile = blockIdx.x;
-    if (a.xcd_map && (gridDim.y & 7) == 0) {           // all query tiles of a head on one XCD (see k_attn_enc_mfma)
+    if (a.xcd_map && (gridDim.y & 7) == 0) {           // all query tiles of a head on one XCD (a head's K/V rows then stay in one L2)
         const int lid = blockIdx.x + gridDim.x * blockIdx.y, k = lid >> 3, hpx = gridDim.y >> 3;
         h = (lid & 7) + 8 * (k % hpx);
         qtile = k / hpx;
@@ -473,7 +278,7 @@ __global__ __launch_bounds__(256) void k_attn_enc_bf16(const AttnArgs a) {
     for (int r = 0; r < 16; r++) { o0[r] = 0.f; o1[r] = 0.f; }
     float m = -1e30f, l = 0.f;
 
-    // staging: 32 rows x 16 float4 for K and for V -> 2 + 2 per thread (as k_attn_enc_mfma)
+    // staging: 32 rows x 16 float4 for K and for V -> 2 + 2 per thread 
     float4 rk[2], rv[2];
     auto load_tile = [&](int t0) {
 #pragma unroll
@@ -538,7 +343,7 @@ __global__ __launch_bounds__(256) void k_attn_enc_bf16(const AttnArgs a) {
                 for (int p = 0; p < 3; p++) kf[p] = *reinterpret_cast<const bf16x8_t *>(Kp + p * KPL + li * KROW + (16 * t + 8 * lg) * 2);
                 sc = ab_mfma6(kf, qp[t], sc);
             }
-            // ---- online softmax for this lane's query (as k_attn_enc_mfma) ---------------------
+            // ---- online softmax for this lane's query  ---------------------
             float mt = -1e30f;
             bool ok[16];
 #pragma unroll
@@ -762,7 +567,7 @@ __global__ __launch_bounds__(256) void k_attn_dec(const AttnArgs a, const int ns
 }
 
 // Encoder attention for streaming-size chunks (n_q <= 32 queries, head_dim 64, no GQA): grid = (heads, 64-key slices of the
-// window), 256 threads; partials (o, m, l) in the layout k_attn_combine<64> merges.  k_attn_enc_mfma tiles 128 queries per
+// window), 256 threads; partials (o, m, l) in the layout k_attn_combine<64> merges.  k_attn_enc_bf16 tiles 128 queries per
 // workgroup and spent 17.5 us per layer on a 25-row chunk, most of it on padding; this is plain f32 FMA (vox_causal_attention,
 // voxtral_kernels.c:412-482, up to summation order): lane = key for the scores (K row in registers, q broadcast from LDS),
 // lane = dim for P.V.
@@ -873,12 +678,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_small(const AttnArgs a, int ke
 // 16 output values are requested before anything is computed on them; the arithmetic and its order are unchanged.
 template <int HD>
 __global__ __launch_bounds__(HD) void k_attn_combine(float *out, int ldo, const float *part_o,
-                                                     const float *part_ml, int n_heads, int nsplit, int n_q = 1 << 30, const L2Pf pf = L2Pf{}) {
-    __shared__ __attribute__((aligned(16))) unsigned char pf_scratch[(HD / 64) * 1024];
-    if ((int)blockIdx.y >= n_q) {        // appended L2-prefetch workgroups (vox_common.h, L2Pf); gridDim.x is a multiple of 8 when they exist
-        l2pf_run(pf, ((int)blockIdx.y - n_q) * (int)gridDim.x + (int)blockIdx.x, (int)blockIdx.x, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_addr(pf_scratch) + (threadIdx.x >> 6) * 1024u)));
-        return;
-    }
+                                                     const float *part_ml, int n_heads, int nsplit) {
     const int head = blockIdx.x, qi = blockIdx.y, d = threadIdx.x;
     const size_t base = ((size_t)qi * n_heads + head) * nsplit;
     float mm = -1e30f, ll = 0.f, ov = 0.f;

@@ -122,37 +122,6 @@ __device__ __forceinline__ float dot16_fp8(const uint4 w, const float4 x0, const
 
 
 // ---------------------------------------------------------------------------------------------------------
-// L2 prefetch jobs attached to latency-bound launches (round 4).  A few-rows encoder layer is eight dependent launches; three
-// of them (k_attn_combine, k_rows_finish x2) occupy a handful of CUs for ~5 us each and move no weight byte, and the GEMM
-// launches between them are far from their byte time because every one of them starts with an HBM round trip.  A launch
-// always deals its workgroups to the XCDs in the same way (linear block id % 8, tools/micro/xcd_rr.hip: the round-robin
-// pointer does NOT carry over from the previous launch), so it is known at enqueue time which XCD's L2 will be asked for
-// which weight rows by the NEXT GEMM launch: block t of its grid reads the 32-row tile t (rows are contiguous: one
-// contiguous slab of 32 * K * 2 bytes), and it runs on XCD t % 8.  The idle launch gets extra workgroups whose only job is to
-// pull those slabs through their own XCD's L2 (LDS-DMA into a scratch slot, data discarded).  Nothing depends on it.
-// Units are 1 KiB pieces; within an XCD class they are ordered piece-major over the class's tiles, so that a byte limit
-// covers every tile to the same depth (a launch is as slow as its slowest workgroup).
-// ---------------------------------------------------------------------------------------------------------
-struct L2PfJob { const unsigned char *base; int tile_bytes; int n_tiles; int max_units; };
-struct L2Pf { L2PfJob job[2]; int n_blocks; };          // n_blocks prefetch workgroups appended to the grid (multiple of 8; 0 = off)
-// pb = index of this workgroup among the prefetch workgroups, lin = its linear block id in the grid, lds = a 1 KiB scratch slot of this wave
-__device__ __forceinline__ void l2pf_run(const L2Pf &pf, int pb, int lin, unsigned lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int cls = lin & 7, slot = (pb >> 3) * nw + wave, nslots = (pf.n_blocks >> 3) * nw;
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const L2PfJob &q = pf.job[j];
-        if (!q.base || q.n_tiles <= cls) continue;
-        const int tiles_x = (q.n_tiles - cls + 7) >> 3, upt = q.tile_bytes >> 10;
-        const int U = min(tiles_x * upt, q.max_units);
-        for (int u = slot; u < U; u += nslots) {
-            const int piece = u / tiles_x, ti = u - piece * tiles_x;
-            glds16(q.base + (size_t)(cls + 8 * ti) * q.tile_bytes + (size_t)piece * 1024 + lane * 16, lds);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the scratch slot is this workgroup's LDS
-}
-
 // Tuning aid (VOX_HIP_FUSE_TL): per-workgroup timeline of one launch, 16 words per workgroup: [0] wall clock at entry,
 // [1] at exit, [2] (XCC_ID << 32) | HW_ID, [3 ..] the kernel's phase stamps - start skew, tails, XCD placement and where
 // every workgroup spends its time.

@@ -107,19 +107,13 @@ struct DecFuseArgs {
     int split_keys, nsplit;    // keys per slice (multiple of 64), active slices (<= 32)
     unsigned *err;
     unsigned long long spin_limit;   // wall_clock64 ticks
-    unsigned long long *trace;       // optional (tuning): [2 blocks][16] wall-clock stamps of the phases, blocks 0 and 255
-    int spread_groups;               // test switch: group = blockIdx / 32 (members spread over all XCDs) instead of blockIdx % 8
-    int wo_serial_reduce;            // A/B switch: the round-2 per-row wave reductions of the Wo partial product
-    int merge_three_trips;           // A/B switch: long-context merge with the (max, sum) and the value fetches one after the other
-    int attn_gqa;                    // round 3: K / V tiles read from LDS once for the 4 heads of a group (0 = once per head, A/B)
     unsigned long long *tl;          // optional (tuning): per-workgroup timeline, see tl_begin / tl_end
     // Round 4: L2 prefetch of the NEXT launch's (k_gemv_w13x) first weight bytes in this kernel's tail, when the memory system is
     // idle (DfPrefetch below).  pf.units = 0 switches it off.
     DfPrefetch pf;
-    int wo_late;                     // round 4: long contexts request their Wo rows behind their partial instead of under the first tile (see the kernel)
 };
 // stamps stay in registers until the end (no stores in the middle of the memory schedule)
-#define DF_MARK(k) do { if (a.trace || a.tl) df_stamp[k] = wall_clock64(); } while (0)
+#define DF_MARK(k) do { if (a.tl) df_stamp[k] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ void df_store_granule(u64 *g, unsigned epoch, float v) {
     __hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -229,8 +223,13 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     float *red = frq + 256;                                                    // [128]: wave sums, the 24 row results
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = a.spread_groups ? blockIdx.x / DF_BPG : blockIdx.x % DF_GROUPS;
-    const int j = a.spread_groups ? blockIdx.x % DF_BPG : blockIdx.x / DF_GROUPS;
+    // Up to 8 key slices a group sits on one XCD (group = blockIdx % 8: the hand-offs stay inside one L2); beyond, its members are
+    // spread over all XCDs (group = blockIdx / 32): the hand-offs then cross XCDs (+0.3 us each), but a group's K/V tiles and Wo rows
+    // come through all eight L2s - measured, ms per step at 232 / 600 / 1900 / 3800 / 8000 keys: 1.382 / 1.485 / 1.593 / 1.724 / 1.896
+    // on one XCD per group against 1.392 / 1.478 / 1.562 / 1.679 / 1.860 spread.
+    const bool spread = a.nsplit > 8;
+    const int g = spread ? blockIdx.x / DF_BPG : blockIdx.x % DF_GROUPS;
+    const int j = spread ? blockIdx.x % DF_BPG : blockIdx.x / DF_GROUPS;
     const unsigned epoch = a.epoch;
     const int pos = a.pos;
     unsigned long long df_stamp[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -445,7 +444,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     __syncthreads();                       // xs / nw are dead from here on: 24 KB of scratch for the attention stage
     DF_MARK(5);
     // L2 prefetch for the next launch (see DfPrefetch): only in the short-context regime (members without Wo rows, one XCD per group)
-    const bool pf_on = a.pf.units > 0 && wo_light && !a.spread_groups;
+    const bool pf_on = a.pf.units > 0 && wo_light;
     const int pf_V = 32 * a.pf.units, pf_Vm = min(a.pf.member_units, pf_V);
     const unsigned pf_lds = lds_addr(tiles) + 65536u + (unsigned)wave * 1024u;      // beyond the Wo reduction scratch; the tiles are dead where this is used
     if (pf_on && !att_block && a.pf.when == 3) {      // A/B: in front of the Wo rows
@@ -463,7 +462,6 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     float *qs = xs;                        // [512] the group's q
     float *kvn = xs + 512;                 // [256] this step's k | v of head g
     float *att = xs + 768;                 // [512] merged attention output of the group's 4 heads
-    float *sc = xs + 1280;                 // [4 heads][2 halves][64 keys] partial scores
     float *pt = xs + 1792;                 // [4 heads][64 keys] softmax numerators of the current tile
     float *cr = xs + 2048;                 // [4] rescale of the running output, [4] running max, [4] running sum
     float *sc8 = xs + 2560;                // [4 heads][8 dim slices][64 keys] partial scores, then [4 key quarters][4 heads][128] partial outputs
@@ -487,7 +485,6 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     //   PV: thread -> (head, dim), walks the tile's keys.  Arithmetic of voxtral_kernels.c:412-482 up to summation order.
     u64 *gp = a.gp + ((size_t)g * DF_BPG) * DF_GP;
     if (att_block) {
-        const int hs = wave >> 1, half = wave & 1;       // score phase
         const int ho = tid >> 7, dd = tid & 127;         // PV phase
         float o_acc = 0.f;
         if (tid < 4) { cr[4 + tid] = -1e30f; cr[8 + tid] = 0.f; }
@@ -505,8 +502,6 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
             if (ti + 1 < n_tiles)                                    // next tile into the other buffer, under this tile's math
                 df_tile_dma(a, g, t0 + DF_TILE, s_hi, lds_addr(tiles + ((ti + 1) & 1) * 2 * DF_TILE_BYTES),
                             lds_addr(tiles + ((ti + 1) & 1) * 2 * DF_TILE_BYTES + DF_TILE_BYTES), wave, lane);
-            // A/B (VOX_HIP_FUSE_WO_LATE=0, rounds 2 - 3): the Wo rows of an attention member stream under its first tile's math
-            if (ti == 0 && !wo_light && !a.wo_late) { DF_LATE_WO(0) DF_LATE_WO(4) DF_LATE_WO(8) }
             if (t0 + DF_TILE > pos && t0 <= pos) {
                 // this step's own K/V row is not visible in the ring to other CUs yet: patch it in from the hand-off
                 const int key = pos - t0;
@@ -515,108 +510,70 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
                 __syncthreads();
             }
             if (ti == 0) DF_MARK(11);
-            if (a.attn_gqa) {
-                // Round 3: K and V rows are read from LDS ONCE for the 4 query heads that share them (they were read once per head:
-                // 2 x 128 KB of LDS traffic per tile, ~0.9 us of the 2.4 us a member spent between its sweep and its partial).
-                //   scores: wave -> 16 of the 128 dims for all 4 heads, lane -> key; the 8 partial sums per (head, key) meet in LDS;
-                //   PV: thread -> (quarter of the tile's keys, dim) for all 4 heads; the 4 quarter sums meet in LDS.
-                {
-                    const unsigned char *krow = kt + lane * 512;
-                    float s4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const int ch = 4 * wave + c;
-                        const float4 kv4 = *reinterpret_cast<const float4 *>(krow + ((ch ^ (lane & 31)) << 4));
-#pragma unroll
-                        for (int hh = 0; hh < 4; hh++) {
-                            const float4 q4 = *reinterpret_cast<const float4 *>(qs + hh * DF_HD + ch * 4);
-                            s4[hh] = fmaf(q4.x, kv4.x, s4[hh]); s4[hh] = fmaf(q4.y, kv4.y, s4[hh]);
-                            s4[hh] = fmaf(q4.z, kv4.z, s4[hh]); s4[hh] = fmaf(q4.w, kv4.w, s4[hh]);
-                        }
-                    }
-#pragma unroll
-                    for (int hh = 0; hh < 4; hh++) sc8[(hh * 8 + wave) * 64 + lane] = s4[hh];
-                }
-                __syncthreads();
-                if (ti == 0) DF_MARK(12);
-                if (wave < 4) {   // one wave per head: online softmax over this tile's keys
-                    float s = 0.f;
-#pragma unroll
-                    for (int w8 = 0; w8 < 8; w8++) s += sc8[(wave * 8 + w8) * 64 + lane];
-                    s *= a.scale;
-                    if (t0 + lane > s_hi) s = -INFINITY;
-                    const float m_old = cr[4 + wave], l_old = cr[8 + wave];
-                    const float m_new = fmaxf(m_old, df_wave_max<USE_DPP>(s));
-                    const float p = expf(s - m_new);
-                    const float corr = expf(m_old - m_new);
-                    const float l_new = l_old * corr + df_wave_sum<USE_DPP>(p);
-                    pt[wave * 64 + lane] = p;
-                    if (lane == 0) { cr[wave] = corr; cr[4 + wave] = m_new; cr[8 + wave] = l_new; }
-                }
-                __syncthreads();
-                {   // quarter sums: keys 16 kq .. 16 kq + 15 of the tile, dim dd, all 4 heads
-                    // only the tile's valid keys: the rows past s_hi hold whatever the ring slot had (0 x NaN would poison the sum)
-                    const int kq = tid >> 7;
-                    const float *vcol = reinterpret_cast<const float *>(vt) + dd;
-                    const int nv = min(DF_TILE, s_hi - t0 + 1);
-                    float a4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int k0 = 16 * kq + 4 * i;
-                        float v[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) v[u] = k0 + u < nv ? vcol[(k0 + u) * 128] : 0.f;
-#pragma unroll
-                        for (int hh = 0; hh < 4; hh++) {
-                            const float4 p4 = *reinterpret_cast<const float4 *>(pt + hh * 64 + k0);
-                            a4[hh] = fmaf(p4.x, v[0], a4[hh]); a4[hh] = fmaf(p4.y, v[1], a4[hh]);
-                            a4[hh] = fmaf(p4.z, v[2], a4[hh]); a4[hh] = fmaf(p4.w, v[3], a4[hh]);
-                        }
-                    }
-#pragma unroll
-                    for (int hh = 0; hh < 4; hh++) sc8[(kq * 4 + hh) * DF_HD + dd] = a4[hh];     // the score area is free again
-                }
-                __syncthreads();
-                {
-                    const float accv = (sc8[(0 * 4 + ho) * DF_HD + dd] + sc8[(1 * 4 + ho) * DF_HD + dd]) +
-                                       (sc8[(2 * 4 + ho) * DF_HD + dd] + sc8[(3 * 4 + ho) * DF_HD + dd]);
-                    o_acc = o_acc * cr[ho] + accv;
-                }
-                continue;
-            }
-            {   // partial scores: this thread's key x 64 dims of head hs
+            // Round 3: K and V rows are read from LDS ONCE for the 4 query heads that share them (they were read once per head:
+            // 2 x 128 KB of LDS traffic per tile, ~0.9 us of the 2.4 us a member spent between its sweep and its partial).
+            //   scores: wave -> 16 of the 128 dims for all 4 heads, lane -> key; the 8 partial sums per (head, key) meet in LDS;
+            //   PV: thread -> (quarter of the tile's keys, dim) for all 4 heads; the 4 quarter sums meet in LDS.
+            {
                 const unsigned char *krow = kt + lane * 512;
-                const float *qh = qs + hs * DF_HD + half * 64;
-                float s = 0.f;
+                float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < 16; c++) {
-                    const float4 kv4 = *reinterpret_cast<const float4 *>(krow + (((half * 16 + c) ^ (lane & 31)) << 4));
-                    const float4 q4 = *reinterpret_cast<const float4 *>(qh + c * 4);
-                    s = fmaf(q4.x, kv4.x, s); s = fmaf(q4.y, kv4.y, s); s = fmaf(q4.z, kv4.z, s); s = fmaf(q4.w, kv4.w, s);
+                for (int c = 0; c < 4; c++) {
+                    const int ch = 4 * wave + c;
+                    const float4 kv4 = *reinterpret_cast<const float4 *>(krow + ((ch ^ (lane & 31)) << 4));
+#pragma unroll
+                    for (int hh = 0; hh < 4; hh++) {
+                        const float4 q4 = *reinterpret_cast<const float4 *>(qs + hh * DF_HD + ch * 4);
+                        s4[hh] = fmaf(q4.x, kv4.x, s4[hh]); s4[hh] = fmaf(q4.y, kv4.y, s4[hh]);
+                        s4[hh] = fmaf(q4.z, kv4.z, s4[hh]); s4[hh] = fmaf(q4.w, kv4.w, s4[hh]);
+                    }
                 }
-                sc[(hs * 2 + half) * 64 + lane] = s;
+#pragma unroll
+                for (int hh = 0; hh < 4; hh++) sc8[(hh * 8 + wave) * 64 + lane] = s4[hh];
             }
             __syncthreads();
-            if (half == 0) {   // one wave per head: online softmax over this tile's keys
-                float s = (sc[(hs * 2) * 64 + lane] + sc[(hs * 2 + 1) * 64 + lane]) * a.scale;
+            if (ti == 0) DF_MARK(12);
+            if (wave < 4) {   // one wave per head: online softmax over this tile's keys
+                float s = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; w8++) s += sc8[(wave * 8 + w8) * 64 + lane];
+                s *= a.scale;
                 if (t0 + lane > s_hi) s = -INFINITY;
-                const float m_old = cr[4 + hs], l_old = cr[8 + hs];
+                const float m_old = cr[4 + wave], l_old = cr[8 + wave];
                 const float m_new = fmaxf(m_old, df_wave_max<USE_DPP>(s));
                 const float p = expf(s - m_new);
                 const float corr = expf(m_old - m_new);
                 const float l_new = l_old * corr + df_wave_sum<USE_DPP>(p);
-                pt[hs * 64 + lane] = p;
-                if (lane == 0) { cr[hs] = corr; cr[4 + hs] = m_new; cr[8 + hs] = l_new; }
+                pt[wave * 64 + lane] = p;
+                if (lane == 0) { cr[wave] = corr; cr[4 + wave] = m_new; cr[8 + wave] = l_new; }
             }
             __syncthreads();
-            {   // PV: out[ho][dd] = out * corr + sum_k p[ho][k] * V[k][dd]
+            {   // quarter sums: keys 16 kq .. 16 kq + 15 of the tile, dim dd, all 4 heads
                 // only the tile's valid keys: the rows past s_hi hold whatever the ring slot had (0 x NaN would poison the sum)
-                const float *pr = pt + ho * 64;
+                const int kq = tid >> 7;
                 const float *vcol = reinterpret_cast<const float *>(vt) + dd;
                 const int nv = min(DF_TILE, s_hi - t0 + 1);
-                float accv = 0.f;
-#pragma unroll 8
-                for (int k = 0; k < nv; k++) accv = fmaf(pr[k], vcol[k * 128], accv);
+                float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int k0 = 16 * kq + 4 * i;
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = k0 + u < nv ? vcol[(k0 + u) * 128] : 0.f;
+#pragma unroll
+                    for (int hh = 0; hh < 4; hh++) {
+                        const float4 p4 = *reinterpret_cast<const float4 *>(pt + hh * 64 + k0);
+                        a4[hh] = fmaf(p4.x, v[0], a4[hh]); a4[hh] = fmaf(p4.y, v[1], a4[hh]);
+                        a4[hh] = fmaf(p4.z, v[2], a4[hh]); a4[hh] = fmaf(p4.w, v[3], a4[hh]);
+                    }
+                }
+#pragma unroll
+                for (int hh = 0; hh < 4; hh++) sc8[(kq * 4 + hh) * DF_HD + dd] = a4[hh];     // the score area is free again
+            }
+            __syncthreads();
+            {
+                const float accv = (sc8[(0 * 4 + ho) * DF_HD + dd] + sc8[(1 * 4 + ho) * DF_HD + dd]) +
+                                   (sc8[(2 * 4 + ho) * DF_HD + dd] + sc8[(3 * 4 + ho) * DF_HD + dd]);
                 o_acc = o_acc * cr[ho] + accv;
             }
         }
@@ -632,7 +589,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
         // Same box, alternating, ms per step at 600 / 1000 / 1900 / 3800 / 8000 keys: 1.4331 / 1.4490 / 1.5265 / 1.6296 / 1.8045 ->
         // 1.4289 / 1.4404 / 1.5141 / 1.5882 / 1.7540 (requesting them right behind the q/k/v sweep instead: +2 % up to 1900 keys - a
         // sweep that finds a stale tag repeats its load behind the rows - and -1 % beyond).
-        if (!wo_light && a.wo_late) { __builtin_amdgcn_sched_barrier(0); DF_LATE_WO(0) DF_LATE_WO(4) DF_LATE_WO(8) }
+        if (!wo_light) { __builtin_amdgcn_sched_barrier(0); DF_LATE_WO(0) DF_LATE_WO(4) DF_LATE_WO(8) }
         if (pf_on && pf_Vm > 0) {      // a member is done: its share of the next launch's first bytes (every tile read is behind the barrier above)
             __builtin_amdgcn_sched_barrier(0);
             df_prefetch_units(a.pf, g, 0, pf_Vm, j * DF_WAVES + wave, ns * DF_WAVES, lane, pf_lds);
@@ -667,8 +624,11 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
             // Round 3: the thread's own (head, dim) granules of all slices are requested BEFORE the (max, sum) pairs are waited
             // for - loads return in order, so the two fetches share one trip to L2 instead of following each other (the merge
             // took 4.6 us at 1900 keys, profiles/r02_fuse_timeline_kv1900.txt).  VOX_HIP_FUSE_MERGE3 = the old three trips.
+            // (one shared trip pays while a member's slice is one 64-key tile - 1.576 vs 1.589 ms per step at 1900 keys; with two tiles
+            //  per member the members finish further apart, the early loads miss and are repeated: 1.731 vs 1.710 at 3800)
+            const bool three_trips = a.split_keys > 64;
             u64 gv[32];
-            if (!a.merge_three_trips) {
+            if (!three_trips) {
 #pragma unroll
                 for (int u = 0; u < 32; u++) gv[u] = df_load_granule(gp + (size_t)min(u, ns - 1) * DF_GP + h * DF_HD + d);
             }
@@ -694,7 +654,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
                 const unsigned long long t0 = wall_clock64();
                 for (unsigned it = 0;; it++) {
                     bool ok = true;
-                    if (it > 0 || a.merge_three_trips) {
+                    if (it > 0 || three_trips) {
 #pragma unroll
                         for (int u = 0; u < 32; u++) gv[u] = df_load_granule(gp + (size_t)min(u, ns - 1) * DF_GP + h * DF_HD + d);
                     }
@@ -778,48 +738,30 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
     if (wo_n > 0) {
         const float4 x0 = *reinterpret_cast<const float4 *>(att + lane * 8);
         const float4 x1 = *reinterpret_cast<const float4 *>(att + lane * 8 + 4);
-        if (a.wo_serial_reduce) {
-            // A/B (VOX_HIP_FUSE_SERIAL_WO): one wave-wide reduction per row, 13-16 in a row - 1.36 us between "wo landed" and
-            // "wo done" in the round-2 timeline (profiles/r02_fuse_timeline_kv232.txt), on the critical path of every layer
-            float mine = 0.f;
+        // The 16 row sums of a wave as ONE transposed reduction through LDS (the K/V tile area is dead by now: every DMA has
+        // landed and every reader is past the barrier above): lane l parks its 16 partial dots in column l of a [16][68]
+        // scratch (row stride 68 floats: the reads below then hit 16 distinct 16-byte slots per service group), lane
+        // (row = l >> 2, quarter = l & 3) adds 16 of them in a fixed order, two quad steps finish the row.  LDS operations
+        // of one wave execute in order, so no barrier is needed between the stores and the loads.
+        float *wr = reinterpret_cast<float *>(tiles) + wave * (16 * 68);
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                if (i < wo_n) {
-                    const float s = df_wave_sum<USE_DPP>(dot8_bf16(wv[i], x0, x1, 0.f));
-                    if (lane == i) mine = s;
-                }
-            }
-            if (lane < wo_n) a.wo_part[(size_t)g * DF_D + wo_row0 + lane] = mine;
-        } else {
-            // The 16 row sums of a wave as ONE transposed reduction through LDS (the K/V tile area is dead by now: every DMA has
-            // landed and every reader is past the barrier above): lane l parks its 16 partial dots in column l of a [16][68]
-            // scratch (row stride 68 floats: the reads below then hit 16 distinct 16-byte slots per service group), lane
-            // (row = l >> 2, quarter = l & 3) adds 16 of them in a fixed order, two quad steps finish the row.  LDS operations
-            // of one wave execute in order, so no barrier is needed between the stores and the loads.
-            float *wr = reinterpret_cast<float *>(tiles) + wave * (16 * 68);
+        for (int i = 0; i < 16; i++) wr[i * 68 + lane] = dot8_bf16(wv[i], x0, x1, 0.f);      // rows past wo_n repeat the last one: never stored
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int row = lane >> 2, q = lane & 3;
+        float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; i++) wr[i * 68 + lane] = dot8_bf16(wv[i], x0, x1, 0.f);      // rows past wo_n repeat the last one: never stored
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int row = lane >> 2, q = lane & 3;
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const float4 v = *reinterpret_cast<const float4 *>(wr + row * 68 + q * 16 + 4 * c);
-                s += (v.x + v.y) + (v.z + v.w);
-            }
-            s += __shfl_xor(s, 1, 4);
-            s += __shfl_xor(s, 2, 4);
-            if (q == 0 && row < wo_n) a.wo_part[(size_t)g * DF_D + wo_row0 + row] = s;
+        for (int c = 0; c < 4; c++) {
+            const float4 v = *reinterpret_cast<const float4 *>(wr + row * 68 + q * 16 + 4 * c);
+            s += (v.x + v.y) + (v.z + v.w);
         }
+        s += __shfl_xor(s, 1, 4);
+        s += __shfl_xor(s, 2, 4);
+        if (q == 0 && row < wo_n) a.wo_part[(size_t)g * DF_D + wo_row0 + row] = s;
     }
     if (pf_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the scratch slot is this workgroup's LDS: no DMA may outlive it
     DF_MARK(10);
-    if (a.trace && tid == 0 && (blockIdx.x == 0 || blockIdx.x == DF_BLOCKS - 1)) {
-#pragma unroll
-        for (int k = 0; k < 11; k++) a.trace[(blockIdx.x ? 16 : 0) + k] = df_stamp[k];
-    }
     tl_end(a.tl, tl0, df_stamp, 13);
 }
 
@@ -840,7 +782,6 @@ struct W13xArgs {
     float eps;
     float *x_out;              // [3072] x' (may alias x)
     float *h;                  // [9216]
-    unsigned long long *trace; // optional (tuning): [2 blocks][16] stamps, written at +32
     unsigned long long *tl;    // optional (tuning): per-workgroup timeline
 };
 constexpr int W13X_THREADS = 768;
@@ -959,10 +900,6 @@ __global__ __launch_bounds__(W13X_THREADS, 1) void k_gemv_w13x(const W13xArgs a)
         }
     }
     DF_MARK(4);
-    if (a.trace && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 255)) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) a.trace[32 + (blockIdx.x ? 16 : 0) + k] = df_stamp[k];
-    }
     tl_end(a.tl, tl0, df_stamp, 5);
 }
 
@@ -1728,7 +1665,7 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
             df_store_granule(mine + ho * DF_HD + dd, epoch, o_acc);
             if (dd == 0) { df_store_granule(mine + 4 * DF_HD + 2 * ho, epoch, cr[4 + ho]); df_store_granule(mine + 4 * DF_HD + 2 * ho + 1, epoch, cr[8 + ho]); }
         }
-        if constexpr (LONG) {      // a member's Wo rows: requested behind its partial (see k_dec_attn_fused, wo_late)
+        if constexpr (LONG) {      // a member's Wo rows: requested behind its partial (see k_dec_attn_fused)
             __builtin_amdgcn_sched_barrier(0);
             DA12_ISSUE_WO()
         }

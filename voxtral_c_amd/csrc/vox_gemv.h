@@ -41,7 +41,7 @@ struct GemvArgs {
     // EPI_LOGITS
     float *blk_val;
     int *blk_idx;
-    // k_gemv2 extras
+    // fast-path extras
     const float *inv_freq;     // EPI_QKV: RoPE computed in the epilogue from st->pos
     const float *adapter;      // PRO_EMBED_RMS: x = adapter[st->adapter_row] + tok_emb[st->token]
     const uint16_t *tok_emb;
@@ -217,191 +217,15 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 
 
 // ---------------------------------------------------------------------------------------
-// k_gemv2 — the production decode GEMV for the 4B shapes.
-//
-// The per-layer matrices are small (25-113 MB): a launch lasts 5-20 us, so what matters is
-// how fast the chip gets from "kernel start" to "every CU has its full share of HBM requests
-// in flight" and that no CU gets a second helping while others idle.  Therefore:
-//   * one pass per block, no grid-stride loop: grid = N / (rows per block) is chosen per
-//     matrix as an exact multiple of the 256 CUs (256 / 512 / 768 blocks);
-//   * a wave issues ALL of its weight loads (RPW rows x CPL 16-byte pieces per lane, fully
-//     unrolled, non-temporal) before anything else — the x staging / RMSNorm / embedding /
-//     attention-combine prologue then runs under the HBM latency instead of in front of it;
-//   * KS = 2 splits K across wave pairs for the K = 9216 down-projection (keeps the loads
-//     per lane at 27 and the grid at 512) with a 2-way LDS reduction;
-//   * the RoPE rotation is computed in the QKV epilogue from the device-resident position
-//     (no table kernel), the step embedding is built in layer 0's prologue (no embed kernel),
-//     the split-K attention partials are merged in the Wo prologue (no combine kernel).
+// The decode GEMVs of the 4B shapes (k_gemv3 below).  The per-layer matrices are small (25-113 MB): a launch lasts 5-20 us, so what
+// matters is how fast the chip gets from "kernel start" to "every CU has its full share of HBM requests in flight" and that no CU
+// gets a second helping while others idle.  Therefore:
+//   * one pass per block, no grid-stride loop: grid = N / (rows per block) is chosen per matrix as an exact multiple of the 256 CUs;
+//   * KS = 2 splits K across wave pairs for the K = 9216 down-projection with a 2-way LDS reduction;
+//   * the RoPE rotation is computed in the QKV epilogue from the position (no table kernel), the step embedding is built in layer
+//     0's prologue (no embed kernel), the split-K attention partials are merged in the Wo prologue (no combine kernel).
+// (k_gemv2, rounds 1 - 4: the same kernel with all weight loads issued first - +6 us per launch, see k_gemv3 - removed in round 5.)
 // ---------------------------------------------------------------------------------------
-template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW>
-__global__ __launch_bounds__(256, MINW) void k_gemv2(const GemvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *xs = smem;                 // [K]
-    float *red = smem + a.K;          // [16] + KS partials [4*RPW*2] + attention scales
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NMAT = (EPI == EPI_SWIGLU) ? 2 : 1;
-    constexpr int RG = 4 / KS;        // row groups (waves along rows) per block
-    const int rg = wave / KS, kp = wave % KS;
-    const int K = a.K, N = a.N;
-    const int row0 = (blockIdx.x * RG + rg) * RPW;
-
-    // ---- 1. every weight byte this wave needs, requested up front ---------------------------
-    uint4 w[NMAT][RPW][CPL];
-#pragma unroll
-    for (int r = 0; r < RPW; r++) {
-        const int row = min(row0 + r, N - 1);
-        const uint4 *p0 = reinterpret_cast<const uint4 *>(a.W + (size_t)row * K) + kp * (CPL * 64) + lane;
-#pragma unroll
-        for (int c = 0; c < CPL; c++) w[0][r][c] = ld_stream(p0 + c * 64);
-        if constexpr (NMAT == 2) {
-            const uint4 *p1 = reinterpret_cast<const uint4 *>(a.W2 + (size_t)row * K) + kp * (CPL * 64) + lane;
-#pragma unroll
-            for (int c = 0; c < CPL; c++) w[1][r][c] = ld_stream(p1 + c * 64);
-        }
-    }
-
-    // ---- 2. prologue under the HBM latency ----------------------------------------------------
-    if constexpr (PRO == PRO_ATTN) {
-        // x[h*HD + d] = sum_s o[h][s][d] * exp(m_s - m) / sum_s l_s exp(m_s - m)
-        float *scl = red + 16 + 4 * RPW * 2;             // [heads][nsplit]
-        const int HD = a.attn_hd, heads = K / HD, ns = a.nsplit;
-        for (int h = tid; h < heads; h += 256) {
-            float mm = -1e30f;
-            for (int sidx = 0; sidx < ns; sidx++) mm = fmaxf(mm, a.part_ml[(h * ns + sidx) * 2]);
-            float ll = 0.f;
-            for (int sidx = 0; sidx < ns; sidx++) ll += a.part_ml[(h * ns + sidx) * 2 + 1] * expf(a.part_ml[(h * ns + sidx) * 2] - mm);
-            const float inv = ll > 0.f ? 1.0f / ll : 0.f;
-            for (int sidx = 0; sidx < ns; sidx++) scl[h * ns + sidx] = expf(a.part_ml[(h * ns + sidx) * 2] - mm) * inv;
-        }
-        __syncthreads();
-        for (int i = tid * 4; i < K; i += 1024) {
-            const int h = i / HD, d = i - h * HD;
-            float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int sidx = 0; sidx < ns; sidx++) {
-                const float f = scl[h * ns + sidx];
-                const float4 o = *reinterpret_cast<const float4 *>(a.part_o + ((size_t)h * ns + sidx) * HD + d);
-                acc4.x += o.x * f; acc4.y += o.y * f; acc4.z += o.z * f; acc4.w += o.w * f;
-            }
-            *reinterpret_cast<float4 *>(xs + i) = acc4;
-        }
-    } else {
-        float ss = 0.f;
-        if constexpr (PRO == PRO_EMBED_RMS) {
-            const float *arow = a.adapter + (size_t)a.st->adapter_row * K;
-            const uint16_t *erow = a.tok_emb + (size_t)a.st->token * K;
-            for (int i = tid * 4; i < K; i += 1024) {
-                float4 v = *reinterpret_cast<const float4 *>(arow + i);
-                const uint2 eb = *reinterpret_cast<const uint2 *>(erow + i);
-                v.x += bf16_lo(eb.x); v.y += bf16_hi(eb.x); v.z += bf16_lo(eb.y); v.w += bf16_hi(eb.y);
-                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-                *reinterpret_cast<float4 *>(xs + i) = v;
-                if (blockIdx.x == 0) *reinterpret_cast<float4 *>(a.x_out + i) = v;
-            }
-        } else {
-            for (int i = tid * 4; i < K; i += 1024) {
-                const float4 v = *reinterpret_cast<const float4 *>(a.x + i);
-                if (PRO == PRO_RMS) ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-                *reinterpret_cast<float4 *>(xs + i) = v;
-            }
-        }
-        if constexpr (PRO == PRO_RMS || PRO == PRO_EMBED_RMS) {
-            ss = wave_sum(ss);
-            if (lane == 0) red[wave] = ss;
-            __syncthreads();
-            const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + a.eps);
-            for (int i = tid * 4; i < K; i += 1024) {
-                float4 v = *reinterpret_cast<float4 *>(xs + i);
-                const float4 g = *reinterpret_cast<const float4 *>(a.norm_w + i);
-                v.x = v.x * inv * g.x; v.y = v.y * inv * g.y; v.z = v.z * inv * g.z; v.w = v.w * inv * g.w;
-                if (a.ada) {
-                    const float4 sc = *reinterpret_cast<const float4 *>(a.ada + i);
-                    v.x *= (1.0f + sc.x); v.y *= (1.0f + sc.y); v.z *= (1.0f + sc.z); v.w *= (1.0f + sc.w);
-                }
-                *reinterpret_cast<float4 *>(xs + i) = v;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- 3. dot products ------------------------------------------------------------------------
-    float acc[NMAT][RPW];
-#pragma unroll
-    for (int m = 0; m < NMAT; m++)
-#pragma unroll
-        for (int r = 0; r < RPW; r++) acc[m][r] = 0.f;
-#pragma unroll
-    for (int c = 0; c < CPL; c++) {
-        const float *xp = xs + ((kp * CPL + c) * 64 + lane) * 8;
-        const float4 x0 = *reinterpret_cast<const float4 *>(xp);
-        const float4 x1 = *reinterpret_cast<const float4 *>(xp + 4);
-#pragma unroll
-        for (int m = 0; m < NMAT; m++)
-#pragma unroll
-            for (int r = 0; r < RPW; r++) acc[m][r] = dot8_bf16(w[m][r][c], x0, x1, acc[m][r]);
-    }
-#pragma unroll
-    for (int m = 0; m < NMAT; m++)
-#pragma unroll
-        for (int r = 0; r < RPW; r++) acc[m][r] = wave_sum(acc[m][r]);
-    if constexpr (KS == 2) {
-        float *part = red + 16;                        // [RG][NMAT*RPW]
-        if (kp == 1 && lane == 0) {
-#pragma unroll
-            for (int m = 0; m < NMAT; m++)
-#pragma unroll
-                for (int r = 0; r < RPW; r++) part[rg * (NMAT * RPW) + m * RPW + r] = acc[m][r];
-        }
-        __syncthreads();
-        if (kp == 0) {
-#pragma unroll
-            for (int m = 0; m < NMAT; m++)
-#pragma unroll
-                for (int r = 0; r < RPW; r++) acc[m][r] += part[rg * (NMAT * RPW) + m * RPW + r];
-        }
-    }
-
-    // ---- 4. epilogue ------------------------------------------------------------------------------
-    if (lane == 0 && kp == 0) {
-        if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-            for (int r = 0; r < RPW; r++) {
-                const int row = row0 + r;
-                if (row < N) a.y[row] = a.y[row] + acc[0][r];
-            }
-        } else if constexpr (EPI == EPI_SWIGLU) {
-#pragma unroll
-            for (int r = 0; r < RPW; r++) {
-                const int row = row0 + r;
-                if (row < N) a.y[row] = silu(acc[0][r]) * acc[1][r];
-            }
-        } else if constexpr (EPI == EPI_QKV) {
-            const int pos = a.st->pos;
-            const int slot = pos % a.kv_cap;
-            const int qk_rows = a.q_rows + a.k_rows;
-            const float fpos = (float)pos;
-#pragma unroll
-            for (int r = 0; r < RPW; r += 2) {
-                const int row = row0 + r;
-                if (row + 1 < N) {
-                    float o0 = acc[0][r], o1 = acc[0][r + 1];
-                    if (row < qk_rows) {
-                        const float ang = fpos * a.inv_freq[(row % a.head_dim) >> 1];
-                        const float c = cosf(ang), sn = sinf(ang);
-                        const float x0 = o0, x1 = o1;
-                        o0 = x0 * c - x1 * sn;
-                        o1 = x0 * sn + x1 * c;
-                    }
-                    float *dst;
-                    if (row < a.q_rows) dst = a.y + row;
-                    else if (row < qk_rows) dst = a.kcache + (size_t)slot * a.kv_dim + (row - a.q_rows);
-                    else dst = a.vcache + (size_t)slot * a.kv_dim + (row - qk_rows);
-                    dst[0] = o0;
-                    dst[1] = o1;
-                }
-            }
-        }
-    }
-}
 
 // bf16 [N, K] -> fp8 e4m3 [N, K] with one f32 scale per row (BASELINE config 5: fp8 decode weights).
 // scale = max|w| / 224 keeps every quantised value inside the finite range of both e4m3 flavours;
@@ -500,11 +324,11 @@ __global__ __launch_bounds__(256) void k_step_begin(const DecState *st, const fl
 
 
 // ---------------------------------------------------------------------------------------
-// k_gemv3 — k_gemv2 with the memory queue in the right order.
+// k_gemv3 — the decode GEMV with the memory queue in the right order.
 //
-// Measured on MI355X (profiles/r01_run2_*): every k_gemv2 launch pays ~6 us on top of
+// Measured on MI355X (profiles/r01_run2_*): a launch that issues its weight loads first pays ~6 us on top of
 // bytes / 6.3 TB/s.  A CU's vector-memory path returns loads in issue order, so the x / norm /
-// partial loads that k_gemv2 issues AFTER its 24-36 weight loads per lane come back last: the
+// partial loads issued AFTER the 24-36 weight loads per lane come back last: the
 // whole prologue (RMSNorm, attention merge) and every FMA then run after the weight stream has
 // drained instead of under it.  Here the order is
 //   1. epilogue operands (residual rows, position, RoPE frequencies)          [registers]

@@ -195,9 +195,7 @@ struct vox_hip_engine {
     size_t mem_used = 0;
     bool use_skinny = true;
     bool use_rowsgemm = true;     // 33 .. 128-row chunks (decoder prefill, encoder flush pass) on k_rowsgemm (vox_rowsgemm.h)
-    int rg_small = 0;             // A/B (VOX_HIP_RG_SMALL): also run <= 32-row encoder chunks on that path instead of k_skinny
-    bool use_dpp = true, use_mfma = true, use_gemv2 = true, use_gemv3 = true, use_splitk = true, use_bf16x3 = true, use_attn_mfma = true;
-    bool use_attn_bf16 = true;    // encoder attention on the bf16 matrix pipe (k_attn_enc_bf16, 6-term exact split) instead of the f32-input MFMA
+    bool use_dpp = true, use_mfma = true, use_fast = true, use_splitk = true, use_bf16x3 = true, use_attn_mfma = true;
 
     // weights
     uint16_t *tok_emb = nullptr, *conv0_w = nullptr, *conv1_w = nullptr, *adapter0 = nullptr, *adapter1 = nullptr;
@@ -241,31 +239,28 @@ struct vox_hip_engine {
     bool fused_ok = false;        // the fused kernels exist for this geometry / device (use_fused may be suspended after a time-out)
     long fuse_rearm = 0;          // clean decode steps on the chain before the fused kernel is tried again (0 = not suspended)
     u64 *d_gq = nullptr, *d_gp = nullptr, *d_gh = nullptr;
-    int merge12 = 2;              // VOX_HIP_MERGE12: 0 = two launches per layer in the 8-wave shape (before), 1 = k_attn12 in place of k_dec_attn_fused where it applies (A/B of the shape), 2 = k_ffn_attn12
+    int merge12 = 2;              // 2 = k_ffn_attn12 (FFN block of layer l + attention block of layer l + 1 in one launch); 0 (VOX_HIP_DISABLE=merge12) = two launches per layer in the 8-wave shape
     u64 *d_gx = nullptr;          // [3072] x'' hand-off of k_ffn_attn12
-    int use_stack = 1;            // VOX_HIP_STACK=0 (A/B): one k_ffn_attn12 launch per layer (round 4) instead of ONE k_dec_stack launch for the layers' FFN / attention blocks
+    int use_stack = 1;            // 0 (VOX_HIP_DISABLE=stack): one k_ffn_attn12 launch per layer (round 4) instead of ONE k_dec_stack launch for all layers' blocks
     u64 *d_gw = nullptr, *d_gxp = nullptr;   // k_dec_stack: [8][3072] Wo partial sums, [3072] x' (hand-off granules)
     DecStackLayer *d_stack_tab = nullptr;    // per-layer pointers of k_dec_stack (device copy of h_stack_tab)
     std::vector<DecStackLayer> h_stack_tab;
-    int merge12_long = 1;         // VOX_HIP_MERGE12_LONG=0 (A/B): beyond merge12_maxkeys two launches per layer in the 8-wave shape (round 4); 1 = k_ffn_attn12<LONG> (9 .. 32 key slices)
-    int merge12_maxkeys = 1024;   // VOX_HIP_MERGE12_MAXKEYS: the merged launches up to this context length (8 key slices of two tiles beyond 512 keys; measured: 2048 = four tiles per member loses 2 % at 1900 keys)
-    int wo_late = 1;              // VOX_HIP_FUSE_WO_LATE=0 (A/B, see DecFuseArgs)
+    int merge12_long = 1;         // 0 (VOX_HIP_DISABLE=merge12_long): beyond merge12_maxkeys two launches per layer in the 8-wave shape (round 4); 1 = k_ffn_attn12<LONG> (9 .. 32 key slices)
+    static constexpr int merge12_maxkeys = 1024;      // 8 key slices up to this context length (two tiles per member beyond 512 keys; measured: 2048 = four tiles per member loses 2 % at 1900 keys)
     float *d_xprime = nullptr;    // x' of the fused FFN launch, written only for the debug taps
     bool use_ffn = false;         // FFN block as one launch (k_ffn_fused) instead of k_gemv_w13x + k_gemv_w2x
     float *d_wo_part = nullptr;
     unsigned *d_fuse_err = nullptr;
     unsigned fuse_epoch = 0;
-    unsigned long long *d_fuse_trace = nullptr;
     bool use_planes = true;       // large-M GEMMs on pre-split bf16 planes (k_gemm_planes)
     bool use_epi = true, use_attn_small = true, use_staged_upload = true;     // A/B switches, read once per engine (self_test)
-    int gp_tn = 2;                // MFMA tiles per wave along N in k_gemm_planes (2: 128 x 128 workgroup tile, 4: 128 x 256)
     // k_gemm_planes with the weight fragments straight from global memory to registers (VOX_HIP_GP_BDIRECT=1).  Measured and NOT
     // kept as the default: 1627-row pass, qkv 114.8 -> 137.7 us, w1;w3 158 -> 190 us (gpurun_out/p13) - the fragment-layout loads
     // (32 bytes from each of 32 rows per instruction, issued twice: both row halves of the tile need them) cost more than the
     // quarter of the LDS-DMA transport they take away.
-    bool gp_bd = false;
     Buf splanes;                  // [3][n][max(D, QD, H)] bf16
     Uploader *up = nullptr;       // staged weight ingest: lives until vox_hip_upload_done (vox_load calls it) or the engine's end
+    bool enc_tl_on = false;
     unsigned long long *d_enc_tl = nullptr;       // VOX_HIP_ENC_TL: [4 GEMM launches][1024 workgroups][16] timeline of one few-rows encoder layer
     unsigned long long *d_fuse_tl = nullptr;      // VOX_HIP_FUSE_TL: [3 kernels][1024 workgroups][3] timeline of the layer-13 launches
     int fuse_failures = 0;
@@ -298,7 +293,7 @@ struct vox_hip_engine {
     // Round 4: L2 prefetch of the next launch's first weight bytes (vox_decfuse.h, DfPrefetch).  VOX_HIP_PF="units,member_units,when"
     // overrides the default (A/B).
     // Default (measured): 24 KiB per target block (6.3 MB per launch) issued by the non-members in front of their Wo rows.
-    int pf_units = 24, pf_member_units = 0, pf_when = 3;
+    static constexpr int pf_units = 24, pf_member_units = 0, pf_when = 3;      // DfPrefetch (vox_decfuse.h): 24 KiB per target block, by the non-members, in front of their Wo rows
 };
 
 // Every host-side wait on the engine stream goes through here and is counted (vox_hip_host_syncs): the multi-GPU
@@ -307,6 +302,27 @@ static hipError_t esync(vox_hip_engine *e) {
     e->n_host_syncs++;
     return hipStreamSynchronize(e->stream);
 }
+
+// VOX_HIP_DISABLE=name[,name..]: the ONE switch of the fallback ladder.  Every name switches one production kernel family off, so
+// that the next older HIP path underneath runs instead (never a CPU path) - what a failed start-up self-test does by itself.  For
+// A/B measurements and for the tests that keep the older paths honest.  Names: fused (the launch-per-GEMV decode chain), ffn_fused,
+// merge12 (two launches per layer), merge12_long (two launches per layer beyond 1024 keys), stack (one launch per layer),
+// fast (the generic decode kernels), dpp, mfma, bf16x3, planes, splitk, skinny, rowsgemm, attn_small, attn_mfma, epi (separate RoPE / SiLU launches), staged_upload, rearm (a timed-out fused kernel stays off),
+// fp8_attn / fp8_lmhead (fp8 mode: these matrices stay bf16), multi_overlap (multi-GPU: wait for the whole wavefront).
+static bool vox_disabled(const char *name) {
+    const char *v = getenv("VOX_HIP_DISABLE");
+    if (!v) return false;
+    const size_t n = strlen(name);
+    for (const char *p = v; *p;) {
+        const char *q = strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : strlen(p);
+        if (len == n && !strncmp(p, name, n)) return true;
+        if (!q) break;
+        p = q + 1;
+    }
+    return false;
+}
+extern "C" int vox_hip_switch_disabled(const char *name) { return name && vox_disabled(name) ? 1 : 0; }
 
 // Stream-side waits for other engines' pending work (see vox_hip_engine::row_fences).
 static int apply_row_fences(vox_hip_engine *e, int64_t upto_row) {         // rows [.., upto_row] are about to be read on e->stream
@@ -450,23 +466,20 @@ static int launch_gemm_planes(vox_hip_engine *e, const uint16_t *Xp, size_t plan
                               int epi = GP_EPI_STD, const GemmArgs *extra = nullptr) {
     GemmArgs a{nullptr, 0, W, Y, ldy, M, N, K, bias, resid, ldr, act, 1, 0, nullptr};
     a.Xp = Xp; a.xp_plane = plane; a.ldxp = ldxp;
-    const size_t lds_bd = (size_t)2 * 3 * GP_PLANE_BYTES;          // direct-B variants: two stages of A planes only
     if (epi == GP_EPI_SWIGLU) {       // N = hidden columns, W = [w1; w3]; output = bf16 planes of the gated hidden rows
         a.Yp = extra->Yp; a.yp_plane = extra->yp_plane;
         const dim3 grid((N + 63) / 64, (M + GB_M - 1) / GB_M);
-        if (e->gp_bd) hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_SWIGLU, true>), grid, dim3(256), lds_bd, e->stream, a);
-        else hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_SWIGLU>), grid, dim3(256), (size_t)2 * gp_stage_bytes(2), e->stream, a);
+        hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_SWIGLU>), grid, dim3(256), (size_t)2 * gp_stage_bytes(2), e->stream, a);
         return 0;
     }
     if (epi == GP_EPI_ROPE) {
         a.rope_tab = extra->rope_tab; a.rope_cols = extra->rope_cols; a.head_dim = extra->head_dim;
         const dim3 grid((N + 127) / 128, (M + GB_M - 1) / GB_M);
-        if (e->gp_bd) hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_ROPE, true>), grid, dim3(256), lds_bd, e->stream, a);
-        else hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_ROPE>), grid, dim3(256), (size_t)2 * gp_stage_bytes(2), e->stream, a);
+        hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_ROPE>), grid, dim3(256), (size_t)2 * gp_stage_bytes(2), e->stream, a);
         return 0;
     }
     if (M <= 0 || N <= 0) return 0;
-    const int TN = e->gp_tn, st = 2;
+    constexpr int TN = 2, st = 2;          // MFMA tiles per wave along N: 128 x 128 workgroup tile
     const int BN = 64 * TN;
     const int tn = (N + BN - 1) / BN, tm = (M + GB_M - 1) / GB_M, nk = K / GP_K;
     const int resident = 512;                      // 2 workgroups per CU (64 / 80 KB of LDS each)
@@ -475,22 +488,17 @@ static int launch_gemm_planes(vox_hip_engine *e, const uint16_t *Xp, size_t plan
         ksplit = std::min(std::min(std::max(1, resident / (tm * tn)), nk / 4), 16);
         if (ksplit < 2) ksplit = 1;
     }
-    auto kern = e->gp_bd ? (TN == 2 ? k_gemm_planes<2, 2, GP_EPI_STD, true> : k_gemm_planes<2, 4, GP_EPI_STD, true>)
-                         : (TN == 2 ? k_gemm_planes<2, 2> : k_gemm_planes<2, 4>);
-    const size_t lds = e->gp_bd ? lds_bd : (size_t)st * gp_stage_bytes(TN);
+    auto kern = k_gemm_planes<2, 2>;
+    const size_t lds = (size_t)st * gp_stage_bytes(TN);
     if (ksplit > 1) {
         if (ensure(e, e->ssplitk, (size_t)ksplit * M * N * 4)) return -1;
         a.ksplit = ksplit; a.kper = (nk + ksplit - 1) / ksplit; a.partial = (float *)e->ssplitk.p;
         a.ksplit = (nk + a.kper - 1) / a.kper;
-        static const int gp_xcd = getenv("VOX_HIP_GP_NO_XCD") ? 0 : 1;
-        if (gp_xcd) {           // 1-D grid in XCD-aware order (vox_gemm_planes.h): groups of tn workgroups sharing an A slab stay on one XCD
+        {           // 1-D grid in XCD-aware order (vox_gemm_planes.h): groups of tn workgroups sharing an A slab stay on one XCD
             a.xcd_tn = tn; a.xcd_tm = tm;
             const int groups = tm * a.ksplit;
             hipLaunchKernelGGL(kern, dim3(8 * ((groups + 7) / 8) * tn), dim3(256), lds, e->stream, a);
             a.xcd_tn = 0;
-        } else {
-            dim3 grid(tn, tm, a.ksplit);
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds, e->stream, a);
         }
         hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((size_t)M * N)), dim3(256), 0, e->stream, a);
     } else {
@@ -675,7 +683,7 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
         hipDeviceProp_t prop;
         const bool geom = d.dec_dim == DF_D && e->dec_qd == DF_DQ && e->dec_kvd == DF_DKV && d.dec_hidden == 9216 &&
                           d.dec_head_dim == DF_HD && d.dec_heads == 32 && d.dec_kv_heads == DF_GROUPS;
-        if (geom && !getenv("VOX_HIP_NO_FUSED") && !getenv("VOX_HIP_NO_GEMV3") && !getenv("VOX_HIP_NO_GEMV2") && !getenv("VOX_HIP_CUMASK") &&
+        if (geom && !vox_disabled("fused") && !vox_disabled("fast") && !getenv("VOX_HIP_CUMASK") &&
             hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount == DF_BLOCKS) {
             bool ok = dalloc(e, &e->d_gq, (size_t)DF_GROUPS * DF_GQ) == 0 && dalloc(e, &e->d_gp, (size_t)DF_GROUPS * DF_BPG * DF_GP) == 0 &&
                       dalloc(e, &e->d_wo_part, (size_t)DF_GROUPS * DF_D) == 0 && dalloc(e, &e->d_fuse_err, 64) == 0 &&
@@ -708,17 +716,13 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
                  dalloc(e, &e->d_stack_tab, (size_t)e->d.dec_layers) == 0;
             if (!ok) { (void)hipGetLastError(); fprintf(stderr, "vox_hip: fused decode kernels unavailable; launch-per-GEMV chain\n"); }
             e->use_fused = ok; e->fused_ok = ok;
-            e->use_ffn = ok && !getenv("VOX_HIP_NO_FFN_FUSED");        // A/B: k_gemv_w13x + k_gemv_w2x instead of k_ffn_fused
-            if (ok && getenv("VOX_HIP_FUSE_TRACE") && hipMalloc((void **)&e->d_fuse_trace, 64 * 8) == hipSuccess)
-                hipMemset(e->d_fuse_trace, 0, 64 * 8);
-            if (getenv("VOX_HIP_FUSE_WO_LATE")) e->wo_late = atoi(getenv("VOX_HIP_FUSE_WO_LATE"));
-            if (getenv("VOX_HIP_MERGE12")) e->merge12 = atoi(getenv("VOX_HIP_MERGE12"));
-            if (getenv("VOX_HIP_MERGE12_MAXKEYS")) e->merge12_maxkeys = atoi(getenv("VOX_HIP_MERGE12_MAXKEYS"));
-            if (getenv("VOX_HIP_MERGE12_LONG")) e->merge12_long = atoi(getenv("VOX_HIP_MERGE12_LONG"));
-            if (getenv("VOX_HIP_STACK")) e->use_stack = atoi(getenv("VOX_HIP_STACK"));
-            e->fp8_attn_bf16 = getenv("VOX_HIP_FP8_ATTN_BF16") != nullptr;
-            e->fp8_lmhead_bf16 = getenv("VOX_HIP_FP8_LMHEAD_BF16") != nullptr;
-            if (const char *pf = getenv("VOX_HIP_PF")) sscanf(pf, "%d,%d,%d", &e->pf_units, &e->pf_member_units, &e->pf_when);
+            e->use_ffn = ok && !vox_disabled("ffn_fused");             // k_gemv_w13x + k_gemv_w2x instead of k_ffn_fused
+            if (vox_disabled("merge12")) e->merge12 = 0;
+            if (vox_disabled("merge12_long")) e->merge12_long = 0;
+            if (vox_disabled("stack")) e->use_stack = 0;
+            e->fp8_attn_bf16 = vox_disabled("fp8_attn");
+            e->fp8_lmhead_bf16 = vox_disabled("fp8_lmhead");
+            e->enc_tl_on = getenv("VOX_HIP_ENC_TL") != nullptr;
             if (ok && getenv("VOX_HIP_FUSE_TL") && hipMalloc((void **)&e->d_fuse_tl, 3 * 1024 * TL_STRIDE * 8) == hipSuccess)
                 hipMemset(e->d_fuse_tl, 0, 3 * 1024 * TL_STRIDE * 8);
         }
@@ -956,11 +960,9 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
                 if (ensure(e, e->spart_ml, (size_t)n * c.heads * ks * 2 * 4)) return -1;
                 a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
             }
-            static const int attn_xcd = getenv("VOX_HIP_ATTN_NO_XCD") ? 0 : 1;
-            a.xcd_map = attn_xcd;
+            a.xcd_map = 1;
             if (e->use_attn_mfma && c.hd == 64 && c.heads == c.kv_heads)
-                if (e->use_attn_bf16) hipLaunchKernelGGL(k_attn_enc_bf16, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
-                else hipLaunchKernelGGL(k_attn_enc_mfma, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(k_attn_enc_bf16, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
             else
                 hipLaunchKernelGGL((k_attn_rows<64>), dim3(qt, c.heads, ks), dim3(128), 0, s, a);
             if (ks > 1)
@@ -1039,8 +1041,7 @@ static RowsCfg dec_cfg(const vox_hip_engine *e) {
 
 // Encoder transformer on device rows x[n, enc_dim] (in place), then final norm into out.
 // Encoder attention of a chunk: window tail in the ring + this chunk's K/V in the merged QKV buffer.
-static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float *attn, int n, int pos0, float *kring, float *vring, int ring_cap,
-                         const L2Pf *pf = nullptr) {
+static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float *attn, int n, int pos0, float *kring, float *vring, int ring_cap) {
     const int N3 = c.QD + 2 * c.KVD;
     hipStream_t s = e->stream;
     AttnArgs a{};
@@ -1054,20 +1055,10 @@ static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float 
         if (ensure(e, e->spart_o, (size_t)n * c.heads * ks * c.hd * 4)) return -1;
         if (ensure(e, e->spart_ml, (size_t)n * c.heads * ks * 2 * 4)) return -1;
         a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
-        static const int nw4 = getenv("VOX_HIP_ATTN_SMALL_4W") ? 1 : 0;        // A/B: the round-2 geometry (4 waves x 8 rows)
-        if (nw4) {
-            if (e->use_dpp) hipLaunchKernelGGL((k_attn_small<true, 4>), dim3(c.heads, ks), dim3(256), 0, s, a, lo);
-            else hipLaunchKernelGGL((k_attn_small<false, 4>), dim3(c.heads, ks), dim3(256), 0, s, a, lo);
-        } else {
-            if (e->use_dpp) hipLaunchKernelGGL((k_attn_small<true, 8>), dim3(c.heads, ks), dim3(512), 0, s, a, lo);
-            else hipLaunchKernelGGL((k_attn_small<false, 8>), dim3(c.heads, ks), dim3(512), 0, s, a, lo);
-        }
-        if (pf && pf->n_blocks > 0 && c.heads % 8 == 0)      // + rows of L2-prefetch workgroups for the GEMM launches that follow (vox_common.h)
-            hipLaunchKernelGGL((k_attn_combine<64>), dim3(c.heads, n + pf->n_blocks / c.heads), dim3(64), 0, s, attn, c.QD,
-                               (const float *)a.part_o, (const float *)a.part_ml, c.heads, ks, n, *pf);
-        else
-            hipLaunchKernelGGL((k_attn_combine<64>), dim3(c.heads, n), dim3(64), 0, s, attn, c.QD,
-                               (const float *)a.part_o, (const float *)a.part_ml, c.heads, ks);
+        if (e->use_dpp) hipLaunchKernelGGL((k_attn_small<true, 8>), dim3(c.heads, ks), dim3(512), 0, s, a, lo);
+        else hipLaunchKernelGGL((k_attn_small<false, 8>), dim3(c.heads, ks), dim3(512), 0, s, a, lo);
+        hipLaunchKernelGGL((k_attn_combine<64>), dim3(c.heads, n), dim3(64), 0, s, attn, c.QD,
+                           (const float *)a.part_o, (const float *)a.part_ml, c.heads, ks);
         return 0;
     }
     const int qt = (n + 127) / 128, blocks = qt * c.heads;
@@ -1079,11 +1070,9 @@ static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float 
         if (ensure(e, e->spart_ml, (size_t)n * c.heads * ks * 2 * 4)) return -1;
         a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
     }
-    static const int attn_xcd = getenv("VOX_HIP_ATTN_NO_XCD") ? 0 : 1;
-    a.xcd_map = attn_xcd;
+    a.xcd_map = 1;
     if (e->use_attn_mfma && c.hd == 64 && c.heads == c.kv_heads)
-        if (e->use_attn_bf16) hipLaunchKernelGGL(k_attn_enc_bf16, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(k_attn_enc_mfma, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_attn_enc_bf16, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((k_attn_rows<64>), dim3(qt, c.heads, ks), dim3(128), 0, s, a);
     if (ks > 1)
@@ -1111,43 +1100,22 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
     float *xn = (float *)e->sxn.p, *qkv = (float *)e->sqkv.p, *attn = (float *)e->sattn.p, *tab = (float *)e->srope.p;
     hipStream_t s = e->stream;
     const int so = skinny_split(c.QD), s2 = skinny_split(c.H);
-    // A/B (VOX_HIP_SK_W2_RG): w2 on k_rowsgemm - measured 9.1 vs 10.2 us for the launch, but its 20 K splits (10 here) cost
-    // k_rows_finish 7.4 instead of 5.9 us: no gain at 25 rows (gpurun_out/p12)
-    static const int sk_w2_rg = getenv("VOX_HIP_SK_W2_RG") ? 1 : 0;
-    const bool w2_rg = e->use_rowsgemm && sk_w2_rg;
-    if (ensure(e, e->ssplitk, std::max((size_t)std::max(so, s2) * n * c.D * 4, w2_rg ? rg_partial_bytes(n, c.D, c.H) : (size_t)0))) return -1;
+    // (measured and not kept: w2 on k_rowsgemm - 9.1 vs 10.2 us for the launch, but its 20 K splits cost k_rows_finish 7.4 instead of
+    //  5.9 us; an L2 prefetch of the next GEMM launch's weight tiles by workgroups appended to the latency-bound launches - the GEMM
+    //  launches get 0.0 - 0.6 us shorter, the carriers longer, 67.7 -> 69.9 us per layer: these launches are not waiting for HBM.
+    //  profiles/NOTES.md)
+    if (ensure(e, e->ssplitk, (size_t)std::max(so, s2) * n * c.D * 4)) return -1;
     // bf16 planes of the normalised rows [3][n][D] and of the gated hidden rows [3][n][H] (sgu is free on this path)
     if (ensure(e, e->sgu, (size_t)3 * n * (c.D + c.H) * 2)) return -1;
     uint16_t *xnp = (uint16_t *)e->sgu.p, *hp = xnp + (size_t)3 * n * c.D;
     float *part = (float *)e->ssplitk.p;
     const size_t lds1 = (size_t)SK_WPB * 4096, lds2 = (size_t)SK_WPB * 2 * 4096;
-    if (getenv("VOX_HIP_ENC_TL") && !e->d_enc_tl && hipMalloc((void **)&e->d_enc_tl, 4 * 1024 * TL_STRIDE * 8) == hipSuccess)
+    if (e->enc_tl_on && !e->d_enc_tl && hipMalloc((void **)&e->d_enc_tl, 4 * 1024 * TL_STRIDE * 8) == hipSuccess)
         hipMemset(e->d_enc_tl, 0, 4 * 1024 * TL_STRIDE * 8);
     auto tlp = [&](int l, int k) { return (e->d_enc_tl && l == L / 2) ? e->d_enc_tl + (size_t)k * 1024 * TL_STRIDE : nullptr; };
-    // L2 prefetch of the next GEMM launches' weight tiles by workgroups appended to the three latency-bound launches of a layer
-    // (vox_common.h, L2Pf).  VOX_HIP_ENC_PF="finish_blocks,combine_blocks,qkvKB,woKB,w1KB,w3KB,w2KB" (KB per XCD; 0 blocks = off).
-    // OFF by default - measured (gpurun_out/r4g): with every GEMM launch's tiles in its XCD's L2 the four GEMM
-    // launches of a 25-row layer get 0.0 - 0.6 us shorter each (13.0 -> 12.4, 10.8 -> 10.8, 9.5 -> 9.2, 4.5 -> 4.4 us) while the
-    // launches carrying the prefetch get longer: 67.7 -> 69.9 us per layer.  These launches are not waiting for HBM.
-    static int pfc[7] = {-1, 0, 0, 0, 0, 0, 0};
-    if (pfc[0] < 0) {
-        int v[7] = {0, 0, 4096, 4096, 4096, 4096, 4096};
-        if (const char *t = getenv("VOX_HIP_ENC_PF")) sscanf(t, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]);
-        v[0] &= ~7; v[1] = (v[1] / c.heads) * c.heads;
-        for (int i = 6; i >= 0; i--) pfc[i] = v[i];
-    }
-    const bool pf_ok = c.heads % 8 == 0 && (N3 / 32) % 8 == 0 && (c.H / 32) % 8 == 0 && (c.D / 32) % 8 == 0;
-    auto pf_job = [&](const uint16_t *W, int N, int K, int kb) {
-        return L2PfJob{reinterpret_cast<const unsigned char *>(W), 32 * K * 2, N / 32, kb};      // 1 KiB units per XCD = KB
-    };
-    auto pf_qkv = [&](int l) {        // attached to the launch in front of layer l's qkv GEMM
-        L2Pf p{};
-        if (pf_ok && pfc[0] > 0 && pfc[2] > 0 && l < L) { p.n_blocks = pfc[0]; p.job[0] = pf_job(e->enc[l].wqkv, N3, c.D, pfc[2]); }
-        return p;
-    };
     if (L > 0)      // attention_norm of layer 0 (no partials, no bias: x is left as it is)
-        hipLaunchKernelGGL(k_rows_finish, dim3(n + pf_qkv(0).n_blocks), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)nullptr, 0, n, c.D, (const float *)nullptr,
-                           (const float *)e->enc[0].n1, c.eps, xn, c.D, xnp, (const float *)nullptr, pf_qkv(0));
+        hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)nullptr, 0, n, c.D, (const float *)nullptr,
+                           (const float *)e->enc[0].n1, c.eps, xn, c.D, xnp, (const float *)nullptr);
     for (int l = 0; l < L; l++) {
         EncLayer &Ly = e->enc[l];
         {   // attention_norm(x) . [wq; wk; wv]^T + bias, RoPE, K/V into the merged buffer and the rings
@@ -1157,25 +1125,13 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
             a.ring_cap = e->enc_ring_cap; a.kv_dim = c.KVD; a.pos0 = pos0; a.q_cols = c.QD; a.tl = tlp(l, 0);
             hipLaunchKernelGGL((k_skinny<SK_QKV, 1, true>), dim3(N3 / 32, 1), dim3(64 * SK_WPB), lds1, s, a);
         }
-        L2Pf pfa{}, pfb{};      // under the partial merge: wo and the gate rows; under the first finish: the up rows and w2
-        if (pf_ok && pfc[1] > 0) {
-            pfa.n_blocks = pfc[1];
-            if (pfc[3] > 0) pfa.job[0] = pf_job(Ly.wo, c.D, c.QD, pfc[3]);
-            if (pfc[4] > 0) pfa.job[1] = pf_job(Ly.w13, c.H, c.D, pfc[4]);
-        }
-        if (pf_ok && pfc[0] > 0) {
-            pfb.n_blocks = pfc[0];
-            if (pfc[5] > 0) pfb.job[0] = pf_job(Ly.w13 + (size_t)c.H * c.D, c.H, c.D, pfc[5]);
-            if (pfc[6] > 0) pfb.job[1] = pf_job(Ly.w2, c.D, c.H, pfc[6]);
-            if (!pfb.job[0].base && !pfb.job[1].base) pfb.n_blocks = 0;
-        }
-        if (enc_attention(e, c, qkv, attn, n, pos0, Ly.kring, Ly.vring, e->enc_ring_cap, &pfa)) return -1;
+        if (enc_attention(e, c, qkv, attn, n, pos0, Ly.kring, Ly.vring, e->enc_ring_cap)) return -1;
         {   // wo as K-split partials, then x += . + bo and ffn_norm in one launch
             SkinnyArgs a{};
             a.X = attn; a.ldx = c.QD; a.n = n; a.W = Ly.wo; a.N = c.D; a.K = c.QD; a.partial = part; a.tl = tlp(l, 1);
             hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, false>), dim3(c.D / 32, so), dim3(64 * SK_WPB), lds1, s, a);
-            hipLaunchKernelGGL(k_rows_finish, dim3(n + pfb.n_blocks), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, so, n, c.D, (const float *)Ly.bo,
-                               (const float *)Ly.n2, c.eps, xn, c.D, xnp, (const float *)nullptr, pfb);
+            hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, so, n, c.D, (const float *)Ly.bo,
+                               (const float *)Ly.n2, c.eps, xn, c.D, xnp, (const float *)nullptr);
         }
         {   // silu(xn w1^T) * (xn w3^T), written as bf16 planes for the w2 launch
             SkinnyArgs a{};
@@ -1184,19 +1140,13 @@ static int encoder_rows_skinny(vox_hip_engine *e, float *x, int n, float *out) {
             hipLaunchKernelGGL((k_skinny<SK_SWIGLU, 1, true>), dim3(c.H / 32, 1), dim3(64 * SK_WPB), lds2, s, a);
         }
         {   // w2 partials, then x += . + b2 and the next norm (next layer's attention_norm, or the final norm into `out`)
-            int s2n = s2;
-            if (w2_rg) {
-                s2n = launch_rowsgemm(e, hp, (size_t)n * c.H, nullptr, 0, n, Ly.w2, c.D, c.H, part);
-            } else {
-                SkinnyArgs a{};
-                a.Xp = hp; a.xp_plane = (size_t)n * c.H; a.n = n; a.W = Ly.w2; a.N = c.D; a.K = c.H; a.partial = part; a.tl = tlp(l, 3);
-                hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, true>), dim3(c.D / 32, s2), dim3(64 * SK_WPB), lds1, s, a);
-            }
+            SkinnyArgs a{};
+            a.Xp = hp; a.xp_plane = (size_t)n * c.H; a.n = n; a.W = Ly.w2; a.N = c.D; a.K = c.H; a.partial = part; a.tl = tlp(l, 3);
+            hipLaunchKernelGGL((k_skinny<SK_PARTIAL, 1, true>), dim3(c.D / 32, s2), dim3(64 * SK_WPB), lds1, s, a);
             const bool last = l + 1 == L;
-            const L2Pf pfn = pf_qkv(l + 1);
-            hipLaunchKernelGGL(k_rows_finish, dim3(n + pfn.n_blocks), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, s2n, n, c.D, (const float *)Ly.b2,
+            hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, s2, n, c.D, (const float *)Ly.b2,
                                (const float *)(last ? e->enc_final_norm : e->enc[l + 1].n1), c.eps, last ? out : xn, c.D,
-                               last ? (uint16_t *)nullptr : xnp, (const float *)nullptr, pfn);
+                               last ? (uint16_t *)nullptr : xnp, (const float *)nullptr);
         }
     }
     if (L == 0)
@@ -1216,22 +1166,17 @@ static RgPlan rg_plan(int n, int N, int K, bool f32x = false) {
     const int mt = (n + 31) / 32, nchunks = K / 64;
     p.wpb = N >= 2048 ? 8 : 4;
     // two weight tiles per wave (every activation fragment read from LDS feeds two MFMAs) for the wide GEMMs of <= 64 rows
-    static const int force_nb = getenv("VOX_HIP_RG_NB") ? atoi(getenv("VOX_HIP_RG_NB")) : 0;
     p.ntile = (mt <= 2 && N >= 4096) ? 2 : 1;
-    if (force_nb == 1 || (force_nb == 2 && mt <= 2 && N >= 512)) p.ntile = force_nb;
     p.nb = (N + 32 * p.ntile * p.wpb - 1) / (32 * p.ntile * p.wpb);
     // chunks per round: two LDS stages of 3 planes x 32 mt rows x cpw x 128 B must fit (mt * cpw <= 6: 144 KB)
-    static const int force_cpw = getenv("VOX_HIP_RG_CPW") ? atoi(getenv("VOX_HIP_RG_CPW")) : 0;
     p.cpw = mt <= 3 ? 2 : 1;
-    if ((force_cpw == 1 || force_cpw == 2) && force_cpw * mt <= 6) p.cpw = force_cpw;
     // register budget of the 512-thread variants (256 VGPRs): two weight register sets of NB x cpw x 4 fragments + 16 NB mt
     // accumulators (+ the f32 rows of the next round) - one chunk per round where two would spill
     if (p.wpb == 8 && (p.ntile == 2 || f32x || n > 64)) p.cpw = 1;
     p.lds = (size_t)2 * 3 * 32 * mt * p.cpw * 128;
     // one workgroup per CU (the stages take up to 144 KB of its LDS): as many K splits as fill the chip without a second wave
     // of workgroups - 288 workgroups on 256 CUs ran 75 us where 216 ran 54 (gpurun_out/p6)
-    static const int target = getenv("VOX_HIP_RG_WGS") ? atoi(getenv("VOX_HIP_RG_WGS")) : 256;      // tuning: workgroups per launch
-    const int S = std::max(1, std::min(nchunks, target / p.nb));
+    const int S = std::max(1, std::min(nchunks, 256 / p.nb));
     int cw = (nchunks + S - 1) / S;
     cw = ((cw + p.cpw - 1) / p.cpw) * p.cpw;
     p.cw = cw; p.S = (nchunks + cw - 1) / cw;
@@ -1361,7 +1306,7 @@ static int encoder_rows_dev(vox_hip_engine *e, float *x, int n, float *out) {
     if (ensure_rows_scratch(e, n, c)) return -1;
     hipLaunchKernelGGL(k_rope_table, dim3(grid1d((size_t)n * c.hd / 2)), dim3(256), 0, e->stream,
                        (float *)e->srope.p, e->enc_inv_freq, e->enc_pos, n, c.hd / 2);
-    if (rowsgemm_ok(e, n, c) && (n > 32 || e->rg_small || !skinny_ok(e, n, c))) {
+    if (rowsgemm_ok(e, n, c) && (n > 32 || !skinny_ok(e, n, c))) {
         if (rows_mid_layers(e, x, n, e->enc_pos, c, true, out)) return -1;
         e->enc_pos += n;
         return 0;
@@ -1384,10 +1329,9 @@ static int encoder_rows_dev(vox_hip_engine *e, float *x, int n, float *out) {
 // <= 32 rows go through k_rowsgemm (f32 rows split in the kernel) + the same fixed-order reduce with the fused epilogue.
 static int gemm_small_rows(vox_hip_engine *e, const float *X, int ldx, const uint16_t *W, float *Y, int ldy, int M, int N, int K,
                            const float *bias, int act) {
-    static const bool off = getenv("VOX_HIP_NO_RG_SMALLGEMM") != nullptr;       // A/B
     // (<= 32 rows only: conv1 13.9 -> 10.7 us, adapter0 19.6 -> 14.9 us at 25 / 6 rows; at the flush pass's 34 - 68 rows the whole
     // encode got 0.14 ms SLOWER on the 2-layer model - gpurun_out/p14 - so those stay on the 128 x 128 tiles)
-    if (!off && e->use_rowsgemm && e->use_mfma && M >= 1 && M <= 32 && K % 64 == 0 && ldx % 4 == 0) {
+    if (e->use_rowsgemm && e->use_mfma && M >= 1 && M <= 32 && K % 64 == 0 && ldx % 4 == 0) {
         if (ensure(e, e->ssplitk, rg_partial_bytes(M, N, K))) return -1;
         const int S = launch_rowsgemm(e, nullptr, 0, X, ldx, M, W, N, K, (float *)e->ssplitk.p);
         GemmArgs a{nullptr, 0, W, Y, ldy, M, N, K, bias, nullptr, 0, act, S, 0, (float *)e->ssplitk.p};
@@ -1860,20 +1804,10 @@ extern "C" int vox_hip_decoder_prefill(vox_hip_engine_t *e, const float *embeds,
 // bound, so they get small slices (64 keys = one 16-key trip per wave); long contexts get
 // bigger ones so that the number of partials stays <= 64.
 static int dec_split_keys(int kv_len) {
-    static const int forced = getenv("VOX_HIP_SPLIT_KEYS") ? atoi(getenv("VOX_HIP_SPLIT_KEYS")) : 0;   // tuning only
-    if (forced >= 64 && kv_len > 512) return forced;
     if (kv_len <= 512) return 64;
     if (kv_len <= 3072) return 128;        // measured: 2500 keys 1.875 ms (128) vs 1.915 ms (256), 4000 keys 1.987 vs 1.979
     if (kv_len <= 8192) return 256;
     return 512;
-}
-
-template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW>
-static void launch_gemv2(vox_hip_engine *e, const GemvArgs &a) {
-    const int rows_per_block = (4 / KS) * RPW;
-    const int grid = (a.N + rows_per_block - 1) / rows_per_block;
-    const size_t lds = ((size_t)a.K + 512) * sizeof(float);
-    hipLaunchKernelGGL((k_gemv2<PRO, EPI, RPW, CPL, KS, MINW>), dim3(grid), dim3(256), lds, e->stream, a);
 }
 
 template <int PRO, int EPI, int RPW, int CPL, int KS, int MINW, bool W8 = false>
@@ -1893,7 +1827,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     const int DD = d.dec_dim, DQ = e->dec_qd, DKV = e->dec_kvd, DH = d.dec_hidden, HD = d.dec_head_dim;
     hipStream_t s = e->stream;
     // production kernels are specialised for the 4B shapes; anything else takes the generic ones
-    const bool fast = e->use_gemv2 && DD == 3072 && DQ == 4096 && DKV == 1024 && DH == 9216;
+    const bool fast = e->use_fast && DD == 3072 && DQ == 4096 && DKV == 1024 && DH == 9216;
     if (!fast) {
         hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(256), 0, s, (const DecState *)e->d_st, (const float *)e->dec_inv_freq,
                            HD / 2, e->dec_rope, e->dx, (const float *)e->adapter, (const uint16_t *)e->tok_emb, DD, build_embed ? 1 : 0);
@@ -1923,15 +1857,14 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
         if (tap_i < 0) return;
         hipMemcpyAsync(e->d_taps + ((size_t)tap_i * (2 * d.dec_layers + 1) + slot) * DD, src, (size_t)DD * 4, hipMemcpyDeviceToDevice, s);
     };
-    static const int tl_layer = getenv("VOX_HIP_FUSE_TL_LAYER") ? atoi(getenv("VOX_HIP_FUSE_TL_LAYER")) : 13;
+    const int tl_layer = 13;          // VOX_HIP_FUSE_TL: the mid-stack layer whose blocks are stamped
     // the 12-wave shape (k_attn12 / k_ffn_attn12): <= 8 key slices (up to merge12_maxkeys keys), 9 .. 32 in its LONG form (round 5); bf16, DPP, no debug hooks
-    static const int spread_env0 = getenv("VOX_HIP_FUSE_SPREAD") ? atoi(getenv("VOX_HIP_FUSE_SPREAD")) : -1;
     const bool long12 = f_ns > 8;
-    const bool shape12 = fused && e->merge12 > 0 && e->use_ffn && !e->use_fp8 && !e->sim_on && (f_ns <= 8 || e->merge12_long) && spread_env0 <= 0 && (e->skip_kinds & ~(1u << PK_W2)) == 0 &&
-                         tap_i < 0 && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0)) && !getenv("VOX_HIP_FUSE_ATTN_PER_HEAD");
+    const bool shape12 = fused && e->merge12 > 0 && e->use_ffn && !e->use_fp8 && !e->sim_on && (f_ns <= 8 || e->merge12_long) && (e->skip_kinds & ~(1u << PK_W2)) == 0 &&
+                         tap_i < 0 && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0));
     // fp8 mode: the W2 launch of layer l and the (fp8) attention block of layer l + 1 as one launch, same regime
-    const bool shape12_f8 = fused && e->merge12 == 2 && e->use_fp8 && !e->fp8_attn_bf16 && !e->sim_on && f_ns <= 8 && spread_env0 <= 0 && (e->skip_kinds & ~(1u << PK_SWIGLU)) == 0 &&
-                            tap_i < 0 && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0)) && !getenv("VOX_HIP_FUSE_ATTN_PER_HEAD") && !getenv("VOX_HIP_OLD_W2");
+    const bool shape12_f8 = fused && e->merge12 == 2 && e->use_fp8 && !e->fp8_attn_bf16 && !e->sim_on && f_ns <= 8 && (e->skip_kinds & ~(1u << PK_SWIGLU)) == 0 &&
+                            tap_i < 0 && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0));
     bool attn_done = false;           // this layer's attention block ran at the end of the previous layer's launch (k_ffn_attn12)
     // k_dec_stack: every block of the step's layers in ONE launch - with the embedding gather (embed = 1: attention(0) included) or behind
     // layer 0's own attention launch (embed = 0: the first step after a prefill, whose x is in memory)
@@ -1983,24 +1916,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 if (++e->fuse_epoch == 0) e->fuse_epoch = 1;
                 a.epoch = e->fuse_epoch; a.split_keys = f_split; a.nsplit = f_ns;
                 a.err = e->d_fuse_err; a.spin_limit = 500000ull;         // 5 ms at the 100 MHz wall clock (a hand-off takes microseconds)
-                a.trace = (l == 13) ? e->d_fuse_trace : nullptr;          // tuning: phase stamps of one mid-stack launch
                 a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl : nullptr;
-                // Group members on all XCDs (group = blockIdx / 32) instead of one XCD per group (blockIdx % 8): the hand-offs then
-                // cross XCDs (+0.3 us each, timeline), but a group's K/V tiles and Wo rows come through all eight L2s - measured on
-                // one box, alternating runs: 232 keys 1.382 -> 1.392 ms per step, 600: 1.485 -> 1.478, 1900: 1.593 -> 1.562,
-                // 3800: 1.724 -> 1.679, 8000: 1.896 -> 1.860.  So: spread beyond 8 key slices (KV > 512).
-                // VOX_HIP_FUSE_SPREAD=1 / =0 forces it on / off.
-                static const int spread_env = getenv("VOX_HIP_FUSE_SPREAD") ? atoi(getenv("VOX_HIP_FUSE_SPREAD")) : -1;
-                a.spread_groups = spread_env >= 0 ? (spread_env != 0) : (f_ns > 8);
-                static const int serial_wo = getenv("VOX_HIP_FUSE_SERIAL_WO") ? 1 : 0;
-                a.wo_serial_reduce = serial_wo;
-                static const int merge3 = getenv("VOX_HIP_FUSE_MERGE3") ? 1 : 0;
-                // (one shared trip pays while a member's slice is one 64-key tile - 1.576 vs 1.589 ms per step at 1900 keys; with
-                // two tiles per member the members finish further apart, the early loads miss and are repeated: 1.731 vs 1.710 at 3800)
-                a.merge_three_trips = merge3 || f_split > 64;
-                static const int attn_old = getenv("VOX_HIP_FUSE_ATTN_PER_HEAD") ? 1 : 0;
-                a.attn_gqa = !attn_old;
-                a.wo_late = e->wo_late;
                 if (e->pf_units > 0) {        // the next launch's (k_gemv_w13x) first bytes, see DfPrefetch
                     a.pf.w = e->use_fp8 ? reinterpret_cast<const unsigned char *>(L.w138) : reinterpret_cast<const unsigned char *>(L.w13);
                     a.pf.row_bytes = e->use_fp8 ? DD : 2 * DD; a.pf.rows_m = DH;
@@ -2058,7 +1974,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                     b.gq = e->d_gq; b.gp = e->d_gp; b.wo_part = e->d_wo_part;
                     if (++e->fuse_epoch == 0) e->fuse_epoch = 1;
                     b.epoch = e->fuse_epoch; b.split_keys = f_split; b.nsplit = f_ns;
-                    b.err = e->d_fuse_err; b.spin_limit = 500000ull; b.attn_gqa = 1;
+                    b.err = e->d_fuse_err; b.spin_limit = 500000ull;
                     b.tl = (l + 1 == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl : nullptr;
                     if (e->pf_units > 0) {
                         b.pf.w = reinterpret_cast<const unsigned char *>(N.w13); b.pf.row_bytes = 2 * DD; b.pf.rows_m = DH;
@@ -2081,7 +1997,6 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                 W13xArgs a{};
                 a.w1 = e->sim_on ? L.w13_s : L.w13; a.w3 = a.w1 + (size_t)DH * DD; a.x = xin; a.wo_part = e->d_wo_part; a.norm_w = L.n2; a.ada = L.ada;
                 a.eps = d.dec_eps; a.x_out = xalt; a.h = e->dh;
-                a.trace = (l == 13) ? e->d_fuse_trace : nullptr;
                 a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + TL_STRIDE * 1024 : nullptr;
                 if (e->use_fp8) {
                     a.w1 = reinterpret_cast<const uint16_t *>(L.w138); a.w3 = reinterpret_cast<const uint16_t *>(L.w138 + (size_t)DH * DD);
@@ -2094,13 +2009,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             }
             tap(2 * l + 1, xalt);         // x' = x + attention block, written by k_gemv_w13x's block 0
             if (!(e->skip_kinds & (1u << PK_W2))) {
-                static const int old_w2 = getenv("VOX_HIP_OLD_W2") ? 1 : 0;         // A/B switch: the k_gemv3 launch this replaced
-                if (old_w2) {
-                    GemvArgs a{};
-                    a.W = L.w2; a.x = e->dh; a.y = xalt; a.N = DD; a.K = DH;        // x' += h . W2^T, in place
-                    a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + 2 * TL_STRIDE * 1024 : nullptr;
-                    launch_gemv3<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
-                } else {
+                {
                     W2xArgs a{};
                     a.w2 = e->sim_on ? L.w2_s : L.w2; a.h = e->dh; a.x = xalt;        // x' += h . W2^T, in place (one wave per row)
                     a.tl = (l == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl + 2 * TL_STRIDE * 1024 : nullptr;
@@ -2115,7 +2024,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                         const unsigned x_epoch = e->fuse_epoch;
                         if (++e->fuse_epoch == 0) e->fuse_epoch = 1;
                         b.epoch = e->fuse_epoch; b.split_keys = f_split; b.nsplit = f_ns;
-                        b.err = e->d_fuse_err; b.spin_limit = 500000ull; b.attn_gqa = 1;
+                        b.err = e->d_fuse_err; b.spin_limit = 500000ull;
                         b.tl = (l + 1 == tl_layer && e->d_fuse_tl) ? e->d_fuse_tl : nullptr;
                         if (e->pf_units > 0) {
                             b.pf.w = reinterpret_cast<const unsigned char *>(N.w138); b.pf.row_bytes = DD; b.pf.rows_m = DH;
@@ -2148,10 +2057,8 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             if (!fast) launch_gemv<PRO_RMS, EPI_QKV, 4>(e, a);
             else if (f8 && l == 0 && build_embed) launch_gemv3<PRO_EMBED_RMS, EPI_QKV, 2, 3, 1, 3, true>(e, a);
             else if (f8) launch_gemv3<PRO_RMS, EPI_QKV, 2, 3, 1, 3, true>(e, a);
-            else if (e->use_gemv3 && l == 0 && build_embed) launch_gemv3<PRO_EMBED_RMS, EPI_QKV, 2, 6, 1, 3>(e, a);
-            else if (e->use_gemv3) launch_gemv3<PRO_RMS, EPI_QKV, 2, 6, 1, 3>(e, a);
-            else if (l == 0 && build_embed) launch_gemv2<PRO_EMBED_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
-            else launch_gemv2<PRO_RMS, EPI_QKV, 6, 6, 1, 1>(e, a);
+            else if (l == 0 && build_embed) launch_gemv3<PRO_EMBED_RMS, EPI_QKV, 2, 6, 1, 3>(e, a);
+            else launch_gemv3<PRO_RMS, EPI_QKV, 2, 6, 1, 3>(e, a);
             prof_mark(e, PK_QKV);
         }
         tap(2 * l, e->dx);
@@ -2186,10 +2093,8 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             if (!fast) launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
             else if (f8 && fuse_combine) launch_gemv3<PRO_ATTN, EPI_RESID, 3, 4, 1, 1, true>(e, a);
             else if (f8) launch_gemv3<PRO_NONE, EPI_RESID, 3, 4, 1, 1, true>(e, a);
-            else if (e->use_gemv3 && fuse_combine) launch_gemv3<PRO_ATTN, EPI_RESID, 3, 8, 1, 1>(e, a);
-            else if (e->use_gemv3) launch_gemv3<PRO_NONE, EPI_RESID, 3, 8, 1, 1>(e, a);
-            else if (fuse_combine) launch_gemv2<PRO_ATTN, EPI_RESID, 3, 8, 1, 1>(e, a);
-            else launch_gemv2<PRO_NONE, EPI_RESID, 3, 8, 1, 1>(e, a);
+            else if (fuse_combine) launch_gemv3<PRO_ATTN, EPI_RESID, 3, 8, 1, 1>(e, a);
+            else launch_gemv3<PRO_NONE, EPI_RESID, 3, 8, 1, 1>(e, a);
             prof_mark(e, PK_WO);
         }
         tap(2 * l + 1, e->dx);
@@ -2205,8 +2110,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             }
             if (!fast) launch_gemv<PRO_RMS, EPI_SWIGLU, 2>(e, a);
             else if (f8) launch_gemv3<PRO_RMS, EPI_SWIGLU, 3, 3, 1, 3, true>(e, a);
-            else if (e->use_gemv3) launch_gemv3<PRO_RMS, EPI_SWIGLU, 3, 6, 1, 3>(e, a);
-            else launch_gemv2<PRO_RMS, EPI_SWIGLU, 3, 6, 1, 3>(e, a);
+            else launch_gemv3<PRO_RMS, EPI_SWIGLU, 3, 6, 1, 3>(e, a);
             prof_mark(e, PK_SWIGLU);
         }
         if (!(e->skip_kinds & (1u << PK_W2)))
@@ -2217,8 +2121,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
             if (f8) { a.W = reinterpret_cast<const uint16_t *>(L.w28); a.wscale = L.s2; }
             if (!fast) launch_gemv<PRO_NONE, EPI_RESID, 2>(e, a);
             else if (f8) launch_gemv3<PRO_NONE, EPI_RESID, 1, 9, 1, 3, true>(e, a);
-            else if (e->use_gemv3) launch_gemv3<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
-            else launch_gemv2<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
+            else launch_gemv3<PRO_NONE, EPI_RESID, 3, 9, 2, 2>(e, a);
             prof_mark(e, PK_W2);
         }
     }
@@ -2264,7 +2167,7 @@ static int fused_failed(vox_hip_engine *e) {
     if (hipMemcpy(&err, e->d_fuse_err, sizeof err, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
     if (!err) return 0;
     e->use_fused = false; e->fuse_failures++;
-    static const bool no_rearm = getenv("VOX_HIP_FUSE_NO_REARM") != nullptr;
+    static const bool no_rearm = vox_disabled("rearm");
     e->fuse_rearm = no_rearm ? 0 : FUSE_REARM_STEPS << std::min(e->fuse_failures - 1, 6);
     fprintf(stderr, "vox_hip: ERROR fused decode kernel timed out in hand-off %u (its 256 workgroups were not co-resident?); "
                     "repeating the work on the launch-per-GEMV chain%s\n", err,
@@ -2538,8 +2441,7 @@ extern "C" int vox_hip_causal_attention(vox_hip_engine_t *e, float *out, const f
     float *po = nullptr, *pml = nullptr;
     int rc = 0;
     if (head_dim == 64 && e->use_attn_mfma && n_heads == n_kv_heads) {
-        if (e->use_attn_bf16) hipLaunchKernelGGL(k_attn_enc_bf16, dim3((seq_q + 127) / 128, n_heads), dim3(256), 0, e->stream, a);
-        else hipLaunchKernelGGL(k_attn_enc_mfma, dim3((seq_q + 127) / 128, n_heads), dim3(256), 0, e->stream, a);
+        hipLaunchKernelGGL(k_attn_enc_bf16, dim3((seq_q + 127) / 128, n_heads), dim3(256), 0, e->stream, a);
     } else if (head_dim == 64 && n_heads == n_kv_heads) {
         hipLaunchKernelGGL((k_attn_rows<64>), dim3((seq_q + 127) / 128, n_heads), dim3(128), 0, e->stream, a);
     } else if (head_dim == 128 && n_heads == 4 * n_kv_heads) {
@@ -2586,30 +2488,7 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
         hipMemsetAsync(e->adapter, 0, (size_t)e->d.dec_dim * 4, e->stream);
     }
     if (set_state(e, pos, 1, 0)) return -1.0;
-    if (getenv("VOX_HIP_GRAPH_TIMING")) {
-        // experiment: the same step captured once into a hipGraph and replayed (no host launch cost).  Only the
-        // launch-per-GEMV chain can be replayed: the fused kernel's hand-off epoch is a launch argument, a replay would
-        // find the previous replay's granules already tagged and read stale data.
-        const bool was_fused = e->use_fused;
-        e->use_fused = false;
-        struct Restore { vox_hip_engine *e; bool f; ~Restore() { e->use_fused = f; } } restore{e, was_fused};
-        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-        for (int i = 0; i < 3; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);
-        esync(e);
-        bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-        if (ok) {
-            enqueue_step(e, pos, true, e->dlogits, -1, 0);
-            ok = hipStreamEndCapture(e->stream, &g) == hipSuccess && g &&
-                 hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
-        }
-        if (!ok) { (void)hipGetLastError(); return -1.0; }
-        for (int i = 0; i < 3; i++) hipGraphLaunch(ge, e->stream);
-        hipEventRecord(e->ev0, e->stream);
-        for (int i = 0; i < iters; i++) hipGraphLaunch(ge, e->stream);
-        hipEventRecord(e->ev1, e->stream);
-        esync(e);
-        hipGraphExecDestroy(ge); hipGraphDestroy(g);
-    } else {
+    {
         for (int i = 0; i < 3; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);   // warm-up
         hipEventRecord(e->ev0, e->stream);
         for (int i = 0; i < iters; i++) enqueue_step(e, pos, true, e->dlogits, -1, 0);
@@ -2619,18 +2498,6 @@ extern "C" double vox_hip_time_decoder_step(vox_hip_engine_t *e, int iters, int 
     float ms = 0.f;
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
     e->dec_pos = saved_pos;
-    if (e->d_fuse_trace) {      // VOX_HIP_FUSE_TRACE: phase stamps (100 MHz wall clock) of the last layer-13 launch, blocks 0 and 255
-        unsigned long long h[64];
-        if (hipMemcpy(h, e->d_fuse_trace, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
-            for (int b = 0; b < 2; b++) {
-                fprintf(stderr, "fuse trace block %d (us since start):", b ? 255 : 0);
-                for (int k = 1; k <= 10; k++) fprintf(stderr, " %d:%.2f", k, (double)(h[b * 16 + k] - h[b * 16]) / 100.0);
-                fprintf(stderr, "\n  w13x block %d: kernel start %.2f us after the fused kernel's start;", b ? 255 : 0,
-                        (double)(h[32 + b * 16] - h[b * 16]) / 100.0);
-                for (int k = 1; k <= 4; k++) fprintf(stderr, " %d:%.2f", k, (double)(h[32 + b * 16 + k] - h[32 + b * 16]) / 100.0);
-                fprintf(stderr, "\n");
-            }
-    }
     if (e->d_fuse_tl && getenv("VOX_HIP_FUSE_TL")) {      // per-workgroup timeline of the last step's layer-13 launches -> text file
         std::vector<unsigned long long> h((size_t)3 * 1024 * TL_STRIDE);
         FILE *f = fopen(getenv("VOX_HIP_FUSE_TL"), "w");
@@ -2760,7 +2627,7 @@ extern "C" int vox_hip_time_decoder_step_without(vox_hip_engine_t *e, int iters,
 
 static bool merged_static_ok(const vox_hip_engine *e) {
     const vox_hip_dims_t &d = e->d;
-    const bool fast = e->use_gemv2 && d.dec_dim == 3072 && e->dec_qd == 4096 && e->dec_kvd == 1024 && d.dec_hidden == 9216;
+    const bool fast = e->use_fast && d.dec_dim == 3072 && e->dec_qd == 4096 && e->dec_kvd == 1024 && d.dec_hidden == 9216;
     return fast && e->use_fused && e->use_dpp && e->merge12 == 2 && e->use_ffn && !e->use_fp8 && !e->sim_on && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0));
 }
 extern "C" int vox_hip_merged_launches_per_step(const vox_hip_engine_t *e, int kv_len) {
@@ -2939,7 +2806,7 @@ static int self_test(vox_hip_engine *e) {
     int failed = 0;
     if (!ok) { fprintf(stderr, "vox_hip: DPP row reduction self-test FAILED\n"); e->use_dpp = false; failed++; }
     hipFree(d_a); hipFree(d_b);
-    if (getenv("VOX_HIP_NO_DPP")) e->use_dpp = false;
+    if (vox_disabled("dpp")) e->use_dpp = false;
 
     // (2) MFMA GEMMs (bf16x3 and f32-input) vs the scalar kernel on an asymmetric 160 x 192 x 128 problem
     const int M = 160, N = 192, K = 128;
@@ -2978,10 +2845,8 @@ static int self_test(vox_hip_engine *e) {
         fprintf(stderr, "vox_hip: f32-input MFMA GEMM self-test FAILED (max diff %g)\n", maxd);
         e->use_mfma = false; failed++;
     }
-    if (getenv("VOX_HIP_NO_BF16X3")) e->use_bf16x3 = false;
+    if (vox_disabled("bf16x3")) e->use_bf16x3 = false;
     {   // (2b) the planes GEMM (pre-split activations, LDS-DMA pipeline) on the same problem, with and without split-K
-        if (getenv("VOX_HIP_GP_TN")) e->gp_tn = atoi(getenv("VOX_HIP_GP_TN")) == 4 ? 4 : 2;
-        if (getenv("VOX_HIP_GP_BDIRECT")) e->gp_bd = true;
         bool okp = hipFuncSetAttribute((const void *)k_gemm_planes<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(2)) == hipSuccess &&
                    hipFuncSetAttribute((const void *)k_gemm_planes<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(4)) == hipSuccess &&
                    hipFuncSetAttribute((const void *)k_gemm_planes<2, 2, GP_EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(2)) == hipSuccess &&
@@ -3005,10 +2870,10 @@ static int self_test(vox_hip_engine *e) {
         }
         if (dp) hipFree(dp);
         if (!okp) { (void)hipGetLastError(); e->use_planes = false; failed++; }
-        if (getenv("VOX_HIP_NO_PLANES")) e->use_planes = false;
-        if (getenv("VOX_HIP_GP_NO_EPI")) e->use_epi = false;                 // A/B: separate RoPE / SiLU launches
-        if (getenv("VOX_HIP_NO_ATTN_SMALL")) e->use_attn_small = false;
-        if (getenv("VOX_HIP_NO_STAGED_UPLOAD")) e->use_staged_upload = false;
+        if (vox_disabled("planes")) e->use_planes = false;
+        if (vox_disabled("epi")) e->use_epi = false;                         // separate RoPE / SiLU launches
+        if (vox_disabled("attn_small")) e->use_attn_small = false;
+        if (vox_disabled("staged_upload")) e->use_staged_upload = false;
     }
 
     // (3) MFMA encoder attention vs the thread-per-query kernel: 200 queries, 2 heads, window 90
@@ -3030,38 +2895,26 @@ static int self_test(vox_hip_engine *e) {
         a.ldo = ld; a.q = dq; a.ldq = ld; a.n_q = nq; a.qpos0 = 0; a.kB = dk; a.vB = dv; a.ldB = ld; a.posB0 = 0;
         a.last_key = nq - 1; a.kA = dk; a.vA = dv; a.capA = 1 << 30; a.ldA = ld; a.n_heads = nh; a.n_kv_heads = nh;
         a.scale = 0.125f; a.window = win; a.st = nullptr;
-        a.out = do1;
-        hipLaunchKernelGGL(k_attn_enc_mfma, dim3((nq + 127) / 128, nh), dim3(256), 0, e->stream, a);
         a.out = do2;
         hipLaunchKernelGGL((k_attn_rows<64>), dim3((nq + 127) / 128, nh), dim3(128), 0, e->stream, a);
+        a.out = do1;
+        hipLaunchKernelGGL(k_attn_enc_bf16, dim3((nq + 127) / 128, nh), dim3(256), 0, e->stream, a);
         HC(esync(e));
         HC(hipMemcpy(r1.data(), do1, r1.size() * 4, hipMemcpyDeviceToHost));
         HC(hipMemcpy(r2.data(), do2, r2.size() * 4, hipMemcpyDeviceToHost));
         double md = 0;
         for (size_t i = 0; i < r1.size(); i++) md = std::max(md, (double)fabsf(r1[i] - r2[i]));
         if (!(md < 1e-4)) {
-            fprintf(stderr, "vox_hip: MFMA attention self-test FAILED (max diff %g)\n", md);
+            fprintf(stderr, "vox_hip: bf16-split MFMA attention self-test FAILED (max diff %g)\n", md);
             e->use_attn_mfma = false; failed++;
         }
-        a.out = do1;
-        hipLaunchKernelGGL(k_attn_enc_bf16, dim3((nq + 127) / 128, nh), dim3(256), 0, e->stream, a);
-        HC(esync(e));
-        HC(hipMemcpy(r1.data(), do1, r1.size() * 4, hipMemcpyDeviceToHost));
-        md = 0;
-        for (size_t i = 0; i < r1.size(); i++) md = std::max(md, (double)fabsf(r1[i] - r2[i]));
-        if (!(md < 1e-4)) {
-            fprintf(stderr, "vox_hip: bf16-split MFMA attention self-test FAILED (max diff %g)\n", md);
-            e->use_attn_bf16 = false; failed++;
-        }
-        if (getenv("VOX_HIP_ATTN_F32")) e->use_attn_bf16 = false;          // A/B: the f32-input MFMA kernel of rounds 1 - 3
         hipFree(dq); hipFree(dk); hipFree(dv); hipFree(do1); hipFree(do2);
-        if (getenv("VOX_HIP_NO_ATTN_MFMA")) e->use_attn_mfma = false;
+        if (vox_disabled("attn_mfma")) e->use_attn_mfma = false;
     }
-    if (getenv("VOX_HIP_NO_MFMA")) e->use_mfma = false;
-    if (getenv("VOX_HIP_NO_GEMV2")) e->use_gemv2 = false;
-    if (getenv("VOX_HIP_NO_GEMV3")) e->use_gemv3 = false;
-    if (getenv("VOX_HIP_NO_SPLITK")) e->use_splitk = false;
-    if (getenv("VOX_HIP_NO_SKINNY")) e->use_skinny = false;
+    if (vox_disabled("mfma")) e->use_mfma = false;
+    if (vox_disabled("fast")) e->use_fast = false;
+    if (vox_disabled("splitk")) e->use_splitk = false;
+    if (vox_disabled("skinny")) e->use_skinny = false;
     if (hipFuncSetAttribute((const void *)k_skinny<SK_SWIGLU, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_WPB * 2 * 4096) != hipSuccess) {
         (void)hipGetLastError();
         e->use_skinny = false;
@@ -3126,8 +2979,7 @@ static int self_test(vox_hip_engine *e) {
                 }
             }
         }
-        if (getenv("VOX_HIP_NO_ROWSGEMM")) e->use_rowsgemm = false;
-        e->rg_small = getenv("VOX_HIP_RG_SMALL") ? 1 : 0;
+        if (vox_disabled("rowsgemm")) e->use_rowsgemm = false;
     }
     hipFree(dx); hipFree(dy0); hipFree(dy1); hipFree(dy2); hipFree(dw); hipFree(dbias);
     if (failed) {
@@ -3156,7 +3008,7 @@ extern "C" unsigned vox_hip_active_paths(const vox_hip_engine_t *e) {
     if (e->use_attn_mfma) m |= VOX_PATH_ATTN_ENC_MFMA;
     if (e->use_dpp) m |= VOX_PATH_ATTN_DEC_DPP;
     if (e->use_splitk) m |= VOX_PATH_GEMM_SPLITK;
-    if (fast_geom && e->use_gemv2 && e->use_gemv3) m |= VOX_PATH_GEMV3;
+    if (fast_geom && e->use_fast) m |= VOX_PATH_GEMV3;
     if (e->use_fp8) m |= VOX_PATH_FP8_DECODE;
     if (fast_geom && e->use_fused && e->use_dpp) m |= VOX_PATH_DEC_FUSED;
     if (e->use_skinny && e->use_mfma) m |= VOX_PATH_SKINNY_ENC;
@@ -3469,7 +3321,7 @@ extern "C" int vox_hip_shard_end_push(vox_hip_engine_t *src, vox_hip_engine_t *o
         if (adapter_dev(src, (const float *)src->stmp_out.p, m, (float *)src->stmp_in.p)) return -1;
         if (peer_copy_async(owner, dst_rows, src, src->stmp_in.p, (size_t)m * DD * 4, src->stream)) return -1;
         // the owner's stream does NOT wait here: its decoder waits for these rows when it gets to them (row_fences)
-        const bool no_overlap = getenv("VOX_MULTI_NO_OVERLAP") != nullptr;              // A/B: the round-3 behaviour (read per call, like host/vox_stream.c)
+        const bool no_overlap = vox_disabled("multi_overlap");                          // the round-3 behaviour (read per call, like host/vox_stream.c)
         if (no_overlap) { if (chain_streams(src, owner)) return -1; }
         else {
             hipEvent_t ev;
@@ -3498,7 +3350,7 @@ extern "C" int vox_hip_encoder_state_push(vox_hip_engine_t *src, vox_hip_engine_
     if (peer_copy_async(dst, dst->conv_in1.p, src, src->conv_in1.p, (size_t)2 * ED * 4, src->stream)) return -1;
     if (peer_copy_async(dst, dst->enc_out.p, src, src->enc_out.p, (size_t)3 * ED * 4, src->stream)) return -1;
     dst->enc_pos = src->enc_pos; dst->c0_carry = src->c0_carry; dst->enc_res = src->enc_res;
-    const bool no_overlap = getenv("VOX_MULTI_NO_OVERLAP") != nullptr;
+    const bool no_overlap = vox_disabled("multi_overlap");
     if (no_overlap) return chain_streams(src, dst);
     hipEvent_t ev;
     if (record_xev(src, &ev)) return -1;

@@ -261,13 +261,8 @@ __global__ __launch_bounds__(64 * SK_WPB) void k_skinny(const SkinnyArgs a) {
 // three passes of up to three load batches each: 8.7 us for 24 splits).
 __global__ __launch_bounds__(1024) void k_rows_finish(float *x, int ldx, const float *partial, int nsplit, int n, int D,
                                                       const float *bias, const float *norm_w, float eps, float *out_norm, int ldo,
-                                                      uint16_t *planes, const float *ada = nullptr, const L2Pf pf = L2Pf{}) {
+                                                      uint16_t *planes, const float *ada = nullptr) {
     __shared__ float red[16];
-    __shared__ __attribute__((aligned(16))) unsigned char pf_scratch[16 * 1024];
-    if ((int)blockIdx.x >= n) {          // appended L2-prefetch workgroups (vox_common.h, L2Pf): the next GEMM launch's weight tiles
-        l2pf_run(pf, (int)blockIdx.x - n, (int)blockIdx.x, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_addr(pf_scratch) + (threadIdx.x >> 6) * 1024u)));
-        return;
-    }
     const int m = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     float *xr = x + (size_t)m * ldx;
     float ss = 0.f;

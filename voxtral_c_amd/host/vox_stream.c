@@ -235,8 +235,8 @@ static void run_encoder(vox_stream_t *s) {
         if (used > 0) {
             /* the shards are only enqueued, and the stream engine does not wait for the others here: its decoder waits for each
              * shard's adapter rows when it reaches them (vox_hip_shard_end_push).  The encoder time accounted here is the host's
-             * enqueue time; VOX_MULTI_NO_OVERLAP=1 (A/B) waits for the whole wavefront as round 3 did. */
-            if (getenv("VOX_MULTI_NO_OVERLAP")) vox_hip_sync(s->eng);
+             * enqueue time; VOX_HIP_DISABLE=multi_overlap waits for the whole wavefront as round 3 did. */
+            if (vox_hip_switch_disabled("multi_overlap")) vox_hip_sync(s->eng);
             vox_hip_add_encode_ms(s->eng, now_ms() - t0);
             __atomic_fetch_add(&s->ctx->n_sharded_chunks, 1, __ATOMIC_RELAXED);
             s->mel_cursor += used;

@@ -291,6 +291,7 @@ enum vox_hip_path {
     VOX_PATH_ROWSGEMM         = 1u << 11,  /* 33 .. 128-row passes (decoder prefill, encoder flush) on the weight-streaming MFMA kernel k_rowsgemm */
     VOX_PATH_FFN_ATTN12       = 1u << 12,  /* decode step: FFN block of layer l + attention block of layer l + 1 as ONE launch (k_ffn_attn12, every context length since round 5; fp8: k_w2x_attn12 up to 1024 keys) */
     VOX_PATH_DEC_STACK        = 1u << 13,  /* decode step: FFN(0) and the attention + FFN blocks of layers 1 .. L-1 as ONE launch (k_dec_stack): 4 launches per token */
+    VOX_PATH_FP8_MFMA         = 1u << 14,  /* fp8 mode (config 5 only): the decoder prefill multiplies on the fp8 MFMA (k_rowsgemm_f8: e4m3 weights, activations as two e4m3 terms) */
 };
 #define VOX_PATH_ALL_BF16 (VOX_PATH_GEMM_MFMA_BF16X3 | VOX_PATH_GEMM_MFMA_F32 | VOX_PATH_GEMM_SPLITK | \
                            VOX_PATH_ATTN_ENC_MFMA | VOX_PATH_ATTN_DEC_DPP | VOX_PATH_GEMV3 | VOX_PATH_DEC_FUSED | VOX_PATH_SKINNY_ENC | \

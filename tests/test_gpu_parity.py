@@ -989,6 +989,33 @@ def test_rowsgemm_matches_the_scalar_reference_kernel(tiny, M, K, N):
         assert err < 5e-5, (impl, err, np.nonzero(np.abs(y - ref).max(axis=1) > 5e-5)[0][:16])
 
 
+@pytest.mark.parametrize("M,K,N", [(1, 3072, 6144), (16, 3072, 6144), (17, 4096, 3072), (38, 3072, 6144), (38, 4096, 3072), (38, 3072, 18432),
+                                   (38, 9216, 3072), (48, 3072, 512), (49, 1280, 1000), (64, 9216, 3072), (33, 192, 96)])
+def test_fp8_mfma_rowsgemm_matches_the_dequantised_reference(tiny, M, K, N):
+    """fp8 mode's M > 1 GEMM (k_rowsgemm_f8, vox_rowsgemm_f8.h: e4m3 weights with one scale per row on v_mfma_f32_16x16x32_fp8_fp8,
+    the f32 activations as TWO e4m3 terms) against the same device-quantised weights dequantised and multiplied in f32 (impl 7): the
+    difference is what the activation split and the MFMA's K permutation add - it must stay at the level of the 8 significant bits
+    the split keeps (a wrong fragment layout would be an O(1) error), in every 16-row tile count (1 .. 4), around the tile edges,
+    for K ranges that do not divide evenly into rounds and N that is no multiple of the workgroup's 256 rows.  Heavy-tailed rows
+    with outlier columns and activations spanning four orders of magnitude, as the decoder's normalised rows do on the realistic-statistics checkpoint."""
+    rng = np.random.default_rng(M * 977 + K + N)
+    x = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-3.0, 2.5, (1, K)))).astype(np.float32)
+    wt = rng.standard_t(3, (N, K)) / np.sqrt(3.0 * K)
+    wt[:, rng.integers(0, K, max(1, K // 200))] *= 40.0
+    w = vo.f32_to_bf16(wt.astype(np.float32))
+    b = rng.standard_normal(N).astype(np.float32)
+    ref = tiny.linear_bf16(x, w, b, impl=7)
+    y = tiny.linear_bf16(x, w, b, impl=6)
+    full = tiny.linear_bf16(x, w, b, impl=3)           # the bf16 weights themselves: how large the weights' own quantisation error is
+    scale = float(np.sqrt(((full - b) ** 2).mean()))
+    err = float(np.abs(y - ref).max()) / scale
+    rms = float(np.sqrt(((y - ref) ** 2).mean())) / scale
+    qerr = float(np.sqrt(((ref - full) ** 2).mean())) / scale
+    diag(f"fp8_rowsgemm_{M}_{K}_{N}", max_err_over_rms_y=err, rms_err_over_rms_y=rms, weight_quantisation_rms_err_over_rms_y=qerr)
+    assert rms < 4e-3 and err < 0.15, (rms, err, qerr)          # (max over ~1e5 outputs of heavy-tailed rows, in units of rms(y))
+    assert rms < 0.25 * qerr + 1e-4, (rms, qerr)
+
+
 def test_few_rows_paths_agree_with_the_large_m_paths(vox):
     """The same encoder chunks (1 .. 128 rows, after a big first chunk and on a cold window) and the same decoder prefills
     (1 .. 128 rows, then three greedy steps) on two engines of one process: one with the k_rowsgemm path switched off

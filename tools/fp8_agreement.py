@@ -5,7 +5,7 @@ step sees the same inputs) against the bf16 run, next to the margin-conditioned 
 Variants: the shipped fp8 mode (one f32 scale per output row, real e4m3 streaming kernels), the same with the LM head kept on
 the bf16 embedding (VOX_HIP_DISABLE=fp8_lmhead), and block-scaled variants simulated exactly on the bf16 kernels with power-of-two
 scales (vox_hip_simulate_block_fp8: per row, per 128, per 32 weights; LM head quantised or not).
-usage: fp8_agreement.py out.json"""
+usage: fp8_agreement.py out.json [preset [golden.npz]]   (default: full, tests/golden/stream_full_batch.npz)"""
 import ctypes as C, json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,9 +13,11 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import voxtral_c_amd as v
 from conftest import model_dir
 
-g = np.load(os.path.join(ROOT, "tests", "golden", "stream_full_batch.npz"), allow_pickle=True)
+preset = sys.argv[2] if len(sys.argv) > 2 else "full"
+gname = sys.argv[3] if len(sys.argv) > 3 else "stream_full_batch.npz"
+g = np.load(os.path.join(ROOT, "tests", "golden", gname), allow_pickle=True)
 audio = g["audio_i16"].astype(np.float32) / 32768.0
-d = model_dir("full")
+d = model_dir(preset)
 v.hip.vox_hip_simulate_block_fp8.argtypes = [C.c_void_p, C.c_int, C.c_int]
 
 with v.Model(d) as m:
@@ -57,7 +59,7 @@ for name, env in (("fp8 mode as shipped: e4m3 + f32 scale per row, all decode GE
     for k in env: del os.environ[k]
     print(name, rows[name], flush=True)
 
-out = {"clip": "tests/golden/stream_full_batch.npz (30 s night1968, 386 steps)", "min_bf16_top2_margin": float(margin.min()),
+out = {"clip": f"tests/golden/{gname} ({len(audio) / 16000:g} s, {len(g['tokens'])} steps)", "checkpoint": preset, "min_bf16_top2_margin": float(margin.min()),
        "bf16_margin_quantiles_1_10_50pct": [float(np.quantile(margin, q)) for q in (0.01, 0.1, 0.5)],
        "criterion": "BASELINE config 5: tokens match bf16 greedy (free run identical); teacher-forced agreement = share of steps with the "
                     "same argmax when every step sees the bf16 run's inputs",

@@ -34,6 +34,7 @@
 #include "vox_decfuse.h"
 #include "vox_skinny.h"
 #include "vox_rowsgemm.h"
+#include "vox_rowsgemm_f8.h"
 
 using namespace vox;
 
@@ -233,6 +234,7 @@ struct vox_hip_engine {
     uint8_t *tok_emb8 = nullptr; float *stok = nullptr;
     uint16_t *tok_emb_s = nullptr;      // simulated-quantisation copy of the LM head (see DecLayer::wqkv_s)
     bool sim_on = false, sim_lm = false;
+    bool fp8_prefill_bf16 = false;       // VOX_HIP_DISABLE=fp8_prefill: fp8 mode with the prefill on the bf16 matrices (rounds 2 - 4)
     bool fp8_attn_bf16 = false, fp8_lmhead_bf16 = false;     // A/B and agreement-study switches of the fp8 mode, read at creation
     // fused attention half of the decode step (vox_decfuse.h)
     bool use_fused = false;
@@ -308,7 +310,7 @@ static hipError_t esync(vox_hip_engine *e) {
 // A/B measurements and for the tests that keep the older paths honest.  Names: fused (the launch-per-GEMV decode chain), ffn_fused,
 // merge12 (two launches per layer), merge12_long (two launches per layer beyond 1024 keys), stack (one launch per layer),
 // fast (the generic decode kernels), dpp, mfma, bf16x3, planes, splitk, skinny, rowsgemm, attn_small, attn_mfma, epi (separate RoPE / SiLU launches), staged_upload, rearm (a timed-out fused kernel stays off),
-// fp8_attn / fp8_lmhead (fp8 mode: these matrices stay bf16), multi_overlap (multi-GPU: wait for the whole wavefront).
+// fp8_attn / fp8_lmhead / fp8_prefill (fp8 mode: these matrices / this pass stay bf16), multi_overlap (multi-GPU: wait for the whole wavefront).
 static bool vox_disabled(const char *name) {
     const char *v = getenv("VOX_HIP_DISABLE");
     if (!v) return false;
@@ -722,6 +724,7 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
             if (vox_disabled("stack")) e->use_stack = 0;
             e->fp8_attn_bf16 = vox_disabled("fp8_attn");
             e->fp8_lmhead_bf16 = vox_disabled("fp8_lmhead");
+            e->fp8_prefill_bf16 = vox_disabled("fp8_prefill");
             e->enc_tl_on = getenv("VOX_HIP_ENC_TL") != nullptr;
             if (ok && getenv("VOX_HIP_FUSE_TL") && hipMalloc((void **)&e->d_fuse_tl, 3 * 1024 * TL_STRIDE * 8) == hipSuccess)
                 hipMemset(e->d_fuse_tl, 0, 3 * 1024 * TL_STRIDE * 8);
@@ -1218,6 +1221,37 @@ static size_t rg_partial_bytes(int n, int N, int K) {       // (the f32-activati
     return (size_t)std::max(rg_plan(n, N, K, false).S, rg_plan(n, N, K, true).S) * n * N * 4;
 }
 
+// fp8 mode (BASELINE config 5): partial[S][n][N] = x . W8^T on the fp8 MFMA (k_rowsgemm_f8, vox_rowsgemm_f8.h), n <= 64 rows of f32
+// activations, W8 = row-scaled e4m3.  Returns S or -1.  The activations' pre-scale: normalised rows, attention outputs and gated
+// hidden rows of this model stay far below 224 / 2 in magnitude, and e4m3 keeps its 4 significant bits down to 2^-6 / 2.
+constexpr int RGF8_WPB = 8, RGF8_CPW = 2;
+static int rgf8_splits(int N, int K) {
+    const int nb = (N + 32 * RGF8_WPB - 1) / (32 * RGF8_WPB), nchunks = K / 64;
+    const int S = std::max(1, std::min(nchunks / RGF8_CPW, 256 / nb));
+    int cw = (nchunks + S - 1) / S;
+    cw = ((cw + RGF8_CPW - 1) / RGF8_CPW) * RGF8_CPW;
+    return (nchunks + cw - 1) / cw;
+}
+static size_t rgf8_partial_bytes(int n, int N, int K) { return (size_t)rgf8_splits(N, K) * n * N * 4; }
+static int launch_rowsgemm_f8(vox_hip_engine *e, const float *X, int ldx, int n, const uint8_t *W8, const float *wscale, int N, int K, float *partial) {
+    if (n < 1 || n > 64 || K % 64 || ldx % 4) { g_err = "rowsgemm_f8: needs 1 <= n <= 64, K % 64 == 0"; return -1; }
+    const int nb = (N + 32 * RGF8_WPB - 1) / (32 * RGF8_WPB), nchunks = K / 64;
+    const int S0 = std::max(1, std::min(nchunks / RGF8_CPW, 256 / nb));
+    int cw = (nchunks + S0 - 1) / S0;
+    cw = ((cw + RGF8_CPW - 1) / RGF8_CPW) * RGF8_CPW;
+    const int S = (nchunks + cw - 1) / cw;
+    RowsGemmF8Args a{};
+    a.X = X; a.ldx = ldx; a.n = n; a.W = W8; a.wscale = wscale; a.N = N; a.K = K; a.cw = cw; a.prescale = 2.0f; a.partial = partial;
+    const dim3 grid(nb, S), block(64 * RGF8_WPB);
+    switch ((n + 15) / 16) {
+        case 1: hipLaunchKernelGGL((k_rowsgemm_f8<RGF8_WPB, RGF8_CPW, 1>), grid, block, 0, e->stream, a); break;
+        case 2: hipLaunchKernelGGL((k_rowsgemm_f8<RGF8_WPB, RGF8_CPW, 2>), grid, block, 0, e->stream, a); break;
+        case 3: hipLaunchKernelGGL((k_rowsgemm_f8<RGF8_WPB, RGF8_CPW, 3>), grid, block, 0, e->stream, a); break;
+        default: hipLaunchKernelGGL((k_rowsgemm_f8<RGF8_WPB, RGF8_CPW, 4>), grid, block, 0, e->stream, a); break;
+    }
+    return S;
+}
+
 // Decoder attention of `n` prefill rows over the KV ring (the rows' own K/V are in the ring already).
 static int dec_attention_rows(vox_hip_engine *e, const RowsCfg &c, float *qkv, float *attn, int n, int pos0, float *kring, float *vring, int ring_cap) {
     hipStream_t s = e->stream;
@@ -1255,7 +1289,16 @@ static int rows_mid_layers(vox_hip_engine *e, float *x, int n, int pos0, const R
     if (ensure(e, e->ssplitk, pb)) return -1;
     if (ensure(e, e->sgu, (size_t)3 * n * (c.D + c.H) * 2)) return -1;       // bf16 planes of the normalised rows and of the gated hidden rows
     if (ensure(e, e->sqkv, (size_t)n * N3 * 4) || ensure(e, e->sattn, (size_t)n * c.QD * 4)) return -1;
-    uint16_t *xnp = (uint16_t *)e->sgu.p, *hp = xnp + (size_t)3 * n * c.D;
+    // fp8 mode (BASELINE config 5): the decoder prefill reads the row-scaled e4m3 copies of its matrices and multiplies on the fp8 MFMA
+    // (k_rowsgemm_f8); the normalised rows and the gated hidden rows then travel as f32 (the kernel splits them into e4m3 terms)
+    const bool f8 = !is_enc && e->use_fp8 && e->use_mfma && !e->fp8_prefill_bf16 && n <= 64 && e->dec[0].wqkv8;
+    if (f8) {
+        pb = std::max(std::max(rgf8_partial_bytes(n, N3, c.D), rgf8_partial_bytes(n, c.D, c.QD)),
+                      std::max(rgf8_partial_bytes(n, 2 * c.H, c.D), rgf8_partial_bytes(n, c.D, c.H)));
+        if (ensure(e, e->ssplitk, pb) || ensure(e, e->sxn, (size_t)n * c.D * 4) || ensure(e, e->sgu, (size_t)n * c.H * 4)) return -1;
+    }
+    float *xnf = f8 ? (float *)e->sxn.p : nullptr, *hf = f8 ? (float *)e->sgu.p : nullptr;
+    uint16_t *xnp = f8 ? (uint16_t *)nullptr : (uint16_t *)e->sgu.p, *hp = f8 ? (uint16_t *)nullptr : xnp + (size_t)3 * n * c.D;
     float *part = (float *)e->ssplitk.p, *qkv = (float *)e->sqkv.p, *attn = (float *)e->sattn.p, *tab = (float *)e->srope.p;
     const int ring_cap = is_enc ? e->enc_ring_cap : e->dec_ring_cap;
     // the chunk's K/V rows may go to their ring slots before attention when they cannot overwrite a row the window still needs
@@ -1266,14 +1309,16 @@ static int rows_mid_layers(vox_hip_engine *e, float *x, int n, int pos0, const R
     };
     if (L > 0)
         hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)nullptr, 0, n, c.D, (const float *)nullptr,
-                           norm_of(0, 0), c.eps, (float *)nullptr, 0, xnp, (const float *)nullptr);
+                           norm_of(0, 0), c.eps, xnf, c.D, xnp, (const float *)nullptr);
     for (int l = 0; l < L; l++) {
         const uint16_t *wqkv = is_enc ? e->enc[l].wqkv : e->dec[l].wqkv, *wo = is_enc ? e->enc[l].wo : e->dec[l].wo;
         const uint16_t *w13 = is_enc ? e->enc[l].w13 : e->dec[l].w13, *w2 = is_enc ? e->enc[l].w2 : e->dec[l].w2;
         float *kring = is_enc ? e->enc[l].kring : e->dec[l].kring, *vring = is_enc ? e->enc[l].vring : e->dec[l].vring;
         const float *bqkv = is_enc ? e->enc[l].bqkv : nullptr, *bo = is_enc ? e->enc[l].bo : nullptr, *b2 = is_enc ? e->enc[l].b2 : nullptr;
         const float *ada = is_enc ? nullptr : e->dec[l].ada;
-        int S = launch_rowsgemm(e, xnp, (size_t)n * c.D, nullptr, 0, n, wqkv, N3, c.D, part);
+        int S = f8 ? launch_rowsgemm_f8(e, xnf, c.D, n, e->dec[l].wqkv8, e->dec[l].sqkv, N3, c.D, part)
+                   : launch_rowsgemm(e, xnp, (size_t)n * c.D, nullptr, 0, n, wqkv, N3, c.D, part);
+        if (S < 0) return -1;
         hipLaunchKernelGGL(k_qkv_finish, dim3(grid1d((size_t)n * N3 / 4)), dim3(256), 0, s, qkv, N3, (const float *)part, S, n, bqkv,
                            (const float *)tab, c.QD + c.KVD, c.hd, append_early ? kring : (float *)nullptr, vring, ring_cap, c.KVD, pos0, c.QD);
         if (is_enc) {
@@ -1284,16 +1329,22 @@ static int rows_mid_layers(vox_hip_engine *e, float *x, int n, int pos0, const R
                                    kring, vring, ring_cap, c.KVD, qkv, N3, c.QD, c.QD + c.KVD, n - keep, keep, pos0 + n - keep);
             }
         } else if (dec_attention_rows(e, c, qkv, attn, n, pos0, kring, vring, ring_cap)) return -1;
-        S = launch_rowsgemm(e, nullptr, 0, attn, c.QD, n, wo, c.D, c.QD, part);
+        S = f8 ? launch_rowsgemm_f8(e, attn, c.QD, n, e->dec[l].wo8, e->dec[l].so, c.D, c.QD, part)
+               : launch_rowsgemm(e, nullptr, 0, attn, c.QD, n, wo, c.D, c.QD, part);
+        if (S < 0) return -1;
         hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, S, n, c.D, bo,
-                           norm_of(l, 1), c.eps, (float *)nullptr, 0, xnp, ada);
-        S = launch_rowsgemm(e, xnp, (size_t)n * c.D, nullptr, 0, n, w13, 2 * c.H, c.D, part);
-        hipLaunchKernelGGL(k_swiglu_finish, dim3(grid1d((size_t)n * c.H / 4)), dim3(256), 0, s, hp, (size_t)n * c.H, (const float *)part, S, n, c.H);
-        S = launch_rowsgemm(e, hp, (size_t)n * c.H, nullptr, 0, n, w2, c.D, c.H, part);
+                           norm_of(l, 1), c.eps, xnf, c.D, xnp, ada);
+        S = f8 ? launch_rowsgemm_f8(e, xnf, c.D, n, e->dec[l].w138, e->dec[l].s13, 2 * c.H, c.D, part)
+               : launch_rowsgemm(e, xnp, (size_t)n * c.D, nullptr, 0, n, w13, 2 * c.H, c.D, part);
+        if (S < 0) return -1;
+        hipLaunchKernelGGL(k_swiglu_finish, dim3(grid1d((size_t)n * c.H / 4)), dim3(256), 0, s, hp, (size_t)n * c.H, (const float *)part, S, n, c.H, hf);
+        S = f8 ? launch_rowsgemm_f8(e, hf, c.H, n, e->dec[l].w28, e->dec[l].s2, c.D, c.H, part)
+               : launch_rowsgemm(e, hp, (size_t)n * c.H, nullptr, 0, n, w2, c.D, c.H, part);
+        if (S < 0) return -1;
         const bool last = l + 1 == L;
         const float *next_norm = last ? (is_enc ? e->enc_final_norm : (const float *)nullptr) : norm_of(l + 1, 0);
         hipLaunchKernelGGL(k_rows_finish, dim3(n), dim3(rf_threads(c.D)), 0, s, x, c.D, (const float *)part, S, n, c.D, b2,
-                           next_norm, c.eps, last ? out : (float *)nullptr, c.D, last ? (uint16_t *)nullptr : xnp, (const float *)nullptr);
+                           next_norm, c.eps, last ? out : xnf, c.D, last ? (uint16_t *)nullptr : xnp, (const float *)nullptr);
     }
     if (L == 0 && out)
         hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, s, out, c.D, x, c.D, e->enc_final_norm, (const float *)nullptr, c.D, c.eps);
@@ -2412,6 +2463,26 @@ extern "C" int vox_hip_linear_bf16(vox_hip_engine_t *e, float *y, const float *x
         hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((size_t)M * N)), dim3(256), 0, e->stream, a);
         HC(esync(e));
         hipFree(dp); hipFree(part);
+    } else if (impl == 6 || impl == 7) {
+        // test surface of the fp8 mode's M > 1 GEMM: the weights are quantised on the device as vox_hip_quantize_decoder_fp8 does
+        // (k_quant_fp8_rows: e4m3, one f32 scale per row); impl 6 = k_rowsgemm_f8 (fp8 MFMA, activations as two e4m3 terms);
+        // impl 7 = the SAME quantised weights dequantised to f32 and multiplied in f32 (the reference of 6: isolates what the
+        // activation split and the MFMA add to the weights' quantisation error)
+        if (M > 64 || K % 64) { g_err = "vox_hip_linear_bf16: impl 6 / 7 need M <= 64 and K % 64 == 0"; return -1; }
+        uint8_t *dq = nullptr; float *dsc = nullptr, *part = nullptr;
+        HC(hipMalloc((void **)&dq, (size_t)N * K)); HC(hipMalloc((void **)&dsc, (size_t)N * 4));
+        hipLaunchKernelGGL(k_quant_fp8_rows, dim3(N), dim3(256), 0, e->stream, (const uint16_t *)dw, dq, dsc, K);
+        if (impl == 6) {
+            HC(hipMalloc((void **)&part, rgf8_partial_bytes(M, N, K)));
+            const int S = launch_rowsgemm_f8(e, dx, K, M, dq, dsc, N, K, part);
+            if (S < 0) return -1;
+            GemmArgs a{nullptr, 0, dw, dy, N, M, N, K, db, nullptr, 0, ACT_NONE, S, 0, part};
+            hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((size_t)M * N)), dim3(256), 0, e->stream, a);
+        } else {
+            hipLaunchKernelGGL(k_fp8_ref_gemm, dim3(N), dim3(64), 0, e->stream, dy, (const float *)dx, (const uint8_t *)dq, (const float *)dsc, (const float *)db, M, N, K);
+        }
+        HC(esync(e));
+        hipFree(dq); hipFree(dsc); if (part) hipFree(part);
     } else if (linear_dev(e, dy, N, dx, K, dw, db, M, K, N, ACT_NONE, nullptr, 0, impl)) return -1;
     HC(esync(e));
     HC(hipGetLastError());
@@ -3010,6 +3081,7 @@ extern "C" unsigned vox_hip_active_paths(const vox_hip_engine_t *e) {
     if (e->use_splitk) m |= VOX_PATH_GEMM_SPLITK;
     if (fast_geom && e->use_fast) m |= VOX_PATH_GEMV3;
     if (e->use_fp8) m |= VOX_PATH_FP8_DECODE;
+    if (e->use_fp8 && e->use_mfma && !e->fp8_prefill_bf16) m |= VOX_PATH_FP8_MFMA;
     if (fast_geom && e->use_fused && e->use_dpp) m |= VOX_PATH_DEC_FUSED;
     if (e->use_skinny && e->use_mfma) m |= VOX_PATH_SKINNY_ENC;
     if (e->use_planes && e->use_mfma && e->use_bf16x3) m |= VOX_PATH_GEMM_PLANES;

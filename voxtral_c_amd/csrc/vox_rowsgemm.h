@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256) void k_qkv_finish(float *qkv, int N3, const fl
 
 // h[m][j] = silu(sum_s partial[s][m][j]) * sum_s partial[s][m][H + j]  (voxtral_encoder.c:598-606, voxtral_decoder.c:684-687),
 // written as the bf16 planes [3][n][H] the W2 launch consumes.  partial rows are 2 H wide (W = [w1; w3]).
-__global__ __launch_bounds__(256) void k_swiglu_finish(uint16_t *planes, size_t plane, const float *partial, int nsplit, int n, int H) {
+// hf (optional, fp8 mode): the gated rows also as f32 [n][H] for k_rowsgemm_f8, which splits them into e4m3 terms itself.
+__global__ __launch_bounds__(256) void k_swiglu_finish(uint16_t *planes, size_t plane, const float *partial, int nsplit, int n, int H, float *hf = nullptr) {
     const size_t total4 = (size_t)n * H / 4, slice = (size_t)n * 2 * H;
     const int h4 = H / 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(256) void k_swiglu_finish(uint16_t *planes, size_t 
             }
         }
         const float4 o = make_float4(silu(g.x) * u.x, silu(g.y) * u.y, silu(g.z) * u.z, silu(g.w) * u.w);
+        if (hf) { *reinterpret_cast<float4 *>(hf + (size_t)m * H + j) = o; continue; }
         uint32_t h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
         split3(o.x, h0, m0, l0); split3(o.y, h1, m1, l1); split3(o.z, h2, m2, l2); split3(o.w, h3, m3, l3);
         uint16_t *dst = planes + (size_t)m * H + j;

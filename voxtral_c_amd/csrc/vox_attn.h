@@ -42,6 +42,7 @@ struct AttnArgs {
     int window;
     const DecState *st;             // decoder step: qpos0 = st->pos (when non-null)
     // split-K (decoder)
+    unsigned *arrive;               // k_attn_small: [n_heads] arrival counters (zero between launches): the last slice of a head to arrive merges it
     int xcd_map;                    // k_attn_enc_bf16: remap (tile, head) so that a head's query tiles share an XCD (see there)
     int split_keys;                 // keys per blockIdx.y
     float *part_o, *part_ml;        // [n_q][n_heads][nsplit][HD], [..][2]
@@ -571,6 +572,15 @@ __global__ __launch_bounds__(256) void k_attn_dec(const AttnArgs a, const int ns
 // workgroup and spent 17.5 us per layer on a 25-row chunk, most of it on padding; this is plain f32 FMA (vox_causal_attention,
 // voxtral_kernels.c:412-482, up to summation order): lane = key for the scores (K row in registers, q broadcast from LDS),
 // lane = dim for P.V.
+// Device-coherent float store / load without fences: write-through (sc1) stores and L1-bypassing loads, as the decode step's
+// granules use (vox_decfuse.h).  (A device-scope __threadfence() is the wrong tool on this part: its release writes back and its
+// acquire invalidates the XCD's whole L2 - the few-rows encoder layer took 130 us instead of 68 with one in k_attn_small.)
+__device__ __forceinline__ void st_dev(float *p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_dev(const float *p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 __device__ __forceinline__ float as_dpp_sum(float v) {          // wave-wide sum: 4 DPP row steps + the 4 row sums via readlane
     v = row16_sum<true>(v);
     const int iv = __float_as_int(v);
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_small(const AttnArgs a, int ke
             ps[row][lane] = pe;
             if (lane == 0 && row < n) {
                 float *ml = a.part_ml + (((size_t)row * a.n_heads + h) * nz + z) * 2;
-                ml[0] = m > -1e29f ? m : -1e30f; ml[1] = l;
+                st_dev(ml, m > -1e29f ? m : -1e30f); st_dev(ml + 1, l);
             }
         }
     }
@@ -668,8 +678,49 @@ __global__ __launch_bounds__(64 * NW) void k_attn_small(const AttnArgs a, int ke
 #pragma unroll
         for (int r = 0; r < RPW; r++) {
             const int row = wave * RPW + r;
-            if (row < n) a.part_o[(((size_t)row * a.n_heads + h) * nz + z) * 64 + lane] = acc[r];
+            if (row < n) st_dev(a.part_o + (((size_t)row * a.n_heads + h) * nz + z) * 64 + lane, acc[r]);
         }
+    }
+    // ---- merge of the head's key slices by whichever of its workgroups arrives last (round 5: this was a launch of its own,
+    // k_attn_combine: ~5 us of launch floor per encoder layer for 200 KB of partials).  The partials are written through (sc1);
+    // a workgroup counts itself in only when all of its stores have been acknowledged (vmcnt(0), barrier), and the last arriver
+    // reads the partials with L1-bypassing loads.  The arithmetic and its order are k_attn_combine's.
+    if (!a.arrive) return;
+    __shared__ unsigned s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(a.arrive + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == (unsigned)nz - 1u;
+        if (s_last) __hip_atomic_store(a.arrive + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nobody else touches the counter until the next launch)
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int row = wave; row < n; row += NW) {
+        const size_t base = ((size_t)row * a.n_heads + h) * nz;
+        float mm = -1e30f, ll = 0.f, ov = 0.f;
+        for (int s0 = 0; s0 < nz; s0 += 16) {      // batches of 16 slices in flight (a 750-position window is 12 - 13 slices)
+            float2 ml[16]; float o[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int sc = min(s0 + u, nz - 1);
+                ml[u].x = ld_dev(a.part_ml + (base + sc) * 2); ml[u].y = ld_dev(a.part_ml + (base + sc) * 2 + 1);
+                o[u] = ld_dev(a.part_o + (base + sc) * 64 + lane);
+            }
+            float mn = mm;
+#pragma unroll
+            for (int u = 0; u < 16; u++) if (s0 + u < nz) mn = fmaxf(mn, ml[u].x);
+            const float c0 = expf(mm - mn);
+            ll *= c0; ov *= c0; mm = mn;
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                if (s0 + u < nz) {
+                    const float f = expf(ml[u].x - mm);
+                    ll += ml[u].y * f;
+                    ov += o[u] * f;
+                }
+        }
+        a.out[(size_t)row * a.ldo + h * 64 + lane] = ll > 0.f ? ov * (1.0f / ll) : 0.f;
     }
 }
 

@@ -262,6 +262,8 @@ struct vox_hip_engine {
     // quarter of the LDS-DMA transport they take away.
     Buf splanes;                  // [3][n][max(D, QD, H)] bf16
     Uploader *up = nullptr;       // staged weight ingest: lives until vox_hip_upload_done (vox_load calls it) or the engine's end
+    bool attn_merge = true;                 // VOX_HIP_DISABLE=attn_merge: k_attn_combine as a launch of its own (round 4)
+    unsigned *d_attn_arrive = nullptr;      // k_attn_small: per-head arrival counters (zero between launches)
     bool enc_tl_on = false;
     unsigned long long *d_enc_tl = nullptr;       // VOX_HIP_ENC_TL: [4 GEMM launches][1024 workgroups][16] timeline of one few-rows encoder layer
     unsigned long long *d_fuse_tl = nullptr;      // VOX_HIP_FUSE_TL: [3 kernels][1024 workgroups][3] timeline of the layer-13 launches
@@ -309,7 +311,7 @@ static hipError_t esync(vox_hip_engine *e) {
 // that the next older HIP path underneath runs instead (never a CPU path) - what a failed start-up self-test does by itself.  For
 // A/B measurements and for the tests that keep the older paths honest.  Names: fused (the launch-per-GEMV decode chain), ffn_fused,
 // merge12 (two launches per layer), merge12_long (two launches per layer beyond 1024 keys), stack (one launch per layer),
-// fast (the generic decode kernels), dpp, mfma, bf16x3, planes, splitk, skinny, rowsgemm, attn_small, attn_mfma, epi (separate RoPE / SiLU launches), staged_upload, rearm (a timed-out fused kernel stays off),
+// fast (the generic decode kernels), dpp, mfma, bf16x3, planes, splitk, skinny, rowsgemm, attn_small, attn_merge (k_attn_combine as a launch of its own), attn_mfma, epi (separate RoPE / SiLU launches), staged_upload, rearm (a timed-out fused kernel stays off),
 // fp8_attn / fp8_lmhead / fp8_prefill (fp8 mode: these matrices / this pass stay bf16), multi_overlap (multi-GPU: wait for the whole wavefront).
 static bool vox_disabled(const char *name) {
     const char *v = getenv("VOX_HIP_DISABLE");
@@ -665,6 +667,8 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
     }
     // decoder step buffers
     rc |= dalloc(e, &e->d_st, 1);
+    rc |= dalloc(e, &e->d_attn_arrive, (size_t)std::max(1, d.enc_heads));
+    if (!rc && hipMemset(e->d_attn_arrive, 0, (size_t)std::max(1, d.enc_heads) * 4) != hipSuccess) rc = -1;
     rc |= dalloc(e, &e->dx, DD); rc |= dalloc(e, &e->dx2, DD); rc |= dalloc(e, &e->dq, DQ); rc |= dalloc(e, &e->dattn, DQ);
     rc |= dalloc(e, &e->dh, DH); rc |= dalloc(e, &e->dlogits, (size_t)d.vocab);
     e->logits_grid = (d.vocab % (16 * 1024) == 0) ? 1024 : gemv_grid(d.vocab, 16);   // 131072 rows: 8 even trips
@@ -760,7 +764,7 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     F(e->hann); F(e->cosT); F(e->sinT); F(e->filtT); F(e->enc_inv_freq); F(e->dec_inv_freq); F(e->dec_rope);
     F(e->d_st); F(e->dx); F(e->dx2); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
     F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_gq); F(e->d_gp); F(e->d_wo_part); F(e->d_fuse_err);
-    F(e->d_gh); F(e->d_gx); F(e->d_xprime);
+    F(e->d_gh); F(e->d_gx); F(e->d_xprime); F(e->d_gw); F(e->d_gxp); F(e->d_stack_tab); F(e->d_attn_arrive);
     Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
                    &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml, &e->ssplitk};
     for (Buf *b : bufs) F(b->p);
@@ -1058,10 +1062,18 @@ static int enc_attention(vox_hip_engine *e, const RowsCfg &c, float *qkv, float 
         if (ensure(e, e->spart_o, (size_t)n * c.heads * ks * c.hd * 4)) return -1;
         if (ensure(e, e->spart_ml, (size_t)n * c.heads * ks * 2 * 4)) return -1;
         a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
+        // (round 5: the key slices of a head are merged by whichever of its workgroups arrives last - no k_attn_combine launch)
+        // Up to 16 rows the key slices of a head are merged by whichever of its workgroups arrives last (no k_attn_combine launch);
+        // beyond, the merge of 25 - 32 rows by ONE workgroup per head takes longer than the launch it saves.  Same box, us per encoder
+        // layer at 1 / 8 / 16 / 25 / 32 rows: 55.3 / 58.5 / 63.6 / 70.9 / 75.8 merged against 58.4 / 61.5 / 64.9 / 69.9 / 74.0 with the
+        // launch (profiles/r05_enc_rows_ab.txt).
+        const bool merge_here = e->attn_merge && n <= 16;
+        a.arrive = merge_here ? e->d_attn_arrive : nullptr;
         if (e->use_dpp) hipLaunchKernelGGL((k_attn_small<true, 8>), dim3(c.heads, ks), dim3(512), 0, s, a, lo);
         else hipLaunchKernelGGL((k_attn_small<false, 8>), dim3(c.heads, ks), dim3(512), 0, s, a, lo);
-        hipLaunchKernelGGL((k_attn_combine<64>), dim3(c.heads, n), dim3(64), 0, s, attn, c.QD,
-                           (const float *)a.part_o, (const float *)a.part_ml, c.heads, ks);
+        if (!merge_here)
+            hipLaunchKernelGGL((k_attn_combine<64>), dim3(c.heads, n), dim3(64), 0, s, attn, c.QD,
+                               (const float *)a.part_o, (const float *)a.part_ml, c.heads, ks);
         return 0;
     }
     const int qt = (n + 127) / 128, blocks = qt * c.heads;
@@ -2944,6 +2956,7 @@ static int self_test(vox_hip_engine *e) {
         if (vox_disabled("planes")) e->use_planes = false;
         if (vox_disabled("epi")) e->use_epi = false;                         // separate RoPE / SiLU launches
         if (vox_disabled("attn_small")) e->use_attn_small = false;
+        if (vox_disabled("attn_merge")) e->attn_merge = false;
         if (vox_disabled("staged_upload")) e->use_staged_upload = false;
     }
 

@@ -556,6 +556,13 @@ def main():
     audio, golden, golden_name, audio_desc = headline_audio(args.seconds, args.mode)
     if args.preset != "full" or args.weights != "bf16" or mdir == real_model:
         golden = None
+    if args.preset == "full-rs" and args.weights == "bf16":
+        # the realistic-statistics checkpoint (tools/synth_model.c, style -rs): same geometry, same audio, its own goldens from oracle/_ref
+        rs_name = {("batch", 30.0): "stream_fullrs_batch.npz", ("batch", 95.0): "stream_fullrs_batch95.npz",
+                   ("stream", 176.0): "stream_fullrs_continuous.npz"}.get((args.mode, float(args.seconds)))
+        rs_path = os.path.join(ROOT, "tests", "golden", rs_name) if rs_name else None
+        if rs_path and os.path.exists(rs_path):
+            golden, golden_name = np.load(rs_path, allow_pickle=True), rs_name
 
     if args.mode == "stream":
         return stream_mode(args, model, audio, v, dims, golden, golden_name, audio_desc, mdir)

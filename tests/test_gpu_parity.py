@@ -273,7 +273,7 @@ def check_stream(name, g, run):
     recorded.  Pass 1 runs freely (the product behaviour): token ids must equal the reference's.  If a
     step differs, nothing is waved through: pass 2 teacher-forces the reference's ids so that EVERY step
     is still compared, every logits row must be within tolerance, and each differing argmax must be
-    explained by a reference top-2 margin below twice that tolerance."""
+    explained by a reference top-2 margin below twice the logit error measured in the run."""
     ref_t = g["tokens"]
     got = run()
     toks = np.asarray(got["tokens"])
@@ -298,7 +298,9 @@ def check_stream(name, g, run):
         res["pieces_equal"] = forced["pieces"] == list(g["pieces"])
         ok = ok and len(ft) == len(ref_t) and res["pieces_equal"]
         ok = ok and res["forced"]["top8"] < LOGIT_TOL and res["forced"]["full_rows"] < LOGIT_TOL
-        ok = ok and bool((g["margin"][bad] < 2 * LOGIT_TOL).all())
+        # a differing argmax is accepted only where the reference's own top-2 margin is smaller than twice the logit error MEASURED in
+        # this run (not the tolerance): an id flip at a margin the observed error cannot bridge is a failure
+        ok = ok and bool((g["margin"][bad] < 2 * max(res["forced"]["top8"], res["forced"]["full_rows"])).all())
     res["ok"] = bool(ok)
     diag("stream_" + name, **res)
     return res
@@ -382,6 +384,59 @@ def test_stream_full_size_matches_reference_golden(vox):
     assert res["ref_steps"] >= 380 and res["n_distinct_ref"] > 100, res
     if res["first_mismatch"] is None:
         assert np.array_equal(np.asarray(plain["tokens"]), g["tokens"])
+
+
+# ---------------------------------------------------------------------------------------
+# Round 5: the "realistic statistics" checkpoints (tools/synth_model.c, style -rs): Student-t(3) weights, ~0.5 % outlier channels
+# per residual stream with x30 - 100 columns in wq / wk / w1 / w3 and x3 - 6 spikes in the norm weights in front of them, massive-
+# activation rows in wo / w2 / the adapter, residual gains at the point where the REFERENCE's own logits move by ~1e-3 under a 1e-6
+# perturbation of the audio (tools/amplification.py) - the liveliest checkpoint on which "logits within 1e-3" is still a property
+# of the arithmetic.  Goldens from oracle/_ref (tools/make_golden.py --rs / --only fullrs_*).
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,feed,interval,cont", [("smallrs_batch", None, None, False), ("smallrs_long", None, None, False),
+                                                     ("smallrs_stream", 8000, 0.5, True)])
+def test_rs_small_matches_reference_golden(vox, name, feed, interval, cont):
+    """The real per-layer shapes (2 + 2 layers) on the realistic-statistics weights: 8 s, 95 s in one feed (KV beyond 1024: every
+    member shape of the fused decode step), and BASELINE config 3's feed pattern (25-row encoder chunks through k_skinny)."""
+    g = gold(f"stream_{name}.npz")
+    with vox.Model(model_dir("small-rs")) as m:
+        res = check_stream(name, g, run_case(m, g, feed, interval, cont))
+    assert res["ok"], res
+
+
+def test_rs_full_size_matches_reference_golden(vox):
+    """The headline input through the full 32 + 26 layers on the realistic-statistics checkpoint: ids identical to the reference's,
+    logits within 1e-3, and the batched product decode gives the same ids."""
+    g = gold("stream_fullrs_batch.npz")
+    with vox.Model(model_dir("full-rs")) as m:
+        assert "dec_stack" in m.active_paths()[1]
+        res = check_stream("fullrs_batch", g, run_case(m, g))
+        plain = m.transcribe(golden_audio(g))
+    assert res["ok"], res
+    assert res["ref_steps"] >= 380 and res["n_distinct_ref"] >= 40, res
+    if res["first_mismatch"] is None:
+        assert np.array_equal(np.asarray(plain["tokens"]), g["tokens"])
+
+
+def test_rs_full_size_95s_crosses_every_decode_member_shape(vox):
+    """95 s in one feed on the realistic-statistics checkpoint, ~1150 decoder steps: the decode crosses 512 keys (one-tile -> two-tile
+    attention members inside k_dec_stack) and 1024 keys (k_dec_stack -> one k_ffn_attn12<LONG> launch per layer) - both switch points
+    against the reference itself instead of against the engine's own two-launch path on the damped checkpoint."""
+    g = gold("stream_fullrs_batch95.npz")
+    with vox.Model(model_dir("full-rs")) as m:
+        res = check_stream("fullrs_batch95", g, run_case(m, g))
+    assert res["ok"], res
+    assert res["ref_steps"] > 1100, res
+
+
+def test_rs_full_size_config3_feeds_through_a_restart(vox):
+    """BASELINE config 3's feed pattern (0.5 s feeds, -I 0.5, continuous mode) for 176 s on the realistic-statistics checkpoint:
+    25-row encoder chunks behind a full window, decode up to 2000 keys, the continuous-mode full stream reset, and on again."""
+    g = gold("stream_fullrs_continuous.npz")
+    with vox.Model(model_dir("full-rs")) as m:
+        res = check_stream("fullrs_continuous", g, run_case(m, g, 8000, 0.5, True))
+    assert res["ok"], res
+    assert res["ref_steps"] > 2000, res
 
 
 def test_stream_full_size_real_speech_matches_reference_golden(vox):

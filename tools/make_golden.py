@@ -90,6 +90,27 @@ LONG_CASES = [
 ]
 
 
+# Round 5: the "realistic statistics" checkpoints (tools/synth_model.c, style -rs: Student-t weights, outlier channels with matching
+# norm spikes, massive-activation rows, residual gains at the reproducibility limit - tools/amplification.py).  Preset "<geometry>-rs"
+# = the reference library of <geometry> on the -rs weights.
+RS_CASES = [
+    ("smallrs_batch", "small-rs", 8.0, 4, None, None, False),
+    ("smallrs_long", "small-rs", 95.0, 6, None, None, False),          # > 1024 decoder positions at the real per-layer shapes
+    ("smallrs_stream", "small-rs", 20.0, 7, 8000, 0.5, True),          # config 3's feed pattern: 25-row encoder chunks
+    # the headline input through the full model
+    ("fullrs_batch", "full-rs", 30.0, 0, None, None, False, None, "benchmark/night1968/45s_right_through_the_billboard.wav"),
+]
+RS_LONG_CASES = [
+    # 95 s, one feed: ~1150 decoder steps - crosses 512 keys (one-tile -> two-tile attention members of k_dec_stack) and 1024 keys
+    # (k_dec_stack -> one k_ffn_attn12<LONG> launch per layer) in the middle of the decode
+    ("fullrs_batch95", "full-rs", 30.0, 0, None, None, False, None, "benchmark/night1968/45s_right_through_the_billboard.wav",
+     dict(tile_to=95 * 16000, max_logit_rows=1300, stride=64)),
+    # BASELINE config 3's feed pattern through a continuous-mode restart: 176 s in 0.5 s feeds, -I 0.5 (2204 steps, KV to 2000, full stream reset)
+    ("fullrs_continuous", "full-rs", 30.0, 0, 8000, 0.5, True, None, "benchmark/night1968/45s_right_through_the_billboard.wav",
+     dict(tile_to=176 * 16000, max_logit_rows=2400, stride=160)),
+]
+
+
 MARGIN_EDGES = np.array([0, 1e-4, 3e-4, 1e-3, 3e-3, 1e-2, 3e-2, 1e-1, 3e-1, 1, 1e9], np.float64)
 STRIDE = 16
 
@@ -147,6 +168,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the full-size (8.9 GB) model (minutes of CPU)")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--rs", action="store_true", help="the realistic-statistics cases (small ones in seconds, fullrs_batch in ~10 min)")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     libs = {}
@@ -155,6 +177,10 @@ def main():
         cases += FULL_CASES
     if args.only in [c[0] for c in LONG_CASES]:
         cases += LONG_CASES
+    if args.rs:
+        cases = list(RS_CASES)
+    if args.only in [c[0] for c in RS_CASES + RS_LONG_CASES]:
+        cases = list(RS_CASES) + list(RS_LONG_CASES)
     for case in cases:
         name, preset, secs, aseed, feed, interval, cont = case[:7]
         delay_ms = case[7] if len(case) > 7 else None
@@ -162,17 +188,18 @@ def main():
         extra = case[9] if len(case) > 9 else {}
         if args.only and args.only != name:
             continue
-        if preset not in libs:
-            libs[preset] = RefLib(preset)
-        R = libs[preset]
-        d = vo.PRESETS[preset]
+        geom = preset.split("-")[0]            # "full-rs" = the full geometry's reference library on the -rs weights
+        if geom not in libs:
+            libs[geom] = RefLib(geom)
+        R = libs[geom]
+        d = vo.PRESETS[geom]
         audio, audio_i16 = case_audio(R, wav, secs, aseed)
         if extra.get("tile_to"):
             audio = np.tile(audio, -(-extra["tile_to"] // len(audio)))[:extra["tile_to"]].copy()
         ctx = R.load(model_dir(preset))
         r = R.transcribe_stream(ctx, audio, feed_sizes=feeds_for(feed, len(audio)), interval=interval,
                                 continuous=cont, vocab=d.vocab,
-                                max_logit_rows=extra.get("max_logit_rows", 4096 if preset != "full" else 512),
+                                max_logit_rows=extra.get("max_logit_rows", 4096 if geom != "full" else 512),
                                 delay_ms=delay_ms)
         R.free(ctx)
         out = summarise(r, d.vocab, extra.get("stride"))
@@ -204,7 +231,7 @@ def main():
         return
 
     # ---- stage-level goldens on the tiny model (reference functions called directly) ----
-    if not args.only or args.only == "stage":
+    if (not args.only and not args.rs) or args.only == "stage":
         R = libs.get("tiny") or RefLib("tiny")
         d = vo.PRESETS["tiny"]
         rng = np.random.default_rng(7)

@@ -580,19 +580,23 @@ def test_reference_weight_views_are_filled(small):
     assert abs(c.t_cond[0] - np.cos(6.0)) < 1e-6
 
 
-def test_fp8_decode_weights_track_bf16(vox):
-    """BASELINE config 5: fp8 e4m3 copies (one f32 scale per output row) of the decoder matrices for the decode GEMVs.
-    Not a parity mode: every weight moves by up to 2^-4 relative, so logits move by ~1e-2 and a greedy id can flip wherever
-    the bf16 top-2 margin is smaller than that.  Checked here: first-step logits stay close to the bf16 run (the prefill
-    uses the bf16 weights, so step 0 sees identical inputs), the decode step is faster, and - with the bf16 ids teacher-
-    forced so that every step is comparable - the ids agree on every step whose bf16 top-2 margin exceeds 6x that step's rms fp8
-    logit error; the agreement rate and the margin-conditioned counts go to gpurun_out/diag/fp8_vs_bf16.json."""
-    g = gold("stream_full_batch.npz")
+@pytest.mark.parametrize("preset,golden,min_agree", [("full", "stream_full_batch.npz", 0.94), ("full-rs", "stream_fullrs_batch.npz", 0.93)])
+def test_fp8_decode_weights_track_bf16(vox, preset, golden, min_agree):
+    """BASELINE config 5: fp8 e4m3 copies (one f32 scale per output row) of the decoder matrices for the decode GEMVs, and the
+    prefill on the fp8 MFMA.  Not a parity mode: every weight moves by up to 2^-4 relative, so logits move by ~3e-2 rms and a greedy id
+    can flip wherever the bf16 top-2 margin is smaller than that - BASELINE's own criterion ("tokens match bf16 greedy") does NOT hold
+    on either checkpoint family (free run diverges within the first 100 steps: profiles/r05_fp8_agreement*.json, nine variants incl.
+    128- and 32-block scales, which change nothing: e4m3 is floating point).  Checked here, on the plain and on the realistic-
+    statistics checkpoint: first-step logits stay close to the bf16 run, the decode step is faster, and - with the bf16 ids
+    teacher-forced so that every step is comparable - the ids agree on >= 94 % / 93 % of the steps (measured 96.1 % / 94.8 %) and on
+    EVERY step whose bf16 top-2 margin exceeds 6x that step's rms fp8 logit error."""
+    g = gold(golden)
     audio = golden_audio(g)
-    with vox.Model(model_dir("full")) as m:
+    with vox.Model(model_dir(preset)) as m:
         a = m.transcribe(audio, record_logits=512)
-    with vox.Model(model_dir("full"), weights="fp8") as m8:
+    with vox.Model(model_dir(preset), weights="fp8") as m8:
         assert vox.hip.vox_hip_weight_format(m8.engine) == 1
+        assert "fp8_mfma" in m8.active_paths()[1]
         free = m8.transcribe(audio)
         b = m8.transcribe(audio, record_logits=512, force_tokens=a["tokens"])
         t = m8.time_decoder_step(20, 232)
@@ -610,7 +614,7 @@ def test_fp8_decode_weights_track_bf16(vox):
     tf = np.asarray(free["tokens"])
     nf = min(len(tf), len(ta))
     first_div = next((i for i in range(nf) if tf[i] != ta[i]), nf)
-    diag("fp8_vs_bf16", steps=int(n), agree_teacher_forced=float(agree.mean()), free_run_first_divergence=int(first_div),
+    diag("fp8_vs_bf16_" + preset, steps=int(n), agree_teacher_forced=float(agree.mean()), free_run_first_divergence=int(first_div),
          median_max_logit_err=float(np.median(err)), median_rms_logit_err=float(np.median(rms)), cos_step0=cos0,
          steps_with_safe_margin=int(safe.sum()), disagreements_at_safe_margin=int((~agree & safe).sum()),
          steps_with_margin_3rms=int(safe3.sum()), disagreements_at_margin_3rms=int((~agree & safe3).sum()),
@@ -618,8 +622,8 @@ def test_fp8_decode_weights_track_bf16(vox):
          ms_per_token_fp8=t * 1e3)
     assert cos0 > 0.995, cos0
     assert (~agree & safe).sum() == 0, "fp8 flipped an id whose bf16 margin is 6x the rms fp8 logit error"
-    assert agree.mean() > 0.8, float(agree.mean())
-    assert t < 1.30e-3, t          # bf16 decode is ~1.5 ms/token; half the weight bytes must show
+    assert agree.mean() > min_agree, float(agree.mean())
+    assert t < 1.08e-3, t          # bf16 decode is ~1.26 ms/token; half the weight bytes must show
 
 
 def _decode_after_long_prefill(vox, n_prompt, n_steps, seed, env=None, **model_kw):

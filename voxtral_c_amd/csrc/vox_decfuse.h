@@ -1787,7 +1787,10 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
                 for (int i = 0; i < NWL; i++) {
                     const float o = __shfl_xor(sums[i], 16, 64);
                     const int row = wo_row0 + 2 * i + (lane >> 5);
-                    if ((lane & 31) == 0 && row < wo_row0 + wo_n) a.wo_part[(size_t)g * DF_D + row] = (sums[i] + o) * wo_sc[i];
+                    if ((lane & 31) == 0 && row < wo_row0 + wo_n) {
+                        if (gw) df_store_granule(gw + (size_t)g * DF_D + row, epoch, (sums[i] + o) * wo_sc[i]);
+                        else a.wo_part[(size_t)g * DF_D + row] = (sums[i] + o) * wo_sc[i];
+                    }
                 }
             }
         } else
@@ -1852,6 +1855,10 @@ __global__ __launch_bounds__(FFN_THREADS, 1) void k_ffn_attn12(const FfnArgs f, 
 // pieces, and - new - x' in two hops behind rounds 0 and 1 of W1 / W3 (ffn_body<XP>).  The granule buffers are reused layer after
 // layer; a layer's tag is epoch0 + l.  Reuse is safe without any clearing because every buffer's producers of layer l + 1 depend,
 // through the all-to-all hand-offs in between, on every consumer of layer l having finished: see DESIGN.md 3.
+// bf16 only.  The fp8 form of this kernel (k_dec_stack8: fp8 attention body + an fp8 FFN body with the same two x' hops, built and correct -
+// profiles/r05_fp8_stack.patch) is SLOWER than fp8 mode's two launches per layer: 1.043 / 1.122 / 1.135 against 0.963 / 1.057 / 1.078 ms per
+// step at 232 / 600 / 1000 keys (profiles/r05_fp8_stack_ab.txt) - with half the bytes per piece every hand-off sweep returns before its
+// producers have published, each retry costs a piece time, and the h sweep cannot hide behind 28 MB of W2.
 // Up to 8 key slices (1024 keys).  Beyond, the step stays one k_ffn_attn12<LONG> launch per layer: measured, the long form of this
 // kernel gains nothing there (-1 .. +1 %, profiles/r05_stack_ab.txt) - its attention block ends in a chain of three trips to L2
 // that no weight byte covers, and the boundary it saves is short next to that.

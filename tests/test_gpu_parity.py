@@ -422,6 +422,8 @@ def test_rs_full_size_95s_crosses_every_decode_member_shape(vox):
     """95 s in one feed on the realistic-statistics checkpoint, ~1150 decoder steps: the decode crosses 512 keys (one-tile -> two-tile
     attention members inside k_dec_stack) and 1024 keys (k_dec_stack -> one k_ffn_attn12<LONG> launch per layer) - both switch points
     against the reference itself instead of against the engine's own two-launch path on the damped checkpoint."""
+    if not os.path.exists(os.path.join(GOLDEN, "stream_fullrs_batch95.npz")):
+        pytest.skip("stream_fullrs_batch95.npz not generated yet (tools/make_golden.py --only: 30 - 90 min of reference CPU time)")
     g = gold("stream_fullrs_batch95.npz")
     with vox.Model(model_dir("full-rs")) as m:
         res = check_stream("fullrs_batch95", g, run_case(m, g))
@@ -432,6 +434,8 @@ def test_rs_full_size_95s_crosses_every_decode_member_shape(vox):
 def test_rs_full_size_config3_feeds_through_a_restart(vox):
     """BASELINE config 3's feed pattern (0.5 s feeds, -I 0.5, continuous mode) for 176 s on the realistic-statistics checkpoint:
     25-row encoder chunks behind a full window, decode up to 2000 keys, the continuous-mode full stream reset, and on again."""
+    if not os.path.exists(os.path.join(GOLDEN, "stream_fullrs_continuous.npz")):
+        pytest.skip("stream_fullrs_continuous.npz not generated yet (tools/make_golden.py --only: 30 - 90 min of reference CPU time)")
     g = gold("stream_fullrs_continuous.npz")
     with vox.Model(model_dir("full-rs")) as m:
         res = check_stream("fullrs_continuous", g, run_case(m, g, 8000, 0.5, True))

@@ -1903,19 +1903,25 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     const float scale = 1.0f / sqrtf((float)HD);
     const bool fused = fast && e->use_fused && e->use_dpp;      // the FFN kernels reduce with DPP row sums (self-tested at start-up).  fp8 mode: qkv / wo stay on the bf16 matrices (k_dec_attn_fused), w1;w3 and w2 stream the fp8 copies
     // fused path: key slices of the attention stage (<= 32 per KV head, multiples of 64 keys)
+    int tap_i = -1;
+    for (size_t i = 0; i < e->tap_pos.size(); i++) if (e->tap_pos[i] == kv_pos) tap_i = (int)i;
+    // what the 12-wave shape needs apart from the slice count (bf16 form; fp8 form)
+    const bool pf_ok12 = e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0);
+    const bool static12 = fused && e->merge12 > 0 && e->use_ffn && !e->use_fp8 && !e->sim_on && (e->skip_kinds & ~(1u << PK_W2)) == 0 && tap_i < 0 && pf_ok12;
+    const bool static12_f8 = fused && e->merge12 == 2 && e->use_fp8 && !e->fp8_attn_bf16 && !e->sim_on && (e->skip_kinds & ~(1u << PK_SWIGLU)) == 0 && tap_i < 0 && pf_ok12;
     int f_split = 64, f_ns = 1;
     if (fused) {
         while ((kv_len + f_split - 1) / f_split > DF_BPG) f_split += 64;
-        // the merged launches (k_ffn_attn12 / k_w2x_attn12) take up to 8 key slices: beyond 512 keys, up to merge12_maxkeys, of more than one tile each
-        if (e->merge12 == 2 && kv_len > 512 && kv_len <= e->merge12_maxkeys) f_split = ((kv_len + 7) / 8 + 63) / 64 * 64;
+        // the merged launches (k_dec_stack / k_ffn_attn12 / k_w2x_attn12) take up to 8 key slices: beyond 512 keys, up to merge12_maxkeys, of more than
+        // one tile each - only where such a launch will actually run (debug taps, A/B rungs and the simulated-fp8 study keep the 8-wave
+        // kernel's own schedule: 64-key slices)
+        if (e->merge12 == 2 && (static12 || static12_f8) && kv_len > 512 && kv_len <= e->merge12_maxkeys) f_split = ((kv_len + 7) / 8 + 63) / 64 * 64;
         f_ns = (kv_len + f_split - 1) / f_split;
     }
     // Fused path: the residual stream ping-pongs between two buffers.  k_gemv_w13x's block 0 writes x' = x + sum(wo partials)
     // while the other 255 workgroups may not have fetched x yet - in place that is a race that only bites when workgroups
     // of one launch start far apart (two models sharing the GPU: found by test_two_decoders_sharing_the_gpu_stay_correct).
     float *xin = e->dx, *xalt = e->dx2;
-    int tap_i = -1;
-    for (size_t i = 0; i < e->tap_pos.size(); i++) if (e->tap_pos[i] == kv_pos) tap_i = (int)i;
     auto tap = [&](int slot, const float *src) {      // slot 2l: layer l's input, 2l + 1: after its attention block, 2L: the stack's output
         if (tap_i < 0) return;
         hipMemcpyAsync(e->d_taps + ((size_t)tap_i * (2 * d.dec_layers + 1) + slot) * DD, src, (size_t)DD * 4, hipMemcpyDeviceToDevice, s);
@@ -1923,11 +1929,9 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
     const int tl_layer = 13;          // VOX_HIP_FUSE_TL: the mid-stack layer whose blocks are stamped
     // the 12-wave shape (k_attn12 / k_ffn_attn12): <= 8 key slices (up to merge12_maxkeys keys), 9 .. 32 in its LONG form (round 5); bf16, DPP, no debug hooks
     const bool long12 = f_ns > 8;
-    const bool shape12 = fused && e->merge12 > 0 && e->use_ffn && !e->use_fp8 && !e->sim_on && (f_ns <= 8 || e->merge12_long) && (e->skip_kinds & ~(1u << PK_W2)) == 0 &&
-                         tap_i < 0 && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0));
+    const bool shape12 = static12 && (f_ns <= 8 || e->merge12_long);
     // fp8 mode: the W2 launch of layer l and the (fp8) attention block of layer l + 1 as one launch, same regime
-    const bool shape12_f8 = fused && e->merge12 == 2 && e->use_fp8 && !e->fp8_attn_bf16 && !e->sim_on && f_ns <= 8 && (e->skip_kinds & ~(1u << PK_SWIGLU)) == 0 &&
-                            tap_i < 0 && (e->pf_units == 0 || (e->pf_when == 3 && e->pf_member_units == 0));
+    const bool shape12_f8 = static12_f8 && f_ns <= 8;
     bool attn_done = false;           // this layer's attention block ran at the end of the previous layer's launch (k_ffn_attn12)
     // k_dec_stack: every block of the step's layers in ONE launch - with the embedding gather (embed = 1: attention(0) included) or behind
     // layer 0's own attention launch (embed = 0: the first step after a prefill, whose x is in memory)

@@ -306,6 +306,9 @@ unsigned vox_hip_active_paths(const vox_hip_engine_t *e);
 int vox_hip_fuse_stats(const vox_hip_engine_t *e, int *failures, int *armed, long *rearm_in);
 /* Test hook: the next check after a synchronisation behaves as if a hand-off had timed out. */
 int vox_hip_debug_inject_fuse_timeout(vox_hip_engine_t *e);
+/* Test hook: set the hand-off epoch counter (the tags of the {epoch, value} granules) - e.g. just below the point where
+ * the engine zeroes the granule buffers and restarts it (0xFFF00000).  Returns the previous value via *old (may be NULL). */
+int vox_hip_debug_set_handoff_epoch(vox_hip_engine_t *e, unsigned epoch, unsigned *old);
 /* Test hook: residual-stream taps of the decode steps that run at the listed KV positions (n <= 16): x at the start of every
  * layer, x after every attention block, x after the last layer = [2 L + 1][dec_dim] per position (the inputs of the reference's
  * vox_rms_norm calls inside vox_decoder_forward, voxtral_decoder.c:653-694).  Copied in stream order; the kernels are unchanged.

@@ -124,6 +124,30 @@ def test_in_library_later_chunks_are_sharded_too_and_decoding_overlaps(preset, s
         assert n_sharded == 3, n_sharded
 
 
+@pytest.mark.parametrize("preset,devices", [("small", "0,0,0"), ("tiny", "0,0")])
+def test_in_library_larger_chunk_right_behind_a_sharded_one(preset, devices):
+    """A sharded chunk leaves the last engine's state push (K/V rings, conv history rows, encoder rows) in flight on THAT engine's
+    stream; the next feed is eight times larger, so the stream engine's conv / mel / encoder-row buffers must grow - and a growing
+    buffer is freed and re-allocated.  The pending peer copies have to land first (`settle_enc_fences` in `ensure` / `ensure_keep`,
+    round-4 advisor finding): otherwise the new buffer keeps stale conv history.  Fresh Model per run, so the buffers start small."""
+    import voxtral_c_amd as v
+    audio = synth_speech(90.0, 57)
+    first = (10 * 16000 // 1280) * 1280
+    feeds = [first, len(audio)]
+    win = {} if preset != "tiny" else dict(enc_window=48, dec_window=64)
+    with v.Model(model_dir(preset), **win) as m:
+        want = m.transcribe(audio, feed_sizes=feeds)["tokens"]
+    os.environ["VOX_DEVICES"] = devices
+    try:
+        for _ in range(2):
+            with v.Model(model_dir(preset), **win) as mm:
+                got = mm.transcribe(audio, feed_sizes=feeds)["tokens"]
+                assert mm.ctx.n_sharded_chunks == 2, mm.ctx.n_sharded_chunks
+            assert len(want) > 300 and np.array_equal(got, want), (len(got), len(want))
+    finally:
+        del os.environ["VOX_DEVICES"]
+
+
 def _bench_json(cmd, env, timeout=1500, want_rc=0):
     import json
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)

@@ -563,6 +563,33 @@ def test_fused_decode_fallback_is_a_suspension_not_a_verdict(vox):
     assert np.array_equal(np.asarray(t1), g["tokens"]) and np.array_equal(np.asarray(t2), g["tokens"])
 
 
+@pytest.mark.parametrize("name,below", [("stream_full_batch.npz", 3000), ("stream_full_batch300.npz", 40500)])
+def test_handoff_epoch_counter_restarts_in_mid_decode(vox, name, below):
+    """The {epoch, value} granules of the decode launches are tagged from a 32-bit counter (27 tags per step: ~50 h of decoding), and
+    some slots are written by some step shapes only (key slices 9 .. 32).  Put the counter just below its restart point: the granule
+    buffers are zeroed and the counter restarts about 100 steps into the 30 s clip (inside k_dec_stack's regime) / about 1500 steps into
+    the 300 s clip (one k_ffn_attn12<LONG> launch per layer) - the ids must still be the reference's and no hand-off may time out."""
+    import ctypes as C
+    h = vox.hip
+    h.vox_hip_debug_set_handoff_epoch.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_uint)]
+    h.vox_hip_fuse_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long)]
+    g = gold(name)
+    audio = golden_audio(g)
+    with vox.Model(model_dir("full")) as m:
+        f, a, r = C.c_int(), C.c_int(), C.c_long()
+        if h.vox_hip_fuse_stats(m.engine, C.byref(f), C.byref(a), C.byref(r)) != 0:
+            pytest.skip("engine without the fused decode kernel")
+        old = C.c_uint()
+        assert h.vox_hip_debug_set_handoff_epoch(m.engine, 0xFFF00000 - below, C.byref(old)) == 0
+        got = m.transcribe(audio)["tokens"]
+        assert h.vox_hip_debug_set_handoff_epoch(m.engine, 0xFFF00000 - below // 2, C.byref(old)) == 0
+        assert old.value < 400000, hex(old.value)                 # the counter did restart
+        got2 = m.transcribe(audio)["tokens"]
+        h.vox_hip_fuse_stats(m.engine, C.byref(f), C.byref(a), C.byref(r))
+        assert (f.value, a.value) == (0, 1), (f.value, a.value, r.value)
+    assert np.array_equal(np.asarray(got), g["tokens"]) and np.array_equal(np.asarray(got2), g["tokens"])
+
+
 def test_reference_weight_views_are_filled(small):
     """vox_ctx_t starts with the reference's fields (voxtral.h:154-204): the bf16 views point at the checkpoint's bytes,
     the f32 views hold the load_f32 conversions, the big f32 variants are NULL ("NULL if bf16")."""

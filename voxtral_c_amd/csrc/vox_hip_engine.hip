@@ -1896,6 +1896,15 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                            HD / 2, e->dec_rope, e->dx, (const float *)e->adapter, (const uint16_t *)e->tok_emb, DD, build_embed ? 1 : 0);
         prof_mark(e, PK_BEGIN);
     }
+    // Hand-off granules are tagged with launch epochs (up to 2 per layer and step).  Long before the 32-bit counter runs out (~50 h of
+    // decoding) every granule buffer is zeroed in stream order and the counter restarts: a slot that only some step shapes write (key
+    // slices 9 .. 32, the fp8 forms) must not meet its own old tag again.
+    if (e->fuse_epoch > 0xFFF00000u && e->d_gq) {
+        HC(hipMemsetAsync(e->d_gq, 0, (size_t)DF_GROUPS * DF_GQ * 8, s)); HC(hipMemsetAsync(e->d_gp, 0, (size_t)DF_GROUPS * DF_BPG * DF_GP * 8, s));
+        HC(hipMemsetAsync(e->d_gh, 0, (size_t)FFN_H * 8, s));
+        if (e->d_gx) { HC(hipMemsetAsync(e->d_gx, 0, (size_t)DF_D * 8, s)); HC(hipMemsetAsync(e->d_gw, 0, (size_t)8 * DF_D * 8, s)); HC(hipMemsetAsync(e->d_gxp, 0, (size_t)DF_D * 8, s)); }
+        e->fuse_epoch = 0;
+    }
     const int kv_len = std::min(kv_pos + 1, d.dec_window);
     const int split_keys = fast ? dec_split_keys(kv_len) : DEC_SPLIT_KEYS;
     const int nsplit = (kv_len + split_keys - 1) / split_keys;
@@ -1956,8 +1965,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
         if (embed && ++e->fuse_epoch == 0) e->fuse_epoch = 1;          // (embed = 0: layer 0's attention launch took this epoch already)
         sa.epoch0 = e->fuse_epoch; sa.split_keys = f_split; sa.nsplit = f_ns;
         sa.err = e->d_fuse_err; sa.spin_limit = 500000ull;
-        e->fuse_epoch += (unsigned)d.dec_layers;
-        if (e->fuse_epoch > 0xFFFF0000u) e->fuse_epoch = 1;      // (tags are at most one step old: a restart of the counter cannot meet a stale one)
+        e->fuse_epoch += (unsigned)d.dec_layers;                 // (layer l of the launch tags with epoch0 + l; the counter restarts at the top of a step)
         sa.tl = e->d_fuse_tl; sa.tl_layer = tl_layer;
         if (e->skip_kinds & (1u << PK_W2)) {}        // (timing experiment, kind 6: the step without this launch)
         else if (e->d_fuse_tl) hipLaunchKernelGGL(k_dec_stack<true>, dim3(256), dim3(FFN_THREADS), FA12_LDS_BYTES, s, sa);      // VOX_HIP_FUSE_TL: the instrumented build
@@ -2284,6 +2292,14 @@ extern "C" int vox_hip_fuse_stats(const vox_hip_engine_t *e, int *failures, int 
     if (armed) *armed = e->use_fused ? 1 : 0;
     if (rearm_in) *rearm_in = e->fuse_rearm;
     return e->fused_ok ? 0 : 1;
+}
+extern "C" int vox_hip_debug_set_handoff_epoch(vox_hip_engine_t *e, unsigned epoch, unsigned *old) {
+    if (!e) return -1;
+    HC(hipSetDevice(e->device));
+    HC(esync(e));
+    if (old) *old = e->fuse_epoch;
+    e->fuse_epoch = epoch;
+    return 0;
 }
 // Test hook: make the next check after a synchronisation behave as if a hand-off had timed out (the batch is repeated on
 // the chain, the suspension / re-arm logic runs).  No effect on engines without the fused kernel.

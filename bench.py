@@ -194,7 +194,7 @@ def cpu_baseline(model_dir_full, preset_dims):
         est = t_enc * 1696 / 100 + t_pre + 386 * t_step
         measured = None
         try:       # the unmodified reference CLI run end to end on a GPU-box host (tools/cpu_baseline_cli.py), committed per round
-            for prof in ("r04_cpu_baseline_cli.json", "r03_cpu_baseline_cli.json", "r02_cpu_baseline_cli.json"):
+            for prof in ("r05_cpu_baseline_cli.json", "r04_cpu_baseline_cli.json", "r03_cpu_baseline_cli.json", "r02_cpu_baseline_cli.json"):
                 fp = os.path.join(ROOT, "profiles", prof)
                 if os.path.exists(fp):
                     with open(fp) as fh:
@@ -300,7 +300,7 @@ def roofline_block(v, model, dims, n_tok, weights="bf16", pmc=True, graph_floor=
         traffic, traffic_source = live_pmc_traffic(DOM_KERNEL_SUBSTR)
     if traffic is None:
         why = traffic_source
-        for prof in ("r04_pmc_decode_summary.json", "r03_pmc_decode_summary.json", "r02_pmc_decode_summary.json", "r01_pmc_decode_summary.json"):
+        for prof in ("r05_pmc_decode_summary.json", "r04_pmc_decode_summary.json", "r03_pmc_decode_summary.json", "r02_pmc_decode_summary.json", "r01_pmc_decode_summary.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", prof)) as fh:
                     pm = json.load(fh)["kernels"]

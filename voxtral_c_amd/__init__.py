@@ -13,8 +13,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvoxtral.so")
-HIP_LIB_PATH = os.path.join(_HERE, "libvoxhip.so")
+_LIB_DIR = os.environ.get("VOX_LIB_DIR") or _HERE      # (VOX_LIB_DIR: another build of the two libraries - same-box A/B of a compile-time change, tools/lib_ab.sh)
+LIB_PATH = os.path.join(_LIB_DIR, "libvoxtral.so")
+HIP_LIB_PATH = os.path.join(_LIB_DIR, "libvoxhip.so")
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int)

@@ -1539,6 +1539,14 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
     }
     __syncthreads();                       // xs / nw are dead from here on: scratch for the attention stage
     DF_MARK(5);
+    // A member whose slice has a second tile (513 .. 1024 keys) requests it HERE, behind its own publish and in front of its sweep: the
+    // tile does not depend on q, the other buffer is free, and the sweep's first poll - which would wait for the slowest workgroup's
+    // publish anyway - is what queues behind the 64 KB.  Before (round 5), tile 1 was requested under tile 0's math, i.e. after the sweep,
+    // and its latency stood in the chain: same box, alternating builds, 520 / 600 / 800 / 1000 keys 1.372 / 1.345 / 1.369 / 1.354 ->
+    // 1.346 / 1.333 / 1.346 / 1.330 ms per step (profiles/r05_tile1_early_ab.txt).  Not in the long form: there it costs 0.3 - 0.7 % at
+    // 2500 - 3800 keys (a member's Wo rows are queued behind its partial, and with 32 members per group the slowest publish is later).
+    if (!LONG && att_block && wave < 8 && s_hi - s_lo >= DF_TILE)
+        df_tile_dma(a, g, s_lo + DF_TILE, s_hi, lds_addr(tiles + 2 * DF_TILE_BYTES), lds_addr(tiles + 3 * DF_TILE_BYTES), wave, lane);
     const bool pf_on = !LONG && a.pf.units > 0;
     const int pf_V = 32 * a.pf.units;
     const unsigned pf_lds = lds_addr(tiles) + 53248u + (unsigned)wave * 896u;       // 12 x 896 B behind the Wo reduction scratch (52 KB)
@@ -1585,7 +1593,7 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
             const int t0 = s_lo + ti * DF_TILE;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this tile has landed
             __syncthreads();
-            if (ti + 1 < n_tiles && wave < 8)                         // next tile into the other buffer, under this tile's math
+            if ((LONG || ti > 0) && ti + 1 < n_tiles && wave < 8)     // next tile into the other buffer, under this tile's math (short form: tile 1 was requested above)
                 df_tile_dma(a, g, t0 + DF_TILE, s_hi, lds_addr(tiles + ((ti + 1) & 1) * 2 * DF_TILE_BYTES),
                             lds_addr(tiles + ((ti + 1) & 1) * 2 * DF_TILE_BYTES + DF_TILE_BYTES), wave, lane);
             if (t0 + DF_TILE > pos && t0 <= pos) {

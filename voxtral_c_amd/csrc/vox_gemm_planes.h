@@ -23,8 +23,9 @@
 //   global_load_lds, independent of request contiguity (whole 1 KB runs: same) and of pipeline depth (3 or 4 stages at one
 //   workgroup per CU: slower); with the DMAs removed 114 us.  Staging the same tiles through registers (16-byte loads +
 //   ds_write_b128): 633 us.  TN = 4 (128 x 256 tiles, 1.6 x fewer bytes per MFMA): no faster at M = 1664 (520 tiles on 512
-//   slots).  The 128 x 128 / one-barrier-per-slice structure is transport-bound at ~30 %; going further needs the
-//   256 x 256 deep-pipelined structure, whose tile count (7 x 40) does not fill the chip at the 30 s clip's M.
+//   slots), -5 .. -8 % on the encoder pass of the 300 s clip (M = 16946; round 5: the launchers take it from 600 wide tiles on,
+//   profiles/r05_wide_tiles_ab.txt).  The 128 x 128 / one-barrier-per-slice structure is transport-bound at ~30 %; going further
+//   needs the 256 x 256 deep-pipelined structure, whose tile count (7 x 40) does not fill the chip at the 30 s clip's M.
 #pragma once
 #include "vox_gemm.h"
 
@@ -46,6 +47,13 @@ enum { GP_EPI_STD = 0, GP_EPI_SWIGLU = 1, GP_EPI_ROPE = 2 };
 // (fragment layout: an instruction takes 32 bytes from each of 32 rows, the two k steps of a slice and the next slice share the
 // 128-byte line).  The kernel is bound by the LDS-DMA transport (~15 B/clk/CU, header): this takes the B quarter of every stage
 // (8 of 32 KB at TN = 2) off that path and a quarter of the fragment reads off the LDS.
+// SwiGLU launches: row `row` (0 .. 64 TN - 1) of workgroup bx's B tile -> row of [w1; w3] (N hidden columns each)
+template <int TN>
+__device__ __forceinline__ int gp_swiglu_row(int row, int bx, int N) {
+    const int wn = row / (32 * TN), t = (row >> 5) % TN;
+    return (t & 1) * N + min(bx * (32 * TN) + wn * (16 * TN) + (t >> 1) * 32 + (row & 31), N - 1);
+}
+
 template <int NSTAGE, int TN, int EPI = GP_EPI_STD, bool BD = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gp_smem[];
@@ -92,10 +100,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
             const int row = 16 * (q - 24) + drow;
             int wrow = min(bn0 + row, N - 1);
             if constexpr (EPI == GP_EPI_SWIGLU) {
-                // a workgroup covers 64 hidden columns; tile row r = 64 wn + 32 tn + li holds gate (tn = 0: w1) or up (tn = 1: w3)
-                // of column 64 blockIdx.x + 32 wn + li, so that a lane's two accumulator tiles are the pair the gate needs
-                static_assert(EPI != GP_EPI_SWIGLU || TN == 2, "the SwiGLU epilogue pairs the two N tiles of a wave");
-                wrow = ((row >> 5) & 1) * N + min(bx * 64 + (row >> 6) * 32 + (row & 31), N - 1);
+                // a workgroup covers 32 TN hidden columns; tile row r = 32 TN wn + 32 tn + li holds gate (tn even: w1) or up (tn odd: w3)
+                // of column 32 TN blockIdx.x + 16 TN wn + 32 (tn >> 1) + li, so that a lane's accumulator tiles 2 j, 2 j + 1 are the pair the gate needs
+                static_assert(EPI != GP_EPI_SWIGLU || (TN & 1) == 0, "the SwiGLU epilogue pairs the N tiles of a wave");
+                wrow = gp_swiglu_row<TN>(row, bx, N);
             }
             src[i] = reinterpret_cast<const unsigned char *>(a.W + (size_t)wrow * K) + dchunk * 16;
         }
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
     for (int tt = 0; tt < TN; tt++) {
         const int row = wn * (32 * TN) + tt * 32 + li;               // row of the workgroup's B tile
         int wrow = min(bn0 + row, N - 1);
-        if constexpr (EPI == GP_EPI_SWIGLU) wrow = ((row >> 5) & 1) * N + min(bx * 64 + (row >> 6) * 32 + (row & 31), N - 1);
+        if constexpr (EPI == GP_EPI_SWIGLU) wrow = gp_swiglu_row<TN>(row, bx, N);
         bsrc[tt] = a.W + (size_t)wrow * K + lg * 8;
     }
     uint4 bcur[TN][2], bnxt[TN][2];
@@ -193,21 +201,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
     }
     if constexpr (EPI == GP_EPI_SWIGLU) {
         // h = silu(gate) * up (voxtral_encoder.c:598-606), written as the bf16 planes the W2 launch consumes
-        const int col = bx * 64 + wn * 32 + li;
-        if (col < N) {
 #pragma unroll
-            for (int tm = 0; tm < 2; tm++)
+        for (int j = 0; j < TN / 2; j++) {
+            const int col = bx * (32 * TN) + wn * (16 * TN) + j * 32 + li;
+            if (col < N) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int row = bm0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-                    if (row < M) {
-                        const float hv = silu(acc[tm][0][r]) * acc[tm][1][r];
-                        uint32_t ph, pm, pl;
-                        split3(hv, ph, pm, pl);
-                        uint16_t *dst = a.Yp + (size_t)row * N + col;
-                        dst[0] = (uint16_t)(ph >> 16); dst[a.yp_plane] = (uint16_t)(pm >> 16); dst[2 * a.yp_plane] = (uint16_t)(pl >> 16);
+                for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = bm0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                        if (row < M) {
+                            const float hv = silu(acc[tm][2 * j][r]) * acc[tm][2 * j + 1][r];
+                            uint32_t ph, pm, pl;
+                            split3(hv, ph, pm, pl);
+                            uint16_t *dst = a.Yp + (size_t)row * N + col;
+                            dst[0] = (uint16_t)(ph >> 16); dst[a.yp_plane] = (uint16_t)(pm >> 16); dst[2 * a.yp_plane] = (uint16_t)(pl >> 16);
+                        }
                     }
-                }
+            }
         }
     } else if constexpr (EPI == GP_EPI_ROPE) {
         // + bias, then the interleaved-pair RoPE (voxtral_kernels.c:502-526) on columns < rope_cols: the partner of column c is

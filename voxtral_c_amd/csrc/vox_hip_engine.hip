@@ -464,6 +464,13 @@ static int launch_gemm(vox_hip_engine *e, const float *X, int ldx, const uint16_
     return 0;
 }
 
+// Large chunks (the 300 s / 600 s clips' one-feed encoder passes): 128 x 256 tiles (TN = 4) move 1.6 x fewer bytes per MFMA through
+// LDS than 128 x 128.  Only from 600 such tiles on: with fewer, the last round's tail on the 512 resident workgroups eats the gain
+// (the 30 s clip's w1;w3 is 520 tiles: 29 ms for the encoder pass with wide tiles everywhere against 20.4).  Measured, same box,
+// alternating (profiles/r05_wide_tiles_ab.txt): encoder pass of the 300 s clip 144.9 -> 137.2 ms, ids = the reference's; with the
+// weight fragments loaded straight into registers (BD) on top: 150 ms.
+static bool gp_wide(int tiles_wide) { return tiles_wide >= 600; }
+
 // y = sum_p Xp[p] . W^T on pre-split activations (vox_gemm_planes.h); same epilogue / split-K contract as launch_gemm.
 static int launch_gemm_planes(vox_hip_engine *e, const uint16_t *Xp, size_t plane, int ldxp, const uint16_t *W, float *Y, int ldy,
                               int M, int N, int K, const float *bias, const float *resid, int ldr, int act,
@@ -472,17 +479,32 @@ static int launch_gemm_planes(vox_hip_engine *e, const uint16_t *Xp, size_t plan
     a.Xp = Xp; a.xp_plane = plane; a.ldxp = ldxp;
     if (epi == GP_EPI_SWIGLU) {       // N = hidden columns, W = [w1; w3]; output = bf16 planes of the gated hidden rows
         a.Yp = extra->Yp; a.yp_plane = extra->yp_plane;
+        const int tm_ = (M + GB_M - 1) / GB_M;
+        if (gp_wide(tm_ * ((N + 127) / 128))) {
+            hipLaunchKernelGGL((k_gemm_planes<2, 4, GP_EPI_SWIGLU>), dim3((N + 127) / 128, tm_), dim3(256), (size_t)2 * gp_stage_bytes(4), e->stream, a);
+            return 0;
+        }
         const dim3 grid((N + 63) / 64, (M + GB_M - 1) / GB_M);
         hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_SWIGLU>), grid, dim3(256), (size_t)2 * gp_stage_bytes(2), e->stream, a);
         return 0;
     }
     if (epi == GP_EPI_ROPE) {
         a.rope_tab = extra->rope_tab; a.rope_cols = extra->rope_cols; a.head_dim = extra->head_dim;
+        const int tm_ = (M + GB_M - 1) / GB_M;
+        if (gp_wide(tm_ * ((N + 255) / 256))) {
+            hipLaunchKernelGGL((k_gemm_planes<2, 4, GP_EPI_ROPE>), dim3((N + 255) / 256, tm_), dim3(256), (size_t)2 * gp_stage_bytes(4), e->stream, a);
+            return 0;
+        }
         const dim3 grid((N + 127) / 128, (M + GB_M - 1) / GB_M);
         hipLaunchKernelGGL((k_gemm_planes<2, 2, GP_EPI_ROPE>), grid, dim3(256), (size_t)2 * gp_stage_bytes(2), e->stream, a);
         return 0;
     }
     if (M <= 0 || N <= 0) return 0;
+    if (gp_wide(((M + GB_M - 1) / GB_M) * ((N + 255) / 256))) {
+        a.ksplit = 1;
+        hipLaunchKernelGGL((k_gemm_planes<2, 4>), dim3((N + 255) / 256, (M + GB_M - 1) / GB_M), dim3(256), (size_t)2 * gp_stage_bytes(4), e->stream, a);
+        return 0;
+    }
     constexpr int TN = 2, st = 2;          // MFMA tiles per wave along N: 128 x 128 workgroup tile
     const int BN = 64 * TN;
     const int tn = (N + BN - 1) / BN, tm = (M + GB_M - 1) / GB_M, nk = K / GP_K;
@@ -2953,7 +2975,9 @@ static int self_test(vox_hip_engine *e) {
         bool okp = hipFuncSetAttribute((const void *)k_gemm_planes<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(2)) == hipSuccess &&
                    hipFuncSetAttribute((const void *)k_gemm_planes<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(4)) == hipSuccess &&
                    hipFuncSetAttribute((const void *)k_gemm_planes<2, 2, GP_EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(2)) == hipSuccess &&
-                   hipFuncSetAttribute((const void *)k_gemm_planes<2, 2, GP_EPI_ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(2)) == hipSuccess;
+                   hipFuncSetAttribute((const void *)k_gemm_planes<2, 2, GP_EPI_ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(2)) == hipSuccess &&
+                   hipFuncSetAttribute((const void *)k_gemm_planes<2, 4, GP_EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(4)) == hipSuccess &&
+                   hipFuncSetAttribute((const void *)k_gemm_planes<2, 4, GP_EPI_ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gp_stage_bytes(4)) == hipSuccess;
         uint16_t *dp = nullptr;
         okp = okp && hipMalloc((void **)&dp, (size_t)3 * M * K * 2) == hipSuccess;
         if (okp) {

@@ -1079,6 +1079,31 @@ def test_rowsgemm_matches_the_scalar_reference_kernel(tiny, M, K, N):
         assert err < 5e-5, (impl, err, np.nonzero(np.abs(y - ref).max(axis=1) > 5e-5)[0][:16])
 
 
+@pytest.mark.parametrize("M,K,N", [(129, 1280, 1280), (300, 1280, 6144), (1664, 1280, 5120), (3840, 1280, 5120), (3900, 1280, 4992), (2500, 5120, 1280),
+                                   (19300, 1280, 1280), (77, 64, 96)])
+def test_gemm_planes_both_tile_widths_match_the_scalar_reference_kernel(tiny, M, K, N):
+    """k_gemm_planes (vox_gemm_planes.h: the large-M GEMM on producer-split bf16 planes) against the plain fp32 FMA kernel (impl 3)
+    on the same device: the 128 x 128 tiles (with and without split-K) and, from 600 wide tiles on (round 5: the 300 s / 600 s
+    clips' encoder passes), the 128 x 256 tiles; M and N that are not multiples of the tile; the plain epilogue (impl 8: + bias)
+    and the SwiGLU launch (impl 9: w = [w1; w3], result read back from the three bf16 planes it writes)."""
+    rng = np.random.default_rng(M * 17 + K + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = vo.f32_to_bf16((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    b = rng.standard_normal(N).astype(np.float32)
+    ref = tiny.linear_bf16(x, w, b, impl=3)
+    y = tiny.linear_bf16(x, w, b, impl=8)
+    err = float(np.abs(y - ref).max())
+    assert err < 5e-5, (err, np.nonzero(np.abs(y - ref).max(axis=1) > 5e-5)[0][:16])
+    if N % 128 == 0:
+        h = N // 2
+        gu = tiny.linear_bf16(x, w, None, impl=3)            # rows 0 .. h - 1 of w as w1 (gate), h .. N - 1 as w3 (up)
+        g = gu[:, :h].astype(np.float64)
+        want = (g / (1.0 + np.exp(-g)) * gu[:, h:].astype(np.float64)).astype(np.float32)
+        got = tiny.linear_bf16(x, w, None, impl=9)
+        err = float(np.abs(got - want).max())
+        assert got.shape == want.shape and err < 1e-4, (err, np.nonzero(np.abs(got - want).max(axis=1) > 1e-4)[0][:16])
+
+
 @pytest.mark.parametrize("M,K,N", [(1, 3072, 6144), (16, 3072, 6144), (17, 4096, 3072), (38, 3072, 6144), (38, 4096, 3072), (38, 3072, 18432),
                                    (38, 9216, 3072), (48, 3072, 512), (49, 1280, 1000), (64, 9216, 3072), (33, 192, 96)])
 def test_fp8_mfma_rowsgemm_matches_the_dequantised_reference(tiny, M, K, N):

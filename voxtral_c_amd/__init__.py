@@ -321,7 +321,7 @@ class Model:
         x = np.ascontiguousarray(x, np.float32)
         w = np.ascontiguousarray(w_bf16, np.uint16)
         M, K = x.shape
-        N = w.shape[0]
+        N = w.shape[0] // 2 if impl == 9 else w.shape[0]          # impl 9 (SwiGLU launch of k_gemm_planes): w = [w1; w3]
         y = np.empty((M, N), np.float32)
         b = None if bias is None else np.ascontiguousarray(bias, np.float32)
         rc = hip.vox_hip_linear_bf16(self.engine, _fp(y), _fp(x), w.ctypes.data_as(u16p),

@@ -2494,15 +2494,21 @@ extern "C" void vox_hip_add_encode_ms(vox_hip_engine_t *e, double ms) { if (e &&
 // ------------------------------------------------------------------------------------
 // kernel-level test / bench surface
 // ------------------------------------------------------------------------------------
+// y[i] = hi + mid + lo of the bf16 planes p[0 .. 2][i] (test surface: reads a planes-writing epilogue's result back as f32)
+__global__ void k_planes_sum(float *y, const uint16_t *p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = (__uint_as_float((uint32_t)p[i] << 16) + __uint_as_float((uint32_t)p[n + i] << 16)) + __uint_as_float((uint32_t)p[2 * n + i] << 16);
+}
 extern "C" int vox_hip_linear_bf16(vox_hip_engine_t *e, float *y, const float *x, const uint16_t *w, const float *bias,
                                    int M, int K, int N, int impl) {
     if (!e) return -1;
     HC(hipSetDevice(e->device));
     float *dx = nullptr, *dy = nullptr, *db = nullptr; uint16_t *dw = nullptr;
     HC(hipMalloc((void **)&dx, (size_t)M * K * 4)); HC(hipMalloc((void **)&dy, (size_t)M * N * 4));
-    HC(hipMalloc((void **)&dw, (size_t)N * K * 2));
+    const size_t wrows = impl == 9 ? 2 * (size_t)N : (size_t)N;
+    HC(hipMalloc((void **)&dw, wrows * K * 2));
     HC(hipMemcpy(dx, x, (size_t)M * K * 4, hipMemcpyHostToDevice));
-    HC(hipMemcpy(dw, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    HC(hipMemcpy(dw, w, wrows * K * 2, hipMemcpyHostToDevice));
     if (bias) { HC(hipMalloc((void **)&db, (size_t)N * 4)); HC(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice)); }
     if (impl == 4 || impl == 5) {
         // test surface of k_rowsgemm (vox_rowsgemm.h): 4 = activations as bf16 planes, 5 = f32 rows; partials added by k_splitk_reduce
@@ -2537,6 +2543,24 @@ extern "C" int vox_hip_linear_bf16(vox_hip_engine_t *e, float *y, const float *x
         }
         HC(esync(e));
         hipFree(dq); hipFree(dsc); if (part) hipFree(part);
+    } else if (impl == 8 || impl == 9) {
+        // test surface of k_gemm_planes (vox_gemm_planes.h), both tile widths (128 x 128; 128 x 256 from 600 wide tiles on):
+        // 8 = y = x W^T + bias;  9 = the SwiGLU launch: w holds [w1; w3] (2 N rows), y[M][N] = silu(x w1^T) * (x w3^T), read back
+        // as the sum of the three bf16 planes the kernel writes (exact: the planes are the 3-term split of the f32 value)
+        if (K % GP_K || (impl == 9 && N % 64)) { g_err = "vox_hip_linear_bf16: impl 8 / 9 need K % 32 == 0 (9: N % 64 == 0)"; return -1; }
+        uint16_t *dp = nullptr, *dh = nullptr;
+        HC(hipMalloc((void **)&dp, (size_t)3 * M * K * 2));
+        hipLaunchKernelGGL(k_split_planes, dim3(grid1d((size_t)M * K / 4)), dim3(256), 0, e->stream, dp, (size_t)M * K, (const float *)dx, K, M, K);
+        if (impl == 8) {
+            if (launch_gemm_planes(e, dp, (size_t)M * K, K, dw, dy, N, M, N, K, db, nullptr, 0, ACT_NONE)) return -1;
+        } else {
+            HC(hipMalloc((void **)&dh, (size_t)3 * M * N * 2));
+            GemmArgs ex{}; ex.Yp = dh; ex.yp_plane = (size_t)M * N;
+            if (launch_gemm_planes(e, dp, (size_t)M * K, K, dw, nullptr, 0, M, N, K, nullptr, nullptr, 0, ACT_NONE, GP_EPI_SWIGLU, &ex)) return -1;
+            hipLaunchKernelGGL(k_planes_sum, dim3(grid1d((size_t)M * N)), dim3(256), 0, e->stream, dy, (const uint16_t *)dh, (size_t)M * N);
+        }
+        HC(esync(e));
+        hipFree(dp); if (dh) hipFree(dh);
     } else if (linear_dev(e, dy, N, dx, K, dw, db, M, K, N, ACT_NONE, nullptr, 0, impl)) return -1;
     HC(esync(e));
     HC(hipGetLastError());

@@ -220,7 +220,9 @@ __device__ __forceinline__ f32x16 ab_mfma6(const bf16x8_t (&a)[3], const bf16x8_
     return c;
 }
 
-__global__ __launch_bounds__(256) void k_attn_enc_bf16(const AttnArgs a) {
+// (256, 3): 168 registers instead of 182 + 32 accumulation registers, no spills, a third workgroup per CU: nothing at the 30 s clip's
+// 416 workgroups (20.9 -> 20.8 ms per encoder pass), -3.3 % on the 300 s clip's pass (140.0 -> 135.4 ms; profiles/r05_attn_occ_ab.txt)
+__global__ __launch_bounds__(256, 3) void k_attn_enc_bf16(const AttnArgs a) {
     constexpr int HD = 64, TK = 32;
     constexpr int KROW = 144, KPL = TK * KROW;          // bytes per K row / plane
     constexpr int VROW = 72, VPL = HD * VROW;           // bytes per V^T row / plane

@@ -42,11 +42,6 @@ constexpr int gp_stage_bytes(int TN) { return 3 * GP_PLANE_BYTES + 64 * TN * GP_
 // TN = 4 shares every A fragment between four B tiles (10 reads per 24 MFMAs).
 enum { GP_EPI_STD = 0, GP_EPI_SWIGLU = 1, GP_EPI_ROPE = 2 };
 
-// BD ("B direct", round 3): the weight fragments do not go through LDS at all - a lane's B operand (W[col][k .. k + 7], 16 bytes)
-// is loaded straight from global memory into the register the MFMA reads, one slice ahead, with plain (L1-allocating) loads
-// (fragment layout: an instruction takes 32 bytes from each of 32 rows, the two k steps of a slice and the next slice share the
-// 128-byte line).  The kernel is bound by the LDS-DMA transport (~15 B/clk/CU, header): this takes the B quarter of every stage
-// (8 of 32 KB at TN = 2) off that path and a quarter of the fragment reads off the LDS.
 // SwiGLU launches: row `row` (0 .. 64 TN - 1) of workgroup bx's B tile -> row of [w1; w3] (N hidden columns each)
 template <int TN>
 __device__ __forceinline__ int gp_swiglu_row(int row, int bx, int N) {
@@ -54,6 +49,11 @@ __device__ __forceinline__ int gp_swiglu_row(int row, int bx, int N) {
     return (t & 1) * N + min(bx * (32 * TN) + wn * (16 * TN) + (t >> 1) * 32 + (row & 31), N - 1);
 }
 
+// BD ("B direct", round 3): the weight fragments do not go through LDS at all - a lane's B operand (W[col][k .. k + 7], 16 bytes)
+// is loaded straight from global memory into the register the MFMA reads, one slice ahead, with plain (L1-allocating) loads
+// (fragment layout: an instruction takes 32 bytes from each of 32 rows, the two k steps of a slice and the next slice share the
+// 128-byte line).  The kernel is bound by the LDS-DMA transport (~15 B/clk/CU, header): this takes the B quarter of every stage
+// (8 of 32 KB at TN = 2) off that path and a quarter of the fragment reads off the LDS.
 template <int NSTAGE, int TN, int EPI = GP_EPI_STD, bool BD = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gp_smem[];

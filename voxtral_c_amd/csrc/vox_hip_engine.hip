@@ -2266,8 +2266,9 @@ static int fused_failed(vox_hip_engine *e) {
     e->use_fused = false; e->fuse_failures++;
     static const bool no_rearm = vox_disabled("rearm");
     e->fuse_rearm = no_rearm ? 0 : FUSE_REARM_STEPS << std::min(e->fuse_failures - 1, 6);
-    fprintf(stderr, "vox_hip: ERROR fused decode kernel timed out in hand-off %u (its 256 workgroups were not co-resident?); "
-                    "repeating the work on the launch-per-GEMV chain%s\n", err,
+    fprintf(stderr, "vox_hip: ERROR fused decode kernel timed out in hand-off %u (its 256 workgroups were not co-resident?) in the batch "
+                    "of decoder steps from position %d on (hand-off epoch counter %u after it); repeating the work on the launch-per-GEMV chain%s\n",
+            err, e->dec_pos, e->fuse_epoch,
             e->fuse_rearm ? " and staying there for a while before the fused kernel is tried again" : " and staying there");
     (void)hipMemset(e->d_fuse_err, 0, sizeof(unsigned));
     return 1;

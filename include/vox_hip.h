@@ -291,11 +291,12 @@ enum vox_hip_path {
     VOX_PATH_ROWSGEMM         = 1u << 11,  /* 33 .. 128-row passes (decoder prefill, encoder flush) on the weight-streaming MFMA kernel k_rowsgemm */
     VOX_PATH_FFN_ATTN12       = 1u << 12,  /* decode step: FFN block of layer l + attention block of layer l + 1 as ONE launch (k_ffn_attn12, every context length since round 5; fp8: k_w2x_attn12 up to 1024 keys) */
     VOX_PATH_DEC_STACK        = 1u << 13,  /* decode step: FFN(0) and the attention + FFN blocks of layers 1 .. L-1 as ONE launch (k_dec_stack): 4 launches per token */
+    VOX_PATH_ENC_STACK        = 1u << 15,  /* streaming encoder chunks (<= 32 rows): all layers of a chunk as ONE persistent launch (k_enc_stack, round 6); VOX_PATH_SKINNY_ENC's launches are its fallback */
     VOX_PATH_FP8_MFMA         = 1u << 14,  /* fp8 mode (config 5 only): the decoder prefill multiplies on the fp8 MFMA (k_rowsgemm_f8: e4m3 weights, activations as two e4m3 terms) */
 };
 #define VOX_PATH_ALL_BF16 (VOX_PATH_GEMM_MFMA_BF16X3 | VOX_PATH_GEMM_MFMA_F32 | VOX_PATH_GEMM_SPLITK | \
                            VOX_PATH_ATTN_ENC_MFMA | VOX_PATH_ATTN_DEC_DPP | VOX_PATH_GEMV3 | VOX_PATH_DEC_FUSED | VOX_PATH_SKINNY_ENC | \
-                           VOX_PATH_GEMM_PLANES | VOX_PATH_FFN_FUSED | VOX_PATH_ROWSGEMM | VOX_PATH_FFN_ATTN12 | VOX_PATH_DEC_STACK)
+                           VOX_PATH_GEMM_PLANES | VOX_PATH_FFN_FUSED | VOX_PATH_ROWSGEMM | VOX_PATH_FFN_ATTN12 | VOX_PATH_DEC_STACK | VOX_PATH_ENC_STACK)
 unsigned vox_hip_active_paths(const vox_hip_engine_t *e);
 
 /* The fused decode kernel (VOX_PATH_DEC_FUSED) needs its 256 workgroups co-resident; a hand-off that times out (another
@@ -304,6 +305,17 @@ unsigned vox_hip_active_paths(const vox_hip_engine_t *e);
  * failures = time-outs so far, armed = 1 if the fused kernel is live now, rearm_in = steps left of a suspension.
  * Returns 0 if the engine has the fused kernel at all, 1 if not, -1 on error. */
 int vox_hip_fuse_stats(const vox_hip_engine_t *e, int *failures, int *armed, long *rearm_in);
+/* Diagnosis: the bounded spins of the decode launches budget ACTIVE waiting time (gaps between consecutive polls, each capped at
+ * 40 us), so that a dispatch that was switched out for milliseconds (more HSA queues in the process than the hardware scheduler
+ * maps) does not read as a time-out.  Holes (> 1 ms between two polls) are counted: *count = how many so far, *longest_us = the
+ * longest.  Returns 0, -1 on error / no fused kernels. */
+int vox_hip_spin_holes(vox_hip_engine_t *e, unsigned long long *count, double *longest_us);
+/* The encoder stack kernel (VOX_PATH_ENC_STACK, k_enc_stack) needs its 256 workgroups co-resident too; a hand-off that times out makes
+ * the engine repeat the chunk on the launch-per-GEMM path (VOX_PATH_SKINNY_ENC) and suspend the stack kernel for 64 chunks (doubling).
+ * launches / failures so far, armed = 1 if it is live now.  vox_hip_debug_inject_enc_stack_timeout: test hook, the next chunk's check
+ * behaves as if a hand-off had timed out. */
+int vox_hip_enc_stack_stats(const vox_hip_engine_t *e, long *launches, int *failures, int *armed);
+int vox_hip_debug_inject_enc_stack_timeout(vox_hip_engine_t *e);
 /* Test hook: the next check after a synchronisation behaves as if a hand-off had timed out. */
 int vox_hip_debug_inject_fuse_timeout(vox_hip_engine_t *e);
 /* Test hook: set the hand-off epoch counter (the tags of the {epoch, value} granules) - e.g. just below the point where

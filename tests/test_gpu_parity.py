@@ -576,29 +576,26 @@ def test_handoff_epoch_counter_restarts_in_mid_decode(vox, name, below):
     g = gold(name)
     audio = golden_audio(g)
 
-    def attempt():
-        with vox.Model(model_dir("full")) as m:
-            f, a, r = C.c_int(), C.c_int(), C.c_long()
-            if h.vox_hip_fuse_stats(m.engine, C.byref(f), C.byref(a), C.byref(r)) != 0:
-                pytest.skip("engine without the fused decode kernel")
-            old = C.c_uint()
-            assert h.vox_hip_debug_set_handoff_epoch(m.engine, 0xFFF00000 - below, C.byref(old)) == 0
-            got = m.transcribe(audio)["tokens"]
-            assert h.vox_hip_debug_set_handoff_epoch(m.engine, 0xFFF00000 - below // 2, C.byref(old)) == 0
-            assert old.value < 400000, hex(old.value)                 # the counter did restart
-            got2 = m.transcribe(audio)["tokens"]
-            h.vox_hip_fuse_stats(m.engine, C.byref(f), C.byref(a), C.byref(r))
-        # the ids are the reference's whether or not a hand-off timed out (a time-out repeats the batch on the chain)
-        assert np.array_equal(np.asarray(got), g["tokens"]) and np.array_equal(np.asarray(got2), g["tokens"])
-        return f.value, a.value, r.value
-
-    # A time-out caused by the restart would come back at the same steps every time (the counter is set, the clip is fixed); one caused
-    # by something else holding CUs for a few milliseconds (another tenant on the GPU) would not.  So: one repetition, which must be clean.
-    first = attempt()
-    if first[:2] != (0, 1):
-        diag(f"epoch_restart_retry_{name}", first_attempt=first)
-        second = attempt()
-        assert second[:2] == (0, 1), (first, second)
+    h.vox_hip_spin_holes.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_double)]
+    with vox.Model(model_dir("full")) as m:
+        f, a, r = C.c_int(), C.c_int(), C.c_long()
+        if h.vox_hip_fuse_stats(m.engine, C.byref(f), C.byref(a), C.byref(r)) != 0:
+            pytest.skip("engine without the fused decode kernel")
+        old = C.c_uint()
+        assert h.vox_hip_debug_set_handoff_epoch(m.engine, 0xFFF00000 - below, C.byref(old)) == 0
+        got = m.transcribe(audio)["tokens"]
+        assert h.vox_hip_debug_set_handoff_epoch(m.engine, 0xFFF00000 - below // 2, C.byref(old)) == 0
+        assert old.value < 400000, hex(old.value)                 # the counter did restart
+        got2 = m.transcribe(audio)["tokens"]
+        h.vox_hip_fuse_stats(m.engine, C.byref(f), C.byref(a), C.byref(r))
+        holes, longest = C.c_ulonglong(), C.c_double()
+        assert h.vox_hip_spin_holes(m.engine, C.byref(holes), C.byref(longest)) == 0
+    # Round 6: no retry.  The recovered time-outs round 5 saw here (long test processes only) were holes in the dispatch's own run
+    # time - the process's queues switched out for milliseconds - read as waiting by a wall-clock difference; the spins budget ACTIVE
+    # time now (vox_decfuse.h, "bounded spins") and count the holes they see, which this test records next to its verdict.
+    diag(f"epoch_restart_{name}", failures=f.value, armed=a.value, spin_holes=int(holes.value), longest_hole_us=float(longest.value))
+    assert np.array_equal(np.asarray(got), g["tokens"]) and np.array_equal(np.asarray(got2), g["tokens"])
+    assert (f.value, a.value) == (0, 1), (f.value, a.value, r.value, holes.value, longest.value)
 
 
 def test_reference_weight_views_are_filled(small):
@@ -1140,6 +1137,93 @@ def test_fp8_mfma_rowsgemm_matches_the_dequantised_reference(tiny, M, K, N):
     diag(f"fp8_rowsgemm_{M}_{K}_{N}", max_err_over_rms_y=err, rms_err_over_rms_y=rms, weight_quantisation_rms_err_over_rms_y=qerr)
     assert rms < 4e-3 and err < 0.15, (rms, err, qerr)          # (max over ~1e5 outputs of heavy-tailed rows, in units of rms(y))
     assert rms < 0.25 * qerr + 1e-4, (rms, qerr)
+
+
+def _enc_stack_stats(vox, m):
+    import ctypes as C
+    h = vox.hip
+    h.vox_hip_enc_stack_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    n, f, a = C.c_long(), C.c_int(), C.c_int()
+    assert h.vox_hip_enc_stack_stats(m.engine, C.byref(n), C.byref(f), C.byref(a)) == 0
+    return n.value, f.value, a.value
+
+
+@pytest.mark.parametrize("preset", ["small", "small-rs"])
+def test_encoder_stack_kernel_matches_the_launch_per_gemm_path(vox, preset):
+    """Round 6: streaming-size chunks (1 .. 32 rows) through k_enc_stack - all layers of a chunk as ONE persistent launch, hand-offs
+    inside (vox_encstack.h; reference voxtral_encoder.c:452-636) - against the 8-launches-per-layer path (VOX_HIP_DISABLE=enc_stack) on
+    the same inputs: 1, 8, 16, 25 and 32 rows on a cold window, behind a big first chunk, and 40 consecutive 25-row chunks (1000
+    positions: the 750-position window slides and the 832-slot K/V rings wrap).  Same arithmetic up to summation order and the place
+    where 1 / rms is applied: 2e-5 relative on the plain checkpoint, 5e-5 on the realistic-statistics one (outlier channels).  No
+    hand-off may time out, and every chunk must really have taken the stack kernel."""
+    ma = vox.Model(model_dir(preset))
+    os.environ["VOX_HIP_DISABLE"] = "enc_stack"
+    try:
+        mb = vox.Model(model_dir(preset))
+    finally:
+        del os.environ["VOX_HIP_DISABLE"]
+    d = ma.dims
+    tol = 2e-5 if preset == "small" else 5e-5
+    worst = 0.0
+    try:
+        if "enc_stack" not in ma.active_paths()[1]:
+            pytest.skip("engine without the encoder stack kernel (not the 4B encoder shapes / not a 256-CU part)")
+        assert "enc_stack" not in mb.active_paths()[1]
+        chunks = 0
+        for sizes in ([1], [8], [16], [25], [32], [25, 1, 32, 16, 8, 25, 17], [800, 25, 25, 3], [25] * 40):
+            outs = []
+            for m in (ma, mb):
+                m.reset_encoder(); m.reset_counters()
+                rr = np.random.default_rng(7 + sum(sizes))
+                outs.append([m.encoder_forward_incremental(rr.standard_normal((n, d.enc_dim)).astype(np.float32)) for n in sizes])
+            chunks += sum(1 for n in sizes if n <= 32)
+            for i, (n, a, b) in enumerate(zip(sizes, outs[0], outs[1])):
+                assert np.isfinite(a).all()
+                e = float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+                worst = max(worst, e)
+                assert e < tol, ("encoder", sizes[:8], i, n, e)
+        launches, failures, armed = _enc_stack_stats(vox, ma)
+        assert (failures, armed) == (0, 1), (launches, failures, armed)
+        assert launches == chunks, (launches, chunks)
+        assert _enc_stack_stats(vox, mb)[0] == 0
+    finally:
+        ma.close(); mb.close()
+    diag(f"enc_stack_vs_launches_{preset}", worst_rel=worst)
+
+
+def test_encoder_stack_timeout_repeats_the_chunk_on_the_launch_path(vox):
+    """A flagged chunk (a hand-off of k_enc_stack timed out: injected) is repeated from the same rows on the launch-per-GEMM path, the
+    stack kernel is suspended for 64 chunks and then comes back; the outputs are those of an engine that never had it."""
+    import ctypes as C
+    ma = vox.Model(model_dir("small"))
+    os.environ["VOX_HIP_DISABLE"] = "enc_stack"
+    try:
+        mb = vox.Model(model_dir("small"))
+    finally:
+        del os.environ["VOX_HIP_DISABLE"]
+    try:
+        if "enc_stack" not in ma.active_paths()[1]:
+            pytest.skip("engine without the encoder stack kernel")
+        d = ma.dims
+        rr = np.random.default_rng(5)
+        xs = [rr.standard_normal((25, d.enc_dim)).astype(np.float32) for _ in range(70)]
+        vox.hip.vox_hip_debug_inject_enc_stack_timeout.argtypes = [C.c_void_p]
+        outs_a, outs_b = [], []
+        for i, x in enumerate(xs):
+            if i == 2:
+                assert vox.hip.vox_hip_debug_inject_enc_stack_timeout(ma.engine) == 0
+            outs_a.append(ma.encoder_forward_incremental(x))
+            outs_b.append(mb.encoder_forward_incremental(x))
+            if i == 2:
+                assert _enc_stack_stats(vox, ma)[1:] == (1, 0)
+        for i, (a, b) in enumerate(zip(outs_a, outs_b)):
+            e = float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+            assert e < 2e-5, (i, e)
+        assert np.array_equal(outs_a[2], outs_b[2])        # the repeated chunk IS the launch path's
+        launches, failures, armed = _enc_stack_stats(vox, ma)
+        assert failures == 1 and armed == 1 and launches == 3 + (70 - 3 - 64), (launches, failures, armed)
+    finally:
+        ma.close(); mb.close()
 
 
 def test_few_rows_paths_agree_with_the_large_m_paths(vox):

@@ -191,7 +191,7 @@ def _fp(a):
 # vox_hip.h enum vox_hip_path
 PATHS = {"gemm_mfma_bf16x3": 1 << 0, "gemm_mfma_f32": 1 << 1, "gemm_splitk": 1 << 2, "attn_enc_mfma": 1 << 3,
          "attn_dec_dpp": 1 << 4, "gemv3": 1 << 5, "fp8_decode": 1 << 6, "skinny_enc": 1 << 7, "dec_fused": 1 << 8,
-         "gemm_planes": 1 << 9, "ffn_fused": 1 << 10, "rowsgemm": 1 << 11, "ffn_attn12": 1 << 12, "dec_stack": 1 << 13, "fp8_mfma": 1 << 14}
+         "gemm_planes": 1 << 9, "ffn_fused": 1 << 10, "rowsgemm": 1 << 11, "ffn_attn12": 1 << 12, "dec_stack": 1 << 13, "fp8_mfma": 1 << 14, "enc_stack": 1 << 15}
 PATH_ALL_BF16 = sum(v for k, v in PATHS.items() if k not in ("fp8_decode", "fp8_mfma"))
 
 

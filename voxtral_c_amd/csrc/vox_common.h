@@ -121,6 +121,37 @@ __device__ __forceinline__ float dot16_fp8(const uint4 w, const float4 x0, const
 }
 
 
+// ---- bounded spins (round 6) --------------------------------------------------------------------------------------------------
+// A hand-off takes microseconds; a spin that has WAITED for spin_limit ticks (5 ms) means a producer is not running (the 256
+// workgroups are not co-resident) and flags the batch.  What must not count as waiting is time in which the spinning wave itself
+// did not run: when the process has more HSA queues than the hardware scheduler maps (long test processes: every engine and every
+// torch stream ever created), the queue is time-sliced - the whole dispatch is saved, another queue runs for milliseconds, the
+// dispatch is restored - and a wall-clock difference taken across that hole says "5 ms" although every producer was frozen as
+// well.  So the spin budget is ACTIVE time: the sum of the gaps between consecutive polls, each capped at DF_GAP_CAP (a poll of
+// these loops takes 1 - 3 us; a gap of more than 40 us is a hole, not a wait).  Holes are recorded in err[8..9] (largest gap,
+// count) whether or not anything times out, and a time-out records who, where and what it saw in err[1..7] for the host's message.
+constexpr unsigned long long DF_GAP_CAP = 4000ull;          // 40 us at the 100 MHz wall clock
+constexpr unsigned long long DF_HOLE = 100000ull;           // gaps beyond 1 ms are reported as holes
+struct DfSpin { unsigned last, active, maxgap; };            // (32-bit ticks: differences of the low word are all that is used)
+__device__ __forceinline__ void df_spin_begin(DfSpin &s) { s.last = (unsigned)wall_clock64(); s.active = 0; s.maxgap = 0; }
+// One poll has failed: true = the budget is spent (err is set and the caller gives up), false = poll again.
+__device__ __forceinline__ bool df_spin_expired(DfSpin &s, unsigned *err, unsigned long long spin_limit, unsigned code, unsigned epoch) {
+    const unsigned now = (unsigned)wall_clock64(), d = now - s.last;
+    s.last = now;
+    if (d > s.maxgap) s.maxgap = d;
+    if (d > (unsigned)DF_HOLE) {
+        __hip_atomic_fetch_max(err + 8, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(err + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s.active += d < (unsigned)DF_GAP_CAP ? d : (unsigned)DF_GAP_CAP;
+    if (s.active <= (unsigned)spin_limit) return false;
+    if (__hip_atomic_exchange(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {      // the first reporter describes itself
+        err[1] = blockIdx.x; err[2] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);       // HW_REG_XCC_ID
+        err[3] = s.maxgap; err[4] = s.active; err[6] = epoch; err[7] = threadIdx.x;
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Tuning aid (VOX_HIP_FUSE_TL): per-workgroup timeline of one launch, 16 words per workgroup: [0] wall clock at entry,
 // [1] at exit, [2] (XCC_ID << 32) | HW_ID, [3 ..] the kernel's phase stamps - start skew, tails, XCD placement and where

@@ -126,6 +126,7 @@ __device__ __forceinline__ u64 df_load_granule(const u64 *g) {
 // live across it - hundreds of spilled registers.  Laundered once per body entry, the arithmetic stays where it is written.
 __device__ __forceinline__ int df_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
 __device__ __forceinline__ int df_bid() { int b = blockIdx.x; asm volatile("" : "+s"(b)); return b; }
+// (the bounded-spin helper DfSpin / df_spin_expired lives in vox_common.h: the encoder stack kernel uses it too)
 // Re-read one granule until its tag is this launch's epoch (bounded).  Returns the payload.
 // Once ANY wait of ANY launch has timed out (*err != 0: e.g. the 256 workgroups were not co-resident because another
 // process or stream held CUs), every later wait gives up at once: the launches already queued behind the failure then
@@ -134,13 +135,13 @@ __device__ __forceinline__ int df_bid() { int b = blockIdx.x; asm volatile("" : 
 __device__ __forceinline__ float df_wait_granule_e(const u64 *g, unsigned epoch, unsigned *err, unsigned long long spin_limit, unsigned code) {
     u64 v = df_load_granule(g);
     if ((unsigned)(v >> 32) != epoch) {
-        const unsigned long long t0 = wall_clock64();
+        DfSpin sp; df_spin_begin(sp);
         for (unsigned it = 0;; it++) {
             __builtin_amdgcn_s_sleep(2);
             v = df_load_granule(g);
             if ((unsigned)(v >> 32) == epoch) break;
             if ((it & 15u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-            if (wall_clock64() - t0 > spin_limit) { __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (df_spin_expired(sp, err, spin_limit, code, epoch)) break;
         }
     }
     return __uint_as_float((unsigned)v);
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
             }
             __syncthreads();
             {
-                const unsigned long long t0 = wall_clock64();
+                DfSpin sp; df_spin_begin(sp);
                 for (unsigned it = 0;; it++) {
                     bool ok = true;
                     if (it > 0 || three_trips) {
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
                     for (int u = 0; u < 32; u++) ok = ok && (unsigned)(gv[u] >> 32) == epoch;
                     if (ok) break;
                     if ((it & 15u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                    if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if (df_spin_expired(sp, a.err, a.spin_limit, 2u, epoch)) break;
                     __builtin_amdgcn_s_sleep(4);
                 }
 #pragma unroll
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
         } else
         for (int s0 = 0; s0 < ns; s0 += 4) {           // 4 slices = 12 loads in flight per thread, re-issued together until every tag matches
             u64 gv[4][3];
-            const unsigned long long t0 = wall_clock64();
+            DfSpin sp; df_spin_begin(sp);
             for (unsigned it = 0;; it++) {
                 bool ok = true;
 #pragma unroll
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(DF_THREADS, 2) void k_dec_attn_fused(const DecFuseA
                 if (ok) break;
                 // bounded like df_wait_granule: a timeout (or an earlier one of any launch) gives up and flags the batch
                 if ((it & 15u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (df_spin_expired(sp, a.err, a.spin_limit, 2u, epoch)) break;
                 __builtin_amdgcn_s_sleep(4);
             }
 #pragma unroll
@@ -1259,10 +1260,10 @@ __device__ __forceinline__ void ffn_body(const FfnArgs &a, float *smem, u64 *gx,
 #pragma unroll
         for (int u = 0; u < 12; u++) ok = ok && (unsigned)(gv[u] >> 32) == a.epoch;
         if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
-            const unsigned long long t0 = wall_clock64();
+            DfSpin sp; df_spin_begin(sp);
             for (unsigned it = 0;; it++) {
                 if ((it & 15u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (df_spin_expired(sp, a.err, a.spin_limit, 3u, a.epoch)) break;
                 __builtin_amdgcn_s_sleep(8);
                 ok = true;
 #pragma unroll
@@ -1441,10 +1442,10 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
 #pragma unroll
         for (int u = 0; u < 4; u++) ok = ok && (unsigned)(gxv[u] >> 32) == x_epoch;
         if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
-            const unsigned long long t0 = wall_clock64();
+            DfSpin sp; df_spin_begin(sp);
             for (unsigned it = 0;; it++) {
                 if ((it & 15u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (df_spin_expired(sp, a.err, a.spin_limit, 4u, x_epoch)) break;
                 __builtin_amdgcn_s_sleep(4);
                 ok = true;
 #pragma unroll
@@ -1740,7 +1741,7 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
         {
             for (int s0 = 0; s0 < ns; s0 += 4) {
                 u64 gv[4][3];
-                const unsigned long long t0 = wall_clock64();
+                DfSpin sp; df_spin_begin(sp);
                 for (unsigned it = 0;; it++) {
                     bool ok = true;
                     if (tid < 512) {
@@ -1760,7 +1761,7 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
                     }
                     if (ok) break;
                     if ((it & 15u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                    if (wall_clock64() - t0 > a.spin_limit) { __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if (df_spin_expired(sp, a.err, a.spin_limit, 2u, epoch)) break;
                     __builtin_amdgcn_s_sleep(4);
                 }
                 if (tid < 512) {

@@ -33,6 +33,7 @@
 #include "vox_kernel_api.h"
 #include "vox_decfuse.h"
 #include "vox_skinny.h"
+#include "vox_encstack.h"
 #include "vox_rowsgemm.h"
 #include "vox_rowsgemm_f8.h"
 
@@ -254,6 +255,7 @@ struct vox_hip_engine {
     float *d_wo_part = nullptr;
     unsigned *d_fuse_err = nullptr;
     unsigned fuse_epoch = 0;
+    unsigned spin_hole_max = 0; unsigned long long spin_holes = 0;   // holes (> 1 ms between two polls) the bounded spins saw: err[8..9], vox_decfuse.h
     bool use_planes = true;       // large-M GEMMs on pre-split bf16 planes (k_gemm_planes)
     bool use_epi = true, use_attn_small = true, use_staged_upload = true;     // A/B switches, read once per engine (self_test)
     // k_gemm_planes with the weight fragments straight from global memory to registers (VOX_HIP_GP_BDIRECT=1).  Measured and NOT
@@ -261,9 +263,22 @@ struct vox_hip_engine {
     // (32 bytes from each of 32 rows per instruction, issued twice: both row halves of the tile need them) cost more than the
     // quarter of the LDS-DMA transport they take away.
     Buf splanes;                  // [3][n][max(D, QD, H)] bf16
+    Buf es_carry;                 // copy of enc_out's carried rows while a stack-kernel chunk may have to be repeated
     Uploader *up = nullptr;       // staged weight ingest: lives until vox_hip_upload_done (vox_load calls it) or the engine's end
     bool attn_merge = true;                 // VOX_HIP_DISABLE=attn_merge: k_attn_combine as a launch of its own (round 4)
     unsigned *d_attn_arrive = nullptr;      // k_attn_small: per-head arrival counters (zero between launches)
+    // Round 6: the few-rows encoder chunk as ONE persistent launch (k_enc_stack, vox_encstack.h).  enc_stack_ok = the part and the
+    // geometry fit (256 CUs, 4B encoder shapes) and it is not switched off; enc_stack_rearm > 0 = suspended after a hand-off time-out
+    // (chunks left on the 8-launch path before it is tried again).
+    bool enc_stack_ok = false, enc_stack_ready = false, enc_stack_pending = false, enc_stack_now = false;
+    int enc_stack_failures = 0; long enc_stack_rearm = 0; long enc_stack_launches = 0; bool enc_stack_inject = false;
+    unsigned enc_epoch = 0;
+    EncStackLayer *d_es_tab = nullptr;
+    float *d_es_xa = nullptr, *d_es_xb = nullptr, *d_es_ssq = nullptr, *d_es_q = nullptr, *d_es_po = nullptr, *d_es_pml = nullptr,
+          *d_es_wop = nullptr, *d_es_w2p = nullptr;
+    uint16_t *d_es_apl = nullptr, *d_es_hpl = nullptr;
+    unsigned *d_es_flags = nullptr, *d_es_err = nullptr, *h_es_err = nullptr;
+    unsigned long long *d_es_tl = nullptr;
     bool enc_tl_on = false;
     unsigned long long *d_enc_tl = nullptr;       // VOX_HIP_ENC_TL: [4 GEMM launches][1024 workgroups][16] timeline of one few-rows encoder layer
     unsigned long long *d_fuse_tl = nullptr;      // VOX_HIP_FUSE_TL: [3 kernels][1024 workgroups][3] timeline of the layer-13 launches
@@ -787,6 +802,9 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     F(e->d_st); F(e->dx); F(e->dx2); F(e->dq); F(e->dattn); F(e->dh); F(e->dlogits); F(e->blk_val); F(e->blk_idx);
     F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_gq); F(e->d_gp); F(e->d_wo_part); F(e->d_fuse_err);
     F(e->d_gh); F(e->d_gx); F(e->d_xprime); F(e->d_gw); F(e->d_gxp); F(e->d_stack_tab); F(e->d_attn_arrive);
+    F(e->d_es_tab); F(e->d_es_xa); F(e->d_es_xb); F(e->d_es_ssq); F(e->d_es_q); F(e->d_es_po); F(e->d_es_pml); F(e->d_es_wop); F(e->d_es_w2p);
+    F(e->d_es_apl); F(e->d_es_hpl); F(e->d_es_flags); F(e->d_es_err); F(e->d_es_tl); F(e->es_carry.p); F(e->splanes.p);
+    if (e->h_es_err) hipHostFree(e->h_es_err);
     Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
                    &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml, &e->ssplitk};
     for (Buf *b : bufs) F(b->p);
@@ -1386,6 +1404,94 @@ static int rows_mid_layers(vox_hip_engine *e, float *x, int n, int pos0, const R
     return 0;
 }
 
+// ------------------------------------------------------------------------------------
+// Round 6: a streaming-size chunk (n <= 32 rows) through all encoder layers as ONE persistent launch (k_enc_stack,
+// vox_encstack.h) + the final norm.  x is NOT modified (a flagged chunk is repeated on the 8-launch path from the same rows).
+// ------------------------------------------------------------------------------------
+static bool enc_stack_usable(const vox_hip_engine *e, int n) {
+    return e->enc_stack_ok && e->enc_stack_rearm <= 0 && n >= 1 && n <= 32 && e->d.enc_layers >= 1 &&
+           e->d.enc_window + 31 <= ES_NSL * 128 && e->enc_ring_cap >= e->d.enc_window + 32;
+}
+static int enc_stack_init(vox_hip_engine *e) {
+    if (e->enc_stack_ready) return 0;
+    const int L = e->d.enc_layers;
+    int rc = 0;
+    rc |= dalloc(e, &e->d_es_tab, (size_t)L);
+    rc |= dalloc(e, &e->d_es_xa, (size_t)32 * ES_D); rc |= dalloc(e, &e->d_es_xb, (size_t)32 * ES_D);
+    rc |= dalloc(e, &e->d_es_ssq, (size_t)2 * 32 * ES_CB); rc |= dalloc(e, &e->d_es_q, (size_t)32 * ES_QD);
+    rc |= dalloc(e, &e->d_es_po, (size_t)ES_HEADS * ES_NSL * 32 * 64); rc |= dalloc(e, &e->d_es_pml, (size_t)ES_HEADS * ES_NSL * 32 * 2);
+    rc |= dalloc(e, &e->d_es_wop, (size_t)ES_HEADS * 32 * ES_D); rc |= dalloc(e, &e->d_es_w2p, (size_t)ES_KG5 * 32 * ES_D);
+    rc |= dalloc(e, &e->d_es_apl, (size_t)ES_KS_D * 3 * 2 * 512); rc |= dalloc(e, &e->d_es_hpl, (size_t)ES_KS_H * 3 * 2 * 512);
+    rc |= dalloc(e, &e->d_es_flags, (size_t)ES_WGS); rc |= dalloc(e, &e->d_es_err, (size_t)16);
+    if (rc) return -1;
+    if (hipHostMalloc((void **)&e->h_es_err, 16 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    memset(e->h_es_err, 0, 16 * sizeof(unsigned));
+    std::vector<EncStackLayer> tab((size_t)L);
+    for (int l = 0; l < L; l++) {
+        EncLayer &Y = e->enc[l];
+        tab[l] = EncStackLayer{Y.wqkv, Y.wo, Y.w13, Y.w13 + (size_t)ES_H * ES_D, Y.w2, Y.bqkv, Y.bo, Y.b2, Y.n1, Y.n2, Y.kring, Y.vring};
+    }
+    HC(hipMemcpy(e->d_es_tab, tab.data(), tab.size() * sizeof(EncStackLayer), hipMemcpyHostToDevice));
+    HC(hipMemset(e->d_es_apl, 0, (size_t)ES_KS_D * 3 * 2 * 1024)); HC(hipMemset(e->d_es_hpl, 0, (size_t)ES_KS_H * 3 * 2 * 1024));
+    HC(hipMemset(e->d_es_flags, 0, ES_WGS * 4)); HC(hipMemset(e->d_es_err, 0, 16 * 4));
+    HC(hipMemset(e->d_es_xa, 0, (size_t)32 * ES_D * 4)); HC(hipMemset(e->d_es_xb, 0, (size_t)32 * ES_D * 4));
+    if (e->enc_tl_on && hipMalloc((void **)&e->d_es_tl, (size_t)ES_WGS * ES_TL_STRIDE * 8) == hipSuccess) hipMemset(e->d_es_tl, 0, (size_t)ES_WGS * ES_TL_STRIDE * 8);
+    const void *fns[] = {(const void *)k_enc_stack<1, false>, (const void *)k_enc_stack<2, false>, (const void *)k_enc_stack<1, true>, (const void *)k_enc_stack<2, true>};
+    for (const void *f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ES_LDS_BYTES) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    e->enc_epoch = 0;
+    e->enc_stack_ready = true;
+    return 0;
+}
+static int encoder_rows_stack(vox_hip_engine *e, const float *x, int n, float *out) {
+    if (enc_stack_init(e)) return -1;
+    hipStream_t s = e->stream;
+    if (e->enc_epoch > 0xF0000000u) { HC(hipMemsetAsync(e->d_es_flags, 0, ES_WGS * 4, s)); e->enc_epoch = 0; }
+    EncStackArgs a{};
+    a.layers = e->d_es_tab; a.n_layers = e->d.enc_layers; a.n = n; a.pos0 = e->enc_pos; a.ring_cap = e->enc_ring_cap; a.window = e->d.enc_window;
+    a.eps = e->d.enc_eps; a.scale = 1.0f / sqrtf((float)ES_HD); a.x_in = x; a.rope_tab = (const float *)e->srope.p;
+    a.xa = e->d_es_xa; a.xb = e->d_es_xb; a.aplanes = e->d_es_apl; a.ssq = e->d_es_ssq; a.qbuf = e->d_es_q; a.part_o = e->d_es_po; a.part_ml = e->d_es_pml;
+    a.wo_part = e->d_es_wop; a.hplanes = e->d_es_hpl; a.w2_part = e->d_es_w2p; a.flags = e->d_es_flags; a.epoch = e->enc_epoch;
+    a.err = e->d_es_err; a.spin_limit = 500000ull; a.tl = e->d_es_tl; a.tl_layer = e->d.enc_layers / 2;
+    e->enc_epoch += 256u * (unsigned)((ES_PHASES * e->d.enc_layers + 1 + 255) / 256);
+    if (e->d_es_tl) {
+        if (n <= 16) hipLaunchKernelGGL((k_enc_stack<1, true>), dim3(ES_WGS), dim3(ES_THREADS), ES_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((k_enc_stack<2, true>), dim3(ES_WGS), dim3(ES_THREADS), ES_LDS_BYTES, s, a);
+    } else {
+        if (n <= 16) hipLaunchKernelGGL((k_enc_stack<1, false>), dim3(ES_WGS), dim3(ES_THREADS), ES_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((k_enc_stack<2, false>), dim3(ES_WGS), dim3(ES_THREADS), ES_LDS_BYTES, s, a);
+    }
+    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, s, out, ES_D, (const float *)e->d_es_xa, ES_D, e->enc_final_norm, (const float *)nullptr, ES_D, e->d.enc_eps);
+    e->enc_pos += n;
+    e->enc_stack_pending = true; e->enc_stack_launches++;
+    LAUNCH_CHECK("encoder chunk launches (stack kernel)");
+    return 0;
+}
+// Enqueue the read-back of the stack kernel's error words (before the caller's host wait), and judge them after it.
+static void enc_stack_fetch(vox_hip_engine *e) {
+    if (e->enc_stack_pending) hipMemcpyAsync(e->h_es_err, e->d_es_err, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream);
+}
+constexpr long ENC_STACK_REARM_CHUNKS = 64;
+// After the host wait: 1 = a hand-off of the stack kernel timed out in a chunk enqueued since the last check (its results are void:
+// the caller repeats the chunk, which now takes the 8-launch path), 0 = clean.
+static int enc_stack_failed(vox_hip_engine *e) {
+    if (!e->enc_stack_pending) return 0;
+    e->enc_stack_pending = false;
+    const unsigned *w = e->h_es_err;
+    e->spin_hole_max = std::max(e->spin_hole_max, w[8]); e->spin_holes += w[9];
+    if (w[8] | w[9]) (void)hipMemsetAsync(e->d_es_err + 8, 0, 2 * sizeof(unsigned), e->stream);
+    if (e->enc_stack_inject) { e->enc_stack_inject = false; e->h_es_err[0] = 99u; }
+    if (!w[0]) return 0;
+    e->enc_stack_failures++;
+    e->enc_stack_rearm = (ENC_STACK_REARM_CHUNKS << std::min(e->enc_stack_failures - 1, 6)) + 1;      // (+ 1: the repeat of this chunk counts one down)
+    fprintf(stderr, "vox_hip: ERROR the encoder stack kernel timed out in a hand-off (code %u; its 256 workgroups were not co-resident?): workgroup %u "
+                    "(XCD %u) waited for flag value %u, %.1f us of active waiting, longest gap between two polls %.1f us; repeating the chunk on the "
+                    "launch-per-GEMM path and staying there for %ld chunks\n", w[0], w[1], w[2] & 15u, w[6], w[4] / 100.0, w[3] / 100.0, e->enc_stack_rearm - 1);
+    (void)hipMemset(e->d_es_err, 0, 8 * sizeof(unsigned));
+    memset(e->h_es_err, 0, 16 * sizeof(unsigned));
+    return 1;
+}
+
 static int encoder_rows_dev(vox_hip_engine *e, float *x, int n, float *out) {
     const RowsCfg c = enc_cfg(e);
     if (ensure_rows_scratch(e, n, c)) return -1;
@@ -1396,7 +1502,11 @@ static int encoder_rows_dev(vox_hip_engine *e, float *x, int n, float *out) {
         e->enc_pos += n;
         return 0;
     }
-    if (skinny_ok(e, n, c)) return encoder_rows_skinny(e, x, n, out);
+    if (skinny_ok(e, n, c)) {
+        if (e->enc_stack_rearm > 0) e->enc_stack_rearm--;              // a suspension of the stack kernel counts down in chunks
+        else if (e->enc_stack_now && enc_stack_usable(e, n)) return encoder_rows_stack(e, x, n, out);
+        return encoder_rows_skinny(e, x, n, out);
+    }
     for (int l = 0; l < e->d.enc_layers; l++) {
         EncLayer &L = e->enc[l];
         if (run_layer_rows(e, x, n, e->enc_pos, c, L.wqkv, L.bqkv, L.wo, L.bo, L.w13, L.w2, L.b2, L.n1, L.n2,
@@ -1586,10 +1696,20 @@ extern "C" int vox_hip_encoder_chunk(vox_hip_engine_t *e, const float *x_new, in
     const int ED = e->d.enc_dim;
     if (ensure(e, e->stmp_in, (size_t)new_len * ED * 4)) return -1;
     if (ensure(e, e->stmp_out, (size_t)new_len * ED * 4)) return -1;
-    HC(hipMemcpyAsync(e->stmp_in.p, x_new, (size_t)new_len * ED * 4, hipMemcpyHostToDevice, e->stream));
-    if (encoder_rows_dev(e, (float *)e->stmp_in.p, new_len, (float *)e->stmp_out.p)) return -1;
-    HC(hipMemcpyAsync(out, e->stmp_out.p, (size_t)new_len * ED * 4, hipMemcpyDeviceToHost, e->stream));
-    HC(esync(e));
+    const int pos_before = e->enc_pos;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        // (the paths below the stack kernel work in place: the rows are uploaded again for a repeat)
+        HC(hipMemcpyAsync(e->stmp_in.p, x_new, (size_t)new_len * ED * 4, hipMemcpyHostToDevice, e->stream));
+        e->enc_stack_now = attempt == 0;
+        const int erc = encoder_rows_dev(e, (float *)e->stmp_in.p, new_len, (float *)e->stmp_out.p);
+        e->enc_stack_now = false;
+        if (erc) return -1;
+        HC(hipMemcpyAsync(out, e->stmp_out.p, (size_t)new_len * ED * 4, hipMemcpyDeviceToHost, e->stream));
+        enc_stack_fetch(e);
+        HC(esync(e));
+        if (!enc_stack_failed(e)) break;
+        e->enc_pos = pos_before;          // a hand-off of the stack kernel timed out: the same rows again, on the launch-per-GEMM path
+    }
     return 0;
 }
 
@@ -1685,10 +1805,24 @@ extern "C" int vox_hip_stream_encode(vox_hip_engine_t *e, int n_mel, int *conv_r
     if (nq < 0) return -1;
     if (conv_rows) *conv_rows = nq;
     int new_tokens = 0;
-    if (nq > 0) {
+    // (round 6) the stack kernel may flag a chunk (a hand-off timed out): everything from the encoder stack on is then repeated on the
+    // launch-per-GEMM path from the same conv-stem rows, with the stream state rewound to this point
+    const int saved_pos = e->enc_pos, saved_res = e->enc_res; const int64_t saved_total = e->adapter_total;
+    for (int attempt = 0; attempt < 2 && nq > 0; attempt++) {
+        new_tokens = 0;
         if (ensure_keep(e, e->enc_out, (size_t)(3 + nq) * ED * 4, (size_t)3 * ED * 4)) return -1;
         float *eo = (float *)e->enc_out.p;
-        if (encoder_rows_dev(e, x, nq, eo + (size_t)3 * ED)) return -1;
+        // the rows carried for the 4x alignment (rows 0 .. 2) are overwritten at the end of the bracket: keep a copy while a repeat is possible
+        const bool may_repeat = attempt == 0 && skinny_ok(e, nq, enc_cfg(e)) && enc_stack_usable(e, nq) && !(rowsgemm_ok(e, nq, enc_cfg(e)) && nq > 32);
+        if (may_repeat && saved_res > 0) {
+            if (ensure(e, e->es_carry, (size_t)3 * ED * 4)) return -1;
+            HC(hipMemcpyAsync(e->es_carry.p, eo, (size_t)3 * ED * 4, hipMemcpyDeviceToDevice, s));
+        }
+        if (attempt == 1 && saved_res > 0) HC(hipMemcpyAsync(eo, e->es_carry.p, (size_t)3 * ED * 4, hipMemcpyDeviceToDevice, s));
+        e->enc_stack_now = attempt == 0;
+        const int erc = encoder_rows_dev(e, x, nq, eo + (size_t)3 * ED);
+        e->enc_stack_now = false;
+        if (erc) return -1;
         const int total = e->enc_res + nq;
         const int usable = (total / 4) * 4, leftover = total - usable;
         float *first = eo + (size_t)(3 - e->enc_res) * ED;
@@ -1707,6 +1841,11 @@ extern "C" int vox_hip_stream_encode(vox_hip_engine_t *e, int n_mel, int *conv_r
             if (src != dst) HC(hipMemcpyAsync(dst, src, (size_t)ED * 4, hipMemcpyDeviceToDevice, s));
         }
         e->enc_res = leftover;
+        if (!e->enc_stack_pending) break;
+        enc_stack_fetch(e);
+        HC(esync(e));
+        if (!enc_stack_failed(e)) break;
+        e->enc_pos = saved_pos; e->enc_res = saved_res; e->adapter_total = saved_total;       // (the carried rows 0 .. 2 of enc_out were only read)
     }
     if (enc_residual) *enc_residual = e->enc_res;
     HC(hipEventRecord(e->ev1, s));
@@ -1904,6 +2043,28 @@ static void launch_gemv3(vox_hip_engine *e, const GemvArgs &a) {
     if (PRO == PRO_RMS || PRO == PRO_EMBED_RMS) fl += 2 * (size_t)K;
     if (PRO == PRO_ATTN) fl += 256;
     hipLaunchKernelGGL((k_gemv3<PRO, EPI, RPW, CPL, KS, MINW, W8>), dim3(grid), dim3(256), fl * sizeof(float), e->stream, a);
+}
+
+// The end of a decoder pass over one row x[dec_dim] of the stack's output: final norm -> tied-embedding logits -> per-block argmax
+// (voxtral_decoder.c:694-704), then the argmax finish, which also advances the decoder cursor.
+static void enqueue_logits_tail(vox_hip_engine *e, const float *xin, float *logits_dst, int eos, int advance, bool fast) {
+    const vox_hip_dims_t &d = e->d;
+    const int DD = d.dec_dim;
+    hipStream_t s = e->stream;
+    GemvArgs a{};
+    a.W = (e->sim_on && e->sim_lm) ? e->tok_emb_s : e->tok_emb; a.x = xin; a.norm_w = e->dec_final_norm; a.eps = d.dec_eps; a.y = logits_dst;
+    a.N = d.vocab; a.K = DD; a.blk_val = e->blk_val; a.blk_idx = e->blk_idx;
+    // VOX_HIP_DISABLE=fp8_lmhead (agreement study): fp8 mode with the LM head on the bf16 embedding
+    if (fast && e->use_fp8 && !e->fp8_lmhead_bf16) {
+        a.W = reinterpret_cast<const uint16_t *>(e->tok_emb8); a.wscale = e->stok;
+        hipLaunchKernelGGL((k_gemv<PRO_RMS, EPI_LOGITS, 4, true>), dim3(e->logits_grid), dim3(256),
+                           ((size_t)DD + 16) * sizeof(float), s, a);
+    } else
+        launch_gemv<PRO_RMS, EPI_LOGITS, 4>(e, a, e->logits_grid);
+    prof_mark(e, PK_LOGITS);
+    hipLaunchKernelGGL(k_argmax_finish, dim3(1), dim3(256), 0, s, (const float *)e->blk_val, (const int *)e->blk_idx,
+                       e->logits_grid, e->d_st, e->d_tokens, eos, advance);
+    prof_mark(e, PK_ARGMAX);
 }
 
 // Enqueue one decode step. kv_pos = logical position of this token (host mirror of st->pos).
@@ -2223,22 +2384,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
         }
     }
     tap(2 * d.dec_layers, xin);
-    {   // final norm -> tied-embedding logits -> per-block argmax (voxtral_decoder.c:694-704)
-        GemvArgs a{};
-        a.W = (e->sim_on && e->sim_lm) ? e->tok_emb_s : e->tok_emb; a.x = xin; a.norm_w = e->dec_final_norm; a.eps = d.dec_eps; a.y = logits_dst;
-        a.N = d.vocab; a.K = DD; a.blk_val = e->blk_val; a.blk_idx = e->blk_idx;
-        // VOX_HIP_FP8_LMHEAD_BF16 (agreement study): fp8 mode with the LM head on the bf16 embedding
-        if (fast && e->use_fp8 && !e->fp8_lmhead_bf16) {
-            a.W = reinterpret_cast<const uint16_t *>(e->tok_emb8); a.wscale = e->stok;
-            hipLaunchKernelGGL((k_gemv<PRO_RMS, EPI_LOGITS, 4, true>), dim3(e->logits_grid), dim3(256),
-                               ((size_t)DD + 16) * sizeof(float), s, a);
-        } else
-            launch_gemv<PRO_RMS, EPI_LOGITS, 4>(e, a, e->logits_grid);
-        prof_mark(e, PK_LOGITS);
-        hipLaunchKernelGGL(k_argmax_finish, dim3(1), dim3(256), 0, s, (const float *)e->blk_val, (const int *)e->blk_idx,
-                           e->logits_grid, e->d_st, e->d_tokens, eos, advance);
-        prof_mark(e, PK_ARGMAX);
-    }
+    enqueue_logits_tail(e, xin, logits_dst, eos, advance, fast);
     LAUNCH_CHECK("decode step launches");
     return 0;
 }
@@ -2260,17 +2406,24 @@ static int set_state(vox_hip_engine *e, int pos, int token, int64_t adapter_phys
 constexpr long FUSE_REARM_STEPS = 256;
 static int fused_failed(vox_hip_engine *e) {
     if (!e->use_fused) return 0;
-    unsigned err = 0;
-    if (hipMemcpy(&err, e->d_fuse_err, sizeof err, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    unsigned w[16] = {0};
+    if (hipMemcpy(w, e->d_fuse_err, sizeof w, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    e->spin_hole_max = std::max(e->spin_hole_max, w[8]); e->spin_holes += w[9];
+    if (w[8] | w[9]) (void)hipMemset(e->d_fuse_err + 8, 0, 2 * sizeof(unsigned));
+    const unsigned err = w[0];
     if (!err) return 0;
     e->use_fused = false; e->fuse_failures++;
     static const bool no_rearm = vox_disabled("rearm");
     e->fuse_rearm = no_rearm ? 0 : FUSE_REARM_STEPS << std::min(e->fuse_failures - 1, 6);
+    // (ticks of the 100 MHz wall clock -> us)
     fprintf(stderr, "vox_hip: ERROR fused decode kernel timed out in hand-off %u (its 256 workgroups were not co-resident?) in the batch "
-                    "of decoder steps from position %d on (hand-off epoch counter %u after it); repeating the work on the launch-per-GEMV chain%s\n",
-            err, e->dec_pos, e->fuse_epoch,
+                    "of decoder steps from position %d on (hand-off epoch counter %u after it): workgroup %u (XCD %u, thread %u) waited for tag %u, "
+                    "%.1f us of active waiting, longest gap between two polls %.1f us; holes > 1 ms seen by any spin so far: %llu (longest %.1f us); "
+                    "repeating the work on the launch-per-GEMV chain%s\n",
+            err, e->dec_pos, e->fuse_epoch, w[1], w[2] & 15u, w[7], w[6], w[4] / 100.0, w[3] / 100.0,
+            (unsigned long long)e->spin_holes, e->spin_hole_max / 100.0,
             e->fuse_rearm ? " and staying there for a while before the fused kernel is tried again" : " and staying there");
-    (void)hipMemset(e->d_fuse_err, 0, sizeof(unsigned));
+    (void)hipMemset(e->d_fuse_err, 0, 8 * sizeof(unsigned));
     return 1;
 }
 // `steps` decode steps completed cleanly: count down a suspension of the fused kernel.
@@ -2315,6 +2468,34 @@ extern "C" int vox_hip_fuse_stats(const vox_hip_engine_t *e, int *failures, int 
     if (armed) *armed = e->use_fused ? 1 : 0;
     if (rearm_in) *rearm_in = e->fuse_rearm;
     return e->fused_ok ? 0 : 1;
+}
+// Diagnosis: how many holes (> 1 ms between two consecutive polls of a bounded spin: the queue was switched out, vox_decfuse.h
+// "bounded spins") the decode launches have seen so far, and the longest one in microseconds.
+extern "C" int vox_hip_spin_holes(vox_hip_engine_t *e, unsigned long long *count, double *longest_us) {
+    if (!e || !e->d_fuse_err) return -1;
+    unsigned w[2] = {0, 0};
+    HC(hipSetDevice(e->device));
+    HC(esync(e));
+    HC(hipMemcpy(w, e->d_fuse_err + 8, sizeof w, hipMemcpyDeviceToHost));
+    if (count) *count = e->spin_holes + w[1];
+    if (longest_us) *longest_us = std::max(e->spin_hole_max, w[0]) / 100.0;
+    return 0;
+}
+// The encoder stack kernel (VOX_PATH_ENC_STACK): launches so far, hand-off time-outs so far, 1 if it is live now (0: suspended after a
+// time-out, or not available on this engine).  Returns 0, -1 on error.
+extern "C" int vox_hip_enc_stack_stats(const vox_hip_engine_t *e, long *launches, int *failures, int *armed) {
+    if (!e) return -1;
+    if (launches) *launches = (long)e->enc_stack_launches;
+    if (failures) *failures = e->enc_stack_failures;
+    if (armed) *armed = (e->enc_stack_ok && e->enc_stack_rearm <= 0) ? 1 : 0;
+    return 0;
+}
+// Test hook: the next check after a chunk behaves as if a hand-off of the stack kernel had timed out (the chunk is repeated on the
+// launch-per-GEMM path, the suspension runs).
+extern "C" int vox_hip_debug_inject_enc_stack_timeout(vox_hip_engine_t *e) {
+    if (!e || !e->enc_stack_ok) return -1;
+    e->enc_stack_inject = true;
+    return 0;
 }
 extern "C" int vox_hip_debug_set_handoff_epoch(vox_hip_engine_t *e, unsigned epoch, unsigned *old) {
     if (!e) return -1;
@@ -2366,6 +2547,29 @@ extern "C" int vox_hip_decoder_prefill_stream(vox_hip_engine_t *e, int64_t first
     const float *arow = e->adapter + (size_t)(first_row - e->adapter_row0) * DD;
     hipLaunchKernelGGL(k_embed_prompt, dim3(grid1d((size_t)n_prompt * DD)), dim3(256), 0, s, x, arow,
                        (const uint16_t *)e->tok_emb, n_prompt, DD, bos, pad);
+    // Round 5: the LAST prompt row goes through the rows pass too (its k_rowsgemm launches cost the same for 39 rows as for 38, and
+    // the pass computes the last layer's FFN block anyway), and only the logits tail runs on its row of the stack's output - instead
+    // of a whole decode step for it (1.25 ms of the 4.3 ms this call took).  Same arithmetic up to summation order; the reference does
+    // prefill(n - 1) + forward(1) (voxtral.c:1005-1012).  Not with a debug tap on that position (the taps live in the step), not
+    // beyond one k_rowsgemm chunk.  VOX_HIP_DISABLE=prefill_tail is the old sequence.
+    bool tapped = false;
+    for (size_t i = 0; i < e->tap_pos.size(); i++) if (e->tap_pos[i] == e->dec_pos + n_prompt - 1) tapped = true;
+    const bool fast_geom = e->use_fast && DD == 3072 && e->dec_qd == 4096 && e->dec_kvd == 1024 && e->d.dec_hidden == 9216;
+    if (n_prompt > 1 && n_prompt <= 128 && rowsgemm_ok(e, n_prompt, dec_cfg(e)) && !tapped && !e->sim_on && !e->skip_kinds &&
+        !vox_disabled("prefill_tail")) {
+        if (decoder_prefill_dev(e, x, n_prompt)) return -1;
+        int tok = -1;
+        if (set_state(e, e->dec_pos - 1, 0, 0)) return -1;
+        enqueue_logits_tail(e, x + (size_t)(n_prompt - 1) * DD, e->dlogits, -1, 1, fast_geom);
+        HC(hipMemcpyAsync(&tok, e->d_tokens, sizeof(int), hipMemcpyDeviceToHost, s));
+        if (logits) HC(hipMemcpyAsync(logits, e->dlogits, (size_t)e->d.vocab * 4, hipMemcpyDeviceToHost, s));
+        HC(hipEventRecord(e->ev1, s));
+        HC(esync(e));
+        float ms = 0.f; hipEventElapsedTime(&ms, e->ev0, e->ev1);
+        e->timing.prefill_ms += ms;
+        e->adapter_consumed = std::max(e->adapter_consumed, first_row + n_prompt);
+        return tok;
+    }
     if (n_prompt > 1 && decoder_prefill_dev(e, x, n_prompt - 1)) return -1;
     int tok = -1;
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -2688,10 +2892,15 @@ extern "C" double vox_hip_time_encoder_rows(vox_hip_engine_t *e, int n_rows, int
         if (it == 0) hipEventRecord(e->ev0, e->stream);
         hipMemsetAsync(e->stmp_in.p, 0, (size_t)n_rows * ED * 4, e->stream);
         e->enc_pos = ctx_rows;
-        if (encoder_rows_dev(e, (float *)e->stmp_in.p, n_rows, (float *)e->stmp_out.p)) { vox_hip_reset_encoder(e); return -1.0; }
+        e->enc_stack_now = true;
+        const int erc = encoder_rows_dev(e, (float *)e->stmp_in.p, n_rows, (float *)e->stmp_out.p);
+        e->enc_stack_now = false;
+        if (erc) { vox_hip_reset_encoder(e); return -1.0; }
     }
     hipEventRecord(e->ev1, e->stream);
+    enc_stack_fetch(e);
     esync(e);
+    if (enc_stack_failed(e)) { vox_hip_reset_encoder(e); return -1.0; }       // (a flagged pass is not a measurement)
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
     if (e->d_enc_tl && getenv("VOX_HIP_ENC_TL")) {      // per-workgroup timeline of the last pass's mid-stack GEMM launches -> text file
         std::vector<unsigned long long> h((size_t)4 * 1024 * TL_STRIDE);
@@ -2708,6 +2917,24 @@ extern "C" double vox_hip_time_encoder_rows(vox_hip_engine_t *e, int n_rows, int
                     for (int q = 3; q < 8; q++) fprintf(f, " %.2f", r[q] ? (double)(r[q] - t0) / 100.0 : -1.0);
                     fprintf(f, "\n");
                 }
+        }
+        if (f) fclose(f);
+    }
+    if (e->d_es_tl && getenv("VOX_HIP_ENC_TL")) {       // the stack kernel's per-workgroup phase stamps of the mid-stack layer (last pass) -> <file>.stack
+        std::vector<unsigned long long> h((size_t)ES_WGS * ES_TL_STRIDE);
+        const std::string fn = std::string(getenv("VOX_HIP_ENC_TL")) + ".stack";
+        FILE *f = fopen(fn.c_str(), "w");
+        if (f && hipMemcpy(h.data(), e->d_es_tl, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(f, "# block kernel_start_us now_us xcc hw_id | per phase P1 P2 P3 F3 P4 P5 F5: wait_done_us body_done_us (relative to the first P1 wait_done; 100 MHz clock)\n");
+            unsigned long long t0 = ~0ull;
+            for (int b = 0; b < ES_WGS; b++) if (h[(size_t)b * ES_TL_STRIDE + 3] && h[(size_t)b * ES_TL_STRIDE + 3] < t0) t0 = h[(size_t)b * ES_TL_STRIDE + 3];
+            for (int b = 0; b < ES_WGS; b++) {
+                const unsigned long long *r = &h[(size_t)b * ES_TL_STRIDE];
+                if (!r[0]) continue;
+                fprintf(f, "%d %.2f %.2f %u %u", b, ((double)r[0] - (double)t0) / 100.0, ((double)r[1] - (double)t0) / 100.0, (unsigned)(r[2] >> 32), (unsigned)r[2]);
+                for (int q = 0; q < 2 * ES_PHASES; q++) fprintf(f, " %.2f", ((double)r[3 + q] - (double)t0) / 100.0);
+                fprintf(f, "\n");
+            }
         }
         if (f) fclose(f);
     }
@@ -3072,6 +3299,13 @@ static int self_test(vox_hip_engine *e) {
         (void)hipGetLastError();
         e->use_skinny = false;
     }
+    {   // k_enc_stack (round 6): the 4B encoder's shapes on a 256-CU part, all CUs available to the stream; it falls back on k_skinny's launches
+        hipDeviceProp_t prop;
+        const vox_hip_dims_t &d = e->d;
+        e->enc_stack_ok = e->use_skinny && e->use_mfma && e->use_dpp && !vox_disabled("enc_stack") && !getenv("VOX_HIP_CUMASK") &&
+                          d.enc_dim == ES_D && e->enc_qd == ES_QD && d.enc_hidden == ES_H && d.enc_heads == ES_HEADS && d.enc_head_dim == ES_HD &&
+                          hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount == ES_WGS;
+    }
     {   // k_rowsgemm: up to 3 planes x 128 rows x 2 chunks (or 96 rows x 4 chunks) of activations in LDS
         const int rg_lds = 2 * 3 * 32 * 6 * 128;        // the largest request the launcher can make (mt * cpw <= 6)
 #define RG_FN(WPB, CPW) (const void *)k_rowsgemm<WPB, CPW, RG_X_PLANES, 1, 4>, (const void *)k_rowsgemm<WPB, CPW, RG_X_F32, 1, 4>, \
@@ -3171,6 +3405,7 @@ extern "C" unsigned vox_hip_active_paths(const vox_hip_engine_t *e) {
     if (e->use_rowsgemm && e->use_mfma) m |= VOX_PATH_ROWSGEMM;
     if (merged_static_ok(e)) m |= VOX_PATH_FFN_ATTN12;
     if (merged_static_ok(e) && e->use_stack && e->d.dec_layers > 1) m |= VOX_PATH_DEC_STACK;
+    if (e->enc_stack_ok) m |= VOX_PATH_ENC_STACK;
     return m;
 }
 

@@ -803,7 +803,7 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     F(e->d_tokens); F(e->dpart_o); F(e->dpart_ml); F(e->adapter); F(e->d_gq); F(e->d_gp); F(e->d_wo_part); F(e->d_fuse_err);
     F(e->d_gh); F(e->d_gx); F(e->d_xprime); F(e->d_gw); F(e->d_gxp); F(e->d_stack_tab); F(e->d_attn_arrive);
     F(e->d_es_tab); F(e->d_es_xa); F(e->d_es_xb); F(e->d_es_ssq); F(e->d_es_q); F(e->d_es_po); F(e->d_es_pml); F(e->d_es_wop); F(e->d_es_w2p);
-    F(e->d_es_apl); F(e->d_es_hpl); F(e->d_es_flags); F(e->d_es_err); F(e->d_es_tl); F(e->es_carry.p); F(e->splanes.p);
+    F(e->d_es_apl); F(e->d_es_hpl); F(e->d_es_flags); F(e->d_es_err); F(e->d_es_tl); F(e->es_carry.p);
     if (e->h_es_err) hipHostFree(e->h_es_err);
     Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
                    &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml, &e->ssplitk};

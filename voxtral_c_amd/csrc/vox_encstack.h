@@ -145,18 +145,30 @@ __device__ __forceinline__ void es_arrive(const EncStackArgs &a, unsigned value)
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(a.flags + blockIdx.x, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Wave 0 polls all 256 flags until each is at or past `target` (es_poll); the other waves go straight on to request their weight
-// fragments and meet wave 0 at the barrier (es_join).  Wave 0 requests its own fragments AFTER the poll: a poll queued behind ~10 KB of
-// weight loads returns when they have landed.  es_join: false = the chunk is flagged (a time-out here or anywhere else) and the
-// caller leaves the kernel.
-__device__ __forceinline__ void es_poll(const EncStackArgs &a, unsigned target, int *s_ok) {
+// Wave 0 polls the flags of the workgroups this phase depends on until each is at or past `target` (es_poll: one 16-byte load per
+// lane = all 256 flags per poll; `need(f)` says whether workgroup f is a producer of this workgroup's inputs); the other waves go
+// straight on to request their weight fragments and meet wave 0 at the barrier (es_join).  Wave 0 requests its own fragments AFTER
+// the poll: a poll queued behind ~10 KB of weight loads returns when they have landed.  es_join: false = the chunk is flagged (a
+// time-out here or anywhere else) and the caller leaves the kernel.
+// Dependencies narrower than "everybody" shorten the tails (a consumer starts when ITS producers are done); what keeps buffer reuse
+// safe is that the waits in front of P4 and P1 stay global: every buffer is rewritten only behind a global wait that follows its
+// last reader's phase (and the narrow ones are transitively complete: e.g. F3 needs all 32 heads' P3, each needs its head's P2, each
+// needs its head's P1 - all 256 workgroups of P1).
+struct EsNeedAll { __device__ __forceinline__ bool operator()(int) const { return true; } };
+struct EsNeedNone { __device__ __forceinline__ bool operator()(int) const { return false; } };
+struct EsNeedHead { int xcd, h4; __device__ __forceinline__ bool operator()(int f) const { return (f & 7) == xcd && ((f >> 3) & 3) == h4; } };     // the 8 workgroups of a head
+struct EsNeedShift { int sh, v; __device__ __forceinline__ bool operator()(int f) const { return (f >> sh) == v; } };                             // workgroups f with f >> sh == v
+template <typename Need>
+__device__ __forceinline__ void es_poll(const EncStackArgs &a, unsigned target, int *s_ok, const Need need) {
     if (threadIdx.x < 64) {
         const __amdgpu_buffer_rsrc_t fr = es_rsrc(a.flags);
+        const int f0 = threadIdx.x * 4;
+        const bool n0 = need(f0), n1 = need(f0 + 1), n2 = need(f0 + 2), n3 = need(f0 + 3);
         int res = 1;
         DfSpin sp;
         for (unsigned it = 0;; it++) {
             const es_u32x4 f = es_ld16(fr, threadIdx.x * 16);
-            const bool ok = (int)(f.x - target) >= 0 && (int)(f.y - target) >= 0 && (int)(f.z - target) >= 0 && (int)(f.w - target) >= 0;
+            const bool ok = (!n0 || (int)(f.x - target) >= 0) && (!n1 || (int)(f.y - target) >= 0) && (!n2 || (int)(f.z - target) >= 0) && (!n3 || (int)(f.w - target) >= 0);
             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
             if (it == 0) df_spin_begin(sp);
             else if (df_spin_expired(sp, a.err, a.spin_limit, 11u, target)) { res = 0; break; }
@@ -170,8 +182,9 @@ __device__ __forceinline__ bool es_join(const int *s_ok) {
     __syncthreads();
     return *s_ok != 0;
 }
-__device__ __forceinline__ bool es_wait(const EncStackArgs &a, unsigned target, int *s_ok) {
-    es_poll(a, target, s_ok);
+template <typename Need>
+__device__ __forceinline__ bool es_wait(const EncStackArgs &a, unsigned target, int *s_ok, const Need need) {
+    es_poll(a, target, s_ok, need);
     return es_join(s_ok);
 }
 
@@ -284,21 +297,23 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
         const __amdgpu_buffer_rsrc_t apl = es_rsrc(a.aplanes);
 
         // =========================== P1: q;k;v ===============================================================================
+        // workgroup (head, j): columns 8 j .. 8 j + 7 of the head's q, of its k and of its v (24 W rows; the 8 workgroups of a head share an
+        // XCD and are all the attention phase of that head waits for).  W tile 0 = the q rows + the k rows, tile 1 = the v rows (+ 8 idle lanes).
         {
             ES_IDS();
-            const int r0 = 24 * w;
+            const int head = xcd * 4 + (widx & 3), c0 = head * 64 + 8 * (widx >> 2);
             uint4 wq[2][5];
             const __amdgpu_buffer_rsrc_t wr = es_rsrc(L.wqkv);
             auto issue = [&]() {
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
-                    const int row = r0 + min(16 * t + li, 23);
+                    const int row = t == 0 ? (li < 8 ? c0 + li : ES_QD + c0 + li - 8) : 2 * ES_QD + c0 + min(li, 7);
                     const unsigned wo_ = (unsigned)((row * ES_D + (5 * wv) * 32 + kb * 8) * 2);
 #pragma unroll
                     for (int j = 0; j < 5; j++) wq[t][j] = es_ldw(wr, wo_ + j * 64);
                 }
             };
-            es_poll(a, a.epoch + g, &s_ok);              // (wave 0 only)
+            es_poll(a, a.epoch + g, &s_ok, EsNeedAll());            // (wave 0 only)
             issue();
             if (!es_join(&s_ok)) return;
             ES_MARK(0);
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
                         }
                 }
             }
-            // add the 8 K-splitters in wave order: red[wave][row 32][col 32 (24 used)], row stride 33
+            // add the 8 K-splitters in wave order: red[wave][row 32][col 32 (24 used: q 0 .. 7, k 8 .. 15, v 16 .. 23)], row stride 33
             ES_MFMA_SETTLE();
             float *red = reinterpret_cast<float *>(es_lds);
             float *outt = red + 8 * 32 * 33;
@@ -353,16 +368,16 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
                 outt[m * 33 + c] = v;
             }
             __syncthreads();
-            // epilogue: thread = (row m, 4 columns): * inv + bias, RoPE pairs, q / k / v destinations
+            // epilogue: thread = (row m, 4 columns of q, k or v): * inv + bias, RoPE pairs (q, k), destinations
             if (tid < 32 * 6) {
                 const int m = tid / 6, c = (tid - m * 6) * 4;
                 if (m < n) {
-                    const int col = r0 + c;
+                    const int which = c >> 3, col = c0 + (c & 7);               // 0 q, 1 k, 2 v; column inside the [2048] block
                     const float inv = s_inv[m];
-                    const float4 b = *reinterpret_cast<const float4 *>(L.bqkv + col);
+                    const float4 b = *reinterpret_cast<const float4 *>(L.bqkv + which * ES_QD + col);
                     float v0 = outt[m * 33 + c] * inv + b.x, v1 = outt[m * 33 + c + 1] * inv + b.y;
                     float v2 = outt[m * 33 + c + 2] * inv + b.z, v3 = outt[m * 33 + c + 3] * inv + b.w;
-                    if (col < 2 * ES_QD) {
+                    if (which < 2) {
                         const int d = (col & 63) >> 1;
                         const float4 cs = *reinterpret_cast<const float4 *>(a.rope_tab + ((size_t)m * 32 + d) * 2);      // cos d, sin d, cos d+1, sin d+1
                         const float q0 = v0 * cs.x - v1 * cs.y, q1 = v0 * cs.y + v1 * cs.x;
@@ -370,11 +385,10 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
                         v0 = q0; v1 = q1; v2 = q2; v3 = q3;
                     }
                     const es_u32x4 ov = es_f4(v0, v1, v2, v3);
-                    if (col < ES_QD) es_st16(es_rsrc(a.qbuf), (unsigned)(((size_t)m * ES_QD + col) * 4), ov);
+                    if (which == 0) es_st16(es_rsrc(a.qbuf), (unsigned)(((size_t)m * ES_QD + col) * 4), ov);
                     else {
                         const int slot = (a.pos0 + m) % a.ring_cap;
-                        if (col < 2 * ES_QD) es_st16(es_rsrc(L.kring), (unsigned)(((size_t)slot * ES_QD + (col - ES_QD)) * 4), ov);
-                        else es_st16(es_rsrc(L.vring), (unsigned)(((size_t)slot * ES_QD + (col - 2 * ES_QD)) * 4), ov);
+                        es_st16(es_rsrc(which == 1 ? L.kring : L.vring), (unsigned)(((size_t)slot * ES_QD + col) * 4), ov);
                     }
                 }
             }
@@ -383,6 +397,10 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
         }
 
         // =========================== P2: attention partials of (head, key slice) ============================================
+        // k_attn_small's arithmetic (plain f32 FMAs: lane = key for the scores, lane = dim for P.V; vox_causal_attention,
+        // voxtral_kernels.c:412-482 up to summation order) on a slice of up to 128 keys = two 64-key tiles, both resident in LDS.  The
+        // K / V rows of OLD positions do not depend on this layer's P1: they are requested before the wait; rows of this chunk's own
+        // positions (the last slice or two) are fetched behind it.
         {
             ES_IDS();
             const int head = xcd * 4 + (widx & 3);
@@ -390,92 +408,113 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
             const int lo = max(0, a.pos0 - a.window + 1), hi = a.pos0 + n - 1;
             const int nkeys = hi - lo + 1, KS = (nkeys + ES_NSL - 1) / ES_NSL;
             const int t0 = lo + slice * KS, t1 = min(t0 + KS - 1, hi);        // this slice's keys [t0, t1] (empty if t0 > t1)
+            const int ntile = t0 > t1 ? 0 : (t1 - t0) / 64 + 1;               // 0, 1 or 2
             float *qs = reinterpret_cast<float *>(es_lds);                    // [32][64]
-            float *ks = qs + 32 * 64;                                         // [64][65]
-            float *vs = ks + 64 * 65;                                         // [64][64]
-            float *ps = vs + 64 * 64;                                         // [32][64]
-            float *sm = ps + 32 * 64;                                         // [2][32] slice max per tile
-            float *sl = sm + 64;                                              // [2][32]
-            if (!es_wait(a, a.epoch + g, &s_ok)) return;
-            ES_MARK(2);
+            float *ks = qs + 32 * 64;                                         // [2][64][65]
+            float *vs = ks + 2 * 64 * 65;                                     // [2][64][64]
+            float *ps = vs + 2 * 64 * 64;                                     // [2][32][64]
+            float *sm = ps + 2 * 32 * 64;                                     // [2][32] tile max
+            float *sl = sm + 64;                                              // [2][32] tile sum
             const __amdgpu_buffer_rsrc_t qr = es_rsrc(a.qbuf), kr_ = es_rsrc(L.kring), vr_ = es_rsrc(L.vring);
+            // thread -> (key, 4 dims) x 2 per tile
+            es_u32x4 kk[2][2], vv[2][2];
+            auto kv_off = [&](int tile, int it, int &pos) -> unsigned {
+                const int i = tid + it * ES_THREADS, key = i >> 4, c = (i & 15) * 4;
+                pos = t0 + 64 * tile + key;
+                return (unsigned)(((size_t)(pos % a.ring_cap) * ES_QD + head * 64 + c) * 4);
+            };
+#pragma unroll
+            for (int tile = 0; tile < 2; tile++)
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    int pos; const unsigned off = kv_off(tile, it, pos);
+                    kk[tile][it] = es_u32x4{0u, 0u, 0u, 0u}; vv[tile][it] = kk[tile][it];
+                    if (pos <= t1 && pos < a.pos0) { kk[tile][it] = es_ld16(kr_, off); vv[tile][it] = es_ld16(vr_, off); }
+                }
+            if (!es_wait(a, a.epoch + g, &s_ok, EsNeedHead{xcd, widx & 3})) return;
+            ES_MARK(2);
             {
                 const int r = tid >> 4, c = (tid & 15) * 4;                    // 512 threads = 32 rows x 16 column groups
                 es_u32x4 v = es_u32x4{0u, 0u, 0u, 0u};
                 if (r < n) v = es_ld16(qr, (unsigned)(((size_t)r * ES_QD + head * 64 + c) * 4));
-                *reinterpret_cast<es_u32x4 *>(&qs[r * 64 + c]) = v;
-            }
-            const int rows_pw = 4;                                            // 8 waves x 4 query rows
-            float oacc[4] = {0.f, 0.f, 0.f, 0.f};                              // P.V of tile 0 (lane = dim), rescaled when tile 1 arrives
-            for (int tile = 0; tile < 2; tile++) {
-                const int tb = t0 + 64 * tile;
-                if (tile == 1 && tb > t1) break;
-                __syncthreads();                                              // (tile 1: everybody is done with ks / vs / ps of tile 0)
-                for (int i = tid; i < 1024; i += ES_THREADS) {
-                    const int key = i >> 4, c = (i & 15) * 4;
-                    const int pos = tb + key;
-                    es_u32x4 kk = es_u32x4{0u, 0u, 0u, 0u}, vv = kk;
-                    if (pos <= t1) {
-                        const unsigned off = (unsigned)(((size_t)(pos % a.ring_cap) * ES_QD + head * 64 + c) * 4);
-                        kk = es_ld16(kr_, off); vv = es_ld16(vr_, off);
+#pragma unroll
+                for (int tile = 0; tile < 2; tile++)
+#pragma unroll
+                    for (int it = 0; it < 2; it++) {
+                        int pos; const unsigned off = kv_off(tile, it, pos);
+                        if (pos <= t1 && pos >= a.pos0) { kk[tile][it] = es_ld16(kr_, off); vv[tile][it] = es_ld16(vr_, off); }      // this chunk's own rows
                     }
-                    ks[key * 65 + c] = __uint_as_float(kk.x); ks[key * 65 + c + 1] = __uint_as_float(kk.y);
-                    ks[key * 65 + c + 2] = __uint_as_float(kk.z); ks[key * 65 + c + 3] = __uint_as_float(kk.w);
-                    *reinterpret_cast<es_u32x4 *>(&vs[key * 64 + c]) = vv;
-                }
-                __syncthreads();
-                {   // scores: wave = 4 query rows, lane = key
-                    float kreg[64];
+                *reinterpret_cast<es_u32x4 *>(&qs[r * 64 + c]) = v;
 #pragma unroll
-                    for (int d = 0; d < 64; d++) kreg[d] = ks[lane * 65 + d];
-                    const int t = tb + lane;
+                for (int tile = 0; tile < 2; tile++)
+#pragma unroll
+                    for (int it = 0; it < 2; it++) {
+                        const int i = tid + it * ES_THREADS, key = i >> 4, cc = (i & 15) * 4;
+                        float *kd = ks + (tile * 64 + key) * 65 + cc;
+                        kd[0] = __uint_as_float(kk[tile][it].x); kd[1] = __uint_as_float(kk[tile][it].y);
+                        kd[2] = __uint_as_float(kk[tile][it].z); kd[3] = __uint_as_float(kk[tile][it].w);
+                        *reinterpret_cast<es_u32x4 *>(&vs[(tile * 64 + key) * 64 + cc]) = vv[tile][it];
+                    }
+            }
+            __syncthreads();
+            // scores: wave = 4 query rows (all four in flight), lane = key
+            for (int tile = 0; tile < ntile; tile++) {
+                float kreg[64];
+#pragma unroll
+                for (int d = 0; d < 64; d++) kreg[d] = ks[(tile * 64 + lane) * 65 + d];
+                const int t = t0 + 64 * tile + lane;
+                // two rows at a time (two independent FMA chains; all four in flight make the scheduler hoist the q reads of the unrolled loop:
+                // 250 registers and spills all over the kernel)
 #pragma unroll 1
-                    for (int r = 0; r < rows_pw; r++) {
-                        const int row = wv * rows_pw + r, P = a.pos0 + row;
-                        float s = 0.f;
+                for (int rp = 0; rp < 4; rp += 2) {
+                    float sc[2] = {0.f, 0.f};
 #pragma unroll
-                        for (int d = 0; d < 64; d += 4) {
-                            const float4 q4 = *reinterpret_cast<const float4 *>(&qs[row * 64 + d]);
-                            s = fmaf(q4.x, kreg[d], s); s = fmaf(q4.y, kreg[d + 1], s); s = fmaf(q4.z, kreg[d + 2], s); s = fmaf(q4.w, kreg[d + 3], s);
+                    for (int d = 0; d < 64; d += 4) {
+#pragma unroll
+                        for (int r = 0; r < 2; r++) {
+                            const float4 q4 = *reinterpret_cast<const float4 *>(&qs[(wv * 4 + rp + r) * 64 + d]);
+                            sc[r] = fmaf(q4.x, kreg[d], sc[r]); sc[r] = fmaf(q4.y, kreg[d + 1], sc[r]); sc[r] = fmaf(q4.z, kreg[d + 2], sc[r]); sc[r] = fmaf(q4.w, kreg[d + 3], sc[r]);
                         }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const int row = wv * 4 + rp + r, P = a.pos0 + row;
                         const bool ok = row < n && t <= t1 && t <= P && t >= P - a.window + 1;
-                        s = ok ? s * a.scale : -1e30f;
-                        const float mx = as_dpp_max(s);
-                        const float pe = (ok && mx > -1e29f) ? expf(s - mx) : 0.f;
+                        const float sv = ok ? sc[r] * a.scale : -1e30f;
+                        const float mx = as_dpp_max(sv);
+                        const float pe = (ok && mx > -1e29f) ? expf(sv - mx) : 0.f;
                         const float lsum = as_dpp_sum(pe);
-                        ps[row * 64 + lane] = pe;
+                        ps[(tile * 32 + row) * 64 + lane] = pe;
                         if (lane == 0) { sm[tile * 32 + row] = mx > -1e29f ? mx : -1e30f; sl[tile * 32 + row] = lsum; }
                     }
                 }
-                __syncthreads();
-                {   // P.V: wave = 4 query rows, lane = dim
-                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+            // P.V: wave = 4 query rows, lane = dim; the two tiles are merged on their common max
+            float oacc[4] = {0.f, 0.f, 0.f, 0.f}, om[4] = {-1e30f, -1e30f, -1e30f, -1e30f}, ol[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int tile = 0; tile < ntile; tile++) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-                    for (int k4 = 0; k4 < 64; k4 += 4) {
-                        const float v0 = vs[k4 * 64 + lane], v1 = vs[(k4 + 1) * 64 + lane], v2 = vs[(k4 + 2) * 64 + lane], v3 = vs[(k4 + 3) * 64 + lane];
+                for (int k4 = 0; k4 < 64; k4 += 4) {
+                    const float *vb = vs + (tile * 64 + k4) * 64 + lane;
+                    const float v0 = vb[0], v1 = vb[64], v2 = vb[128], v3 = vb[192];
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const float4 p4 = *reinterpret_cast<const float4 *>(&ps[(wv * 4 + r) * 64 + k4]);
-                            acc[r] = fmaf(p4.x, v0, acc[r]); acc[r] = fmaf(p4.y, v1, acc[r]); acc[r] = fmaf(p4.z, v2, acc[r]); acc[r] = fmaf(p4.w, v3, acc[r]);
-                        }
+                    for (int r = 0; r < 4; r++) {
+                        const float4 p4 = *reinterpret_cast<const float4 *>(&ps[(tile * 32 + wv * 4 + r) * 64 + k4]);
+                        acc[r] = fmaf(p4.x, v0, acc[r]); acc[r] = fmaf(p4.y, v1, acc[r]); acc[r] = fmaf(p4.z, v2, acc[r]); acc[r] = fmaf(p4.w, v3, acc[r]);
                     }
-                    if (tile == 0) {
+                }
 #pragma unroll
-                        for (int r = 0; r < 4; r++) oacc[r] = acc[r];
-                    } else {      // merge the two tiles of this slice: common max, rescale
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int row = wv * 4 + r;
-                            const float m0 = sm[row], m1 = sm[32 + row], mm = fmaxf(m0, m1);
-                            const float f0 = expf(m0 - mm), f1 = expf(m1 - mm);
-                            oacc[r] = oacc[r] * f0 + acc[r] * f1;
-                            if (lane == 0) { sl[row] = sl[row] * f0 + sl[32 + row] * f1; sm[row] = mm; }
-                        }
+                for (int r = 0; r < 4; r++) {
+                    const int row = wv * 4 + r;
+                    const float mt = sm[tile * 32 + row], lt = sl[tile * 32 + row];
+                    if (tile == 0) { oacc[r] = acc[r]; om[r] = mt; ol[r] = lt; }
+                    else {
+                        const float mm = fmaxf(om[r], mt), f0 = expf(om[r] - mm), f1 = expf(mt - mm);
+                        oacc[r] = oacc[r] * f0 + acc[r] * f1; ol[r] = ol[r] * f0 + lt * f1; om[r] = mm;
                     }
                 }
             }
-            if (t0 > t1 && tid < 32) { sm[tid] = -1e30f; sl[tid] = 0.f; }      // an empty slice (start of a stream): neutral partial
-            __syncthreads();
             {
                 const __amdgpu_buffer_rsrc_t por = es_rsrc(a.part_o), pmr = es_rsrc(a.part_ml);
                 const size_t base = ((size_t)head * ES_NSL + slice) * 32;
@@ -484,7 +523,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
                     const int row = wv * 4 + r;
                     if (row < n) {
                         es_st4(por, (unsigned)(((base + row) * 64 + lane) * 4), oacc[r]);
-                        if (lane == 0) es_st8(pmr, (unsigned)((base + row) * 8), es_u32x2{__float_as_uint(sm[row]), __float_as_uint(sl[row])});
+                        if (lane == 0) es_st8(pmr, (unsigned)((base + row) * 8), es_u32x2{__float_as_uint(om[r]), __float_as_uint(ol[r])});
                     }
                 }
             }
@@ -509,46 +548,41 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
                     wq[t][1] = es_ldw(wr, wo_ + 64);
                 }
             };
-            es_poll(a, a.epoch + g, &s_ok);              // (wave 0 only)
+            es_poll(a, a.epoch + g, &s_ok, EsNeedHead{xcd, widx & 3});      // (wave 0 only)
             issue();
             if (!es_join(&s_ok)) return;
             ES_MARK(4);
-            // merge the head's 8 key slices (k_attn_combine's arithmetic): wave = rows wv, wv + 8, ..; lane = dim
+            // merge the head's 8 key slices (k_attn_combine's arithmetic): thread = (row, 4 dims)
             unsigned char *afr = es_lds;                  // A fragments [2 ks][3 p][2 u][64 lanes][16 B] = 12 KiB
             {
                 const __amdgpu_buffer_rsrc_t por = es_rsrc(a.part_o), pmr = es_rsrc(a.part_ml);
-                float o[4][ES_NSL]; es_u32x2 ml[4][ES_NSL];
+                const int row = tid >> 4, d4 = (tid & 15) * 4;
+                const int rl = min(row, n - 1);
+                es_u32x4 o[ES_NSL]; es_u32x2 ml[ES_NSL];
 #pragma unroll
-                for (int rr = 0; rr < 4; rr++) {
-                    const int row = min(wv + 8 * rr, n - 1);
-#pragma unroll
-                    for (int s = 0; s < ES_NSL; s++) {
-                        const size_t idx = ((size_t)head * ES_NSL + s) * 32 + row;
-                        o[rr][s] = es_ld4(por, (unsigned)((idx * 64 + lane) * 4));
-                        ml[rr][s] = es_ld8(pmr, (unsigned)(idx * 8));
-                    }
+                for (int sI = 0; sI < ES_NSL; sI++) {
+                    const size_t idx = ((size_t)head * ES_NSL + sI) * 32 + rl;
+                    o[sI] = es_ld16(por, (unsigned)((idx * 64 + d4) * 4));
+                    ml[sI] = es_ld8(pmr, (unsigned)(idx * 8));
                 }
+                float mm = -1e30f, ll = 0.f;
+                float ov[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int rr = 0; rr < 4; rr++) {
-                    const int row = wv + 8 * rr;
-                    float mm = -1e30f, ll = 0.f, ov = 0.f;
+                for (int sI = 0; sI < ES_NSL; sI++) mm = fmaxf(mm, __uint_as_float(ml[sI].x));
 #pragma unroll
-                    for (int s = 0; s < ES_NSL; s++) mm = fmaxf(mm, __uint_as_float(ml[rr][s].x));
-#pragma unroll
-                    for (int s = 0; s < ES_NSL; s++) {
-                        const float f = expf(__uint_as_float(ml[rr][s].x) - mm);
-                        ll += __uint_as_float(ml[rr][s].y) * f;
-                        ov += o[rr][s] * f;
-                    }
-                    const float av = (row < n && ll > 0.f) ? ov * (1.0f / ll) : 0.f;
-                    if (row < 16 * MU) {
-                        uint32_t h, mi, lw;
-                        split3(av, h, mi, lw);
-                        const int k = lane;
-                        *reinterpret_cast<uint16_t *>(afr + es_elem_off(row, k, 0)) = (uint16_t)(h >> 16);
-                        *reinterpret_cast<uint16_t *>(afr + es_elem_off(row, k, 1)) = (uint16_t)(mi >> 16);
-                        *reinterpret_cast<uint16_t *>(afr + es_elem_off(row, k, 2)) = (uint16_t)(lw >> 16);
-                    }
+                for (int sI = 0; sI < ES_NSL; sI++) {
+                    const float f = expf(__uint_as_float(ml[sI].x) - mm);
+                    ll += __uint_as_float(ml[sI].y) * f;
+                    ov[0] += __uint_as_float(o[sI].x) * f; ov[1] += __uint_as_float(o[sI].y) * f;
+                    ov[2] += __uint_as_float(o[sI].z) * f; ov[3] += __uint_as_float(o[sI].w) * f;
+                }
+                const float il = (row < n && ll > 0.f) ? 1.0f / ll : 0.f;
+                if (row < 16 * MU) {
+                    es_u32x2 ph, pm, pl;
+                    es_split4(ov[0] * il, ov[1] * il, ov[2] * il, ov[3] * il, ph, pm, pl);
+                    *reinterpret_cast<es_u32x2 *>(afr + es_elem_off(row, d4, 0)) = ph;
+                    *reinterpret_cast<es_u32x2 *>(afr + es_elem_off(row, d4, 1)) = pm;
+                    *reinterpret_cast<es_u32x2 *>(afr + es_elem_off(row, d4, 2)) = pl;
                 }
             }
             __syncthreads();
@@ -588,7 +622,9 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
         // =========================== F3: x' = x + bo + wo partials; planes of x' g2 ==========================================
         {
             ES_IDS();
-            if (!es_wait(a, a.epoch + g, &s_ok)) return;
+            // (a finish task (row, column block cb) reads the partials of column group ng == cb from all 32 heads: workgroups f with f >> 5 == cb)
+            if (w < n * ES_CB) { if (!es_wait(a, a.epoch + g, &s_ok, EsNeedShift{5, w & 7})) return; }
+            else if (!es_wait(a, a.epoch + g, &s_ok, EsNeedNone())) return;
             ES_MARK(6);
             if (w < n * ES_CB)
                 es_finish(a, w, a.xa, a.xb, a.wo_part, ES_HEADS, (size_t)32 * ES_D, L.bo, L.n2, a.ssq + 32 * ES_CB, true, es_lds);
@@ -614,7 +650,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
                     }
                 }
             };
-            es_poll(a, a.epoch + g, &s_ok);              // (wave 0 only)
+            es_poll(a, a.epoch + g, &s_ok, EsNeedAll());            // (wave 0 only; every finish task: global)
             issue();
             if (!es_join(&s_ok)) return;
             ES_MARK(8);
@@ -709,7 +745,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
                     }
                 }
             };
-            es_poll(a, a.epoch + g, &s_ok);              // (wave 0 only)
+            es_poll(a, a.epoch + g, &s_ok, EsNeedShift{4, kg});     // (wave 0 only; h units 320 kg .. + 319 = P4's workgroups 16 kg .. + 15)
             issue();
             if (!es_join(&s_ok)) return;
             ES_MARK(10);
@@ -774,7 +810,9 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
         // =========================== F5: x = x' + b2 + w2 partials; planes of x g1[l + 1] ===================================
         {
             ES_IDS();
-            if (!es_wait(a, a.epoch + g, &s_ok)) return;
+            // (columns 160 cb .. + 159 = P5's row groups 2 cb and 2 cb + 1, all 16 K groups: workgroups f with f >> 5 == cb)
+            if (w < n * ES_CB) { if (!es_wait(a, a.epoch + g, &s_ok, EsNeedShift{5, w & 7})) return; }
+            else if (!es_wait(a, a.epoch + g, &s_ok, EsNeedNone())) return;
             ES_MARK(12);
             const bool last = l + 1 == a.n_layers;
             if (w < n * ES_CB)

@@ -25,6 +25,9 @@
 // a phase begins when wave 0 has seen the flags it depends on (one 16-byte sc1 load per lane = all 256 flags per poll), bounded
 // by ACTIVE spin time (DfSpin, vox_common.h); a time-out flags the chunk and the host repeats it on the 8-launch path.  The flag
 // values are epoch + phase index with a per-launch epoch, so nothing is ever cleared.
+// Measured and not kept (profiles/NOTES.md, round 6): three polls in flight instead of one (the flag words become a hot spot: every hand-off
+// and every body got slower, 62.3 -> 66.4 us per layer); the attention phase on packed f32 FMAs (v_pk_fma_f32 with transposed q / p tiles: the
+// compiler serialises one LDS read + one dependent FMA pair, 9.6 -> 15.1 us).
 // Every phase's WEIGHT fragments are requested before the wait for the previous phase (waves 1 - 7; wave 0 polls first: a poll queued
 // behind 100 KB of weight loads would return when they land), so the weight stream runs under the hand-offs.
 //
@@ -50,7 +53,7 @@ constexpr int ES_KG5 = 16, ES_NG5 = 16;   // P5: K groups (320 wide) x row group
 constexpr int ES_NG3 = 8;                 // P3: column groups (160 rows of Wo) per head
 constexpr int ES_PHASES = 7;
 constexpr int ES_TL_STRIDE = 32;          // timeline words per workgroup (VOX_HIP_ENC_TL)
-constexpr int ES_LDS_BYTES = 92 * 1024;
+constexpr int ES_LDS_BYTES = 90 * 1024;
 
 struct EncStackLayer {
     const uint16_t *wqkv;                 // [6144][1280] q rows, k rows, v rows
@@ -164,28 +167,16 @@ __device__ __forceinline__ void es_poll(const EncStackArgs &a, unsigned target, 
         const __amdgpu_buffer_rsrc_t fr = es_rsrc(a.flags);
         const int f0 = threadIdx.x * 4;
         const bool n0 = need(f0), n1 = need(f0 + 1), n2 = need(f0 + 2), n3 = need(f0 + 3);
-        auto done = [&](const es_u32x4 f) -> bool {
-            const bool ok = (!n0 || (int)(f.x - target) >= 0) && (!n1 || (int)(f.y - target) >= 0) && (!n2 || (int)(f.z - target) >= 0) && (!n3 || (int)(f.w - target) >= 0);
-            return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
-        };
-        // Three polls in flight, a few hundred ns apart: a poll is a round trip to memory (1 - 2 us under load), and with one at a time
-        // the flag of the last producer is seen up to a whole round trip late.
         int res = 1;
-        es_u32x4 fa = es_ld16(fr, threadIdx.x * 16);
-        __builtin_amdgcn_s_sleep(4);
-        es_u32x4 fb = es_ld16(fr, threadIdx.x * 16);
-        __builtin_amdgcn_s_sleep(4);
-        es_u32x4 fc = es_ld16(fr, threadIdx.x * 16);
-        DfSpin sp; df_spin_begin(sp);
+        DfSpin sp;
         for (unsigned it = 0;; it++) {
-            if (done(fa)) break;
-            fa = es_ld16(fr, threadIdx.x * 16);
-            if (done(fb)) break;
-            fb = es_ld16(fr, threadIdx.x * 16);
-            if (done(fc)) break;
-            fc = es_ld16(fr, threadIdx.x * 16);
-            if (df_spin_expired(sp, a.err, a.spin_limit, 11u, target)) { res = 0; break; }
-            if ((it & 3u) == 3u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { res = 0; break; }
+            const es_u32x4 f = es_ld16(fr, threadIdx.x * 16);
+            const bool ok = (!n0 || (int)(f.x - target) >= 0) && (!n1 || (int)(f.y - target) >= 0) && (!n2 || (int)(f.z - target) >= 0) && (!n3 || (int)(f.w - target) >= 0);
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+            if (it == 0) df_spin_begin(sp);
+            else if (df_spin_expired(sp, a.err, a.spin_limit, 11u, target)) { res = 0; break; }
+            if ((it & 7u) == 7u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { res = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
         }
         if (threadIdx.x == 0) *s_ok = res;
     }
@@ -416,11 +407,11 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
             const int nkeys = hi - lo + 1, KS = (nkeys + ES_NSL - 1) / ES_NSL;
             const int t0 = lo + slice * KS, t1 = min(t0 + KS - 1, hi);        // this slice's keys [t0, t1] (empty if t0 > t1)
             const int ntile = t0 > t1 ? 0 : (t1 - t0) / 64 + 1;               // 0, 1 or 2
-            float *qT = reinterpret_cast<float *>(es_lds);                    // [64 dims][32 rows]: a wave's 4 rows of one dim = one 16-byte broadcast read
-            float *ks = qT + 64 * 32;                                         // [2][64][65]
+            float *qs = reinterpret_cast<float *>(es_lds);                    // [32][64]
+            float *ks = qs + 32 * 64;                                         // [2][64][65]
             float *vs = ks + 2 * 64 * 65;                                     // [2][64][64]
-            float *pT = vs + 2 * 64 * 64;                                     // [2][64 keys][36]: a wave's 4 rows of one key = one 16-byte read
-            float *sm = pT + 2 * 64 * 36;                                     // [2][32] tile max
+            float *ps = vs + 2 * 64 * 64;                                     // [2][32][64]
+            float *sm = ps + 2 * 32 * 64;                                     // [2][32] tile max
             float *sl = sm + 64;                                              // [2][32] tile sum
             const __amdgpu_buffer_rsrc_t qr = es_rsrc(a.qbuf), kr_ = es_rsrc(L.kring), vr_ = es_rsrc(L.vring);
             // thread -> (key, 4 dims) x 2 per tile
@@ -451,8 +442,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
                         int pos; const unsigned off = kv_off(tile, it, pos);
                         if (pos <= t1 && pos >= a.pos0) { kk[tile][it] = es_ld16(kr_, off); vv[tile][it] = es_ld16(vr_, off); }      // this chunk's own rows
                     }
-                qT[(c + 0) * 32 + r] = __uint_as_float(v.x); qT[(c + 1) * 32 + r] = __uint_as_float(v.y);
-                qT[(c + 2) * 32 + r] = __uint_as_float(v.z); qT[(c + 3) * 32 + r] = __uint_as_float(v.w);
+                *reinterpret_cast<es_u32x4 *>(&qs[r * 64 + c]) = v;
 #pragma unroll
                 for (int tile = 0; tile < 2; tile++)
 #pragma unroll
@@ -465,51 +455,53 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
                     }
             }
             __syncthreads();
-            // scores: wave = 4 query rows, lane = key; packed f32 FMAs (v_pk_fma_f32: two rows per instruction, the key's value broadcast)
-            typedef float es_f2 __attribute__((ext_vector_type(2)));
+            // scores: wave = 4 query rows (all four in flight), lane = key
             for (int tile = 0; tile < ntile; tile++) {
                 float kreg[64];
 #pragma unroll
                 for (int d = 0; d < 64; d++) kreg[d] = ks[(tile * 64 + lane) * 65 + d];
                 const int t = t0 + 64 * tile + lane;
-                // one row PAIR at a time (all four rows in flight make the scheduler hoist the q reads of the unrolled loop: spills all over the kernel)
+                // two rows at a time (two independent FMA chains; all four in flight make the scheduler hoist the q reads of the unrolled loop:
+                // 250 registers and spills all over the kernel)
 #pragma unroll 1
                 for (int rp = 0; rp < 4; rp += 2) {
-                    es_f2 s2 = {0.f, 0.f};
+                    float sc[2] = {0.f, 0.f};
 #pragma unroll
-                    for (int d = 0; d < 64; d++) {
-                        const es_f2 q2 = *reinterpret_cast<const es_f2 *>(&qT[d * 32 + wv * 4 + rp]);
-                        s2 = __builtin_elementwise_fma(q2, es_f2{kreg[d], kreg[d]}, s2);
+                    for (int d = 0; d < 64; d += 4) {
+#pragma unroll
+                        for (int r = 0; r < 2; r++) {
+                            const float4 q4 = *reinterpret_cast<const float4 *>(&qs[(wv * 4 + rp + r) * 64 + d]);
+                            sc[r] = fmaf(q4.x, kreg[d], sc[r]); sc[r] = fmaf(q4.y, kreg[d + 1], sc[r]); sc[r] = fmaf(q4.z, kreg[d + 2], sc[r]); sc[r] = fmaf(q4.w, kreg[d + 3], sc[r]);
+                        }
                     }
-                    const float sc[2] = {s2.x, s2.y};
-                    float pe2[2];
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
                         const int row = wv * 4 + rp + r, P = a.pos0 + row;
                         const bool ok = row < n && t <= t1 && t <= P && t >= P - a.window + 1;
                         const float sv = ok ? sc[r] * a.scale : -1e30f;
                         const float mx = as_dpp_max(sv);
-                        pe2[r] = (ok && mx > -1e29f) ? expf(sv - mx) : 0.f;
-                        const float lsum = as_dpp_sum(pe2[r]);
+                        const float pe = (ok && mx > -1e29f) ? expf(sv - mx) : 0.f;
+                        const float lsum = as_dpp_sum(pe);
+                        ps[(tile * 32 + row) * 64 + lane] = pe;
                         if (lane == 0) { sm[tile * 32 + row] = mx > -1e29f ? mx : -1e30f; sl[tile * 32 + row] = lsum; }
                     }
-                    *reinterpret_cast<es_f2 *>(&pT[(tile * 64 + lane) * 36 + wv * 4 + rp]) = es_f2{pe2[0], pe2[1]};
                 }
             }
             __syncthreads();
             // P.V: wave = 4 query rows, lane = dim; the two tiles are merged on their common max
             float oacc[4] = {0.f, 0.f, 0.f, 0.f}, om[4] = {-1e30f, -1e30f, -1e30f, -1e30f}, ol[4] = {0.f, 0.f, 0.f, 0.f};
             for (int tile = 0; tile < ntile; tile++) {
-                es_f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-#pragma unroll 8
-                for (int k = 0; k < 64; k++) {
-                    const float v = vs[(tile * 64 + k) * 64 + lane];
-                    const float4 p4 = *reinterpret_cast<const float4 *>(&pT[(tile * 64 + k) * 36 + wv * 4]);
-                    const es_f2 v2 = {v, v};
-                    a01 = __builtin_elementwise_fma(es_f2{p4.x, p4.y}, v2, a01);
-                    a23 = __builtin_elementwise_fma(es_f2{p4.z, p4.w}, v2, a23);
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                for (int k4 = 0; k4 < 64; k4 += 4) {
+                    const float *vb = vs + (tile * 64 + k4) * 64 + lane;
+                    const float v0 = vb[0], v1 = vb[64], v2 = vb[128], v3 = vb[192];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float4 p4 = *reinterpret_cast<const float4 *>(&ps[(tile * 32 + wv * 4 + r) * 64 + k4]);
+                        acc[r] = fmaf(p4.x, v0, acc[r]); acc[r] = fmaf(p4.y, v1, acc[r]); acc[r] = fmaf(p4.z, v2, acc[r]); acc[r] = fmaf(p4.w, v3, acc[r]);
+                    }
                 }
-                const float acc[4] = {a01.x, a01.y, a23.x, a23.y};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int row = wv * 4 + r;

@@ -598,6 +598,58 @@ def test_handoff_epoch_counter_restarts_in_mid_decode(vox, name, below):
     assert (f.value, a.value) == (0, 1), (f.value, a.value, r.value, holes.value, longest.value)
 
 
+def test_bounded_spins_ignore_time_the_dispatch_was_switched_out(vox):
+    """Round 6 (the recovered hand-off time-outs of round 5): a decode batch runs 26-layer launches whose workgroups spin on each other,
+    bounded by 5 ms.  While one decodes the 300 s clip, a second host thread does what a long test process does all the time - device
+    allocations and frees, large host mappings coming and going, engines (HSA queues) created and destroyed.  Any of these can make
+    the driver switch the process's queues out for a while (the whole dispatch is frozen and restored); a spin that measured wall-clock
+    time across such a hole called it a time-out.  The spins budget ACTIVE time now and count the holes they see: ids must be the
+    reference's and no hand-off may time out, whatever the side thread does; the holes are recorded (diagnostic)."""
+    import ctypes as C
+    import threading
+    h = vox.hip
+    h.vox_hip_fuse_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long)]
+    h.vox_hip_spin_holes.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_double)]
+    h.vox_hip_device_alloc.restype = C.c_void_p
+    h.vox_hip_device_alloc.argtypes = [C.c_void_p, C.c_size_t]
+    h.vox_hip_device_free.argtypes = [C.c_void_p, C.c_void_p]
+    g = gold("stream_full_batch300.npz")
+    audio = golden_audio(g)
+    stop = threading.Event()
+    counts = {"alloc": 0, "maps": 0, "engines": 0}
+    with vox.Model(model_dir("full")) as m:
+        f, a, r = C.c_int(), C.c_int(), C.c_long()
+        if h.vox_hip_fuse_stats(m.engine, C.byref(f), C.byref(a), C.byref(r)) != 0:
+            pytest.skip("engine without the fused decode kernel")
+
+        def churn():
+            i = 0
+            while not stop.is_set():
+                p_ = h.vox_hip_device_alloc(m.engine, (256 << 20) + (i % 7) * (64 << 20))
+                if p_:
+                    h.vox_hip_device_free(m.engine, p_)
+                    counts["alloc"] += 1
+                big = np.ones(48 << 20, np.uint8)              # a fresh 48 MB host mapping, touched, then unmapped
+                del big
+                counts["maps"] += 1
+                if i % 8 == 0:
+                    with vox.Model(model_dir("tiny"), enc_window=48, dec_window=64):
+                        counts["engines"] += 1
+                i += 1
+        th = threading.Thread(target=churn)
+        th.start()
+        try:
+            got = [m.transcribe(audio)["tokens"] for _ in range(2)]
+        finally:
+            stop.set(); th.join()
+        h.vox_hip_fuse_stats(m.engine, C.byref(f), C.byref(a), C.byref(r))
+        holes, longest = C.c_ulonglong(), C.c_double()
+        assert h.vox_hip_spin_holes(m.engine, C.byref(holes), C.byref(longest)) == 0
+    diag("spin_holes_under_churn", failures=f.value, armed=a.value, spin_holes=int(holes.value), longest_hole_us=float(longest.value), **counts)
+    assert all(np.array_equal(np.asarray(t), g["tokens"]) for t in got)
+    assert (f.value, a.value) == (0, 1), (f.value, a.value, int(holes.value), float(longest.value), counts)
+
+
 def test_reference_weight_views_are_filled(small):
     """vox_ctx_t starts with the reference's fields (voxtral.h:154-204): the bf16 views point at the checkpoint's bytes,
     the f32 views hold the load_f32 conversions, the big f32 variants are NULL ("NULL if bf16")."""
@@ -708,6 +760,24 @@ def test_fast_decode_kernels_at_long_context_and_ring_wrap(vox, n_prompt, window
     diag(f"fast_vs_generic_{n_prompt}_{window}", err=err, first=[int(f0), int(f1)], same_steps=same)
     assert f0 == f1
     assert same >= min(n_steps, 95), same          # the wrap (step 88) is inside the compared range
+    assert err < LOGIT_TOL, err
+
+
+def test_production_decode_kernels_cross_the_ring_wrap_at_the_real_window(vox):
+    """Round 6: the decoder's K/V ring (8192 + 1024 slots) wraps at position 9216 and the 8192-position window has been sliding since
+    position 8192 (the reference compacts its cache there: voxtral_decoder.c:317-347, 615-623).  deep_wrap pins that to the reference
+    at width 384, i.e. on the generic GEMV chain; here the PRODUCTION launches of the 4B geometry (one k_ffn_attn12<LONG> per layer,
+    32 key slices) decode positions 9150 .. 9349 - across slot 9216 - against the launch-per-GEMV chain (VOX_HIP_DISABLE=fused) on
+    the same 9150 prefilled rows: same ids, logits within the tolerance."""
+    n_prompt, n_steps = 9150, 200
+    f0, t0, l0 = _decode_after_long_prefill(vox, n_prompt, n_steps, 11)
+    f1, t1, l1 = _decode_after_long_prefill(vox, n_prompt, n_steps, 11, env={"VOX_HIP_DISABLE": "fused"})
+    same = int(np.argmax(t0 != t1)) if (t0 != t1).any() else n_steps
+    upto = same + 1 if same < n_steps else same
+    err = float(np.abs(l0[:upto] - l1[:upto]).max())
+    diag("ring_wrap_real_window", err=err, first=[int(f0), int(f1)], same_steps=same)
+    assert f0 == f1
+    assert same >= 120, same                       # position 9216 (step 66) and well beyond
     assert err < LOGIT_TOL, err
 
 

@@ -193,24 +193,33 @@ def cpu_baseline(model_dir_full, preset_dims):
         # extrapolation of a 100-row chunk is a lower bound), 38-row prefill, 386 steps
         est = t_enc * 1696 / 100 + t_pre + 386 * t_step
         measured = None
-        try:       # the unmodified reference CLI run end to end on a GPU-box host (tools/cpu_baseline_cli.py), committed per round
-            for prof in ("r05_cpu_baseline_cli.json", "r04_cpu_baseline_cli.json", "r03_cpu_baseline_cli.json", "r02_cpu_baseline_cli.json"):
-                fp = os.path.join(ROOT, "profiles", prof)
-                if os.path.exists(fp):
-                    with open(fp) as fh:
-                        measured = dict(json.load(fh), source="profiles/" + prof)
-                    break
+        try:       # the unmodified reference CLI run end to end on a GPU-box host (tools/cpu_baseline_cli.py), committed per round: the newest one
+            import glob
+            profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_cpu_baseline_cli.json")), reverse=True)
+            if profs:
+                with open(profs[0]) as fh:
+                    measured = dict(json.load(fh), source="profiles/" + os.path.basename(profs[0]))
         except Exception:
             pass
-        return {"value": round(est / 30.0, 2), "unit": "wall s / audio s (RTF), 30 s clip, extrapolated from the sample",
-                "builder_run_end_to_end": measured,
-                "cores": os.cpu_count(), "kind": "reference",
-                "threads_note": "decode GEMV is single-threaded in the reference; OpenBLAS threads only in the M>1 GEMMs",
+        live = {"value": round(est / 30.0, 2), "unit": "wall s / audio s (RTF), 30 s clip, extrapolated from the live sample (a lower bound: "
+                                                        "encoder attention grows with the window)",
                 "decode_tok_s": round(1.0 / t_step, 3), "ms_per_decode_step": round(t_step * 1e3, 1),
                 "prefill38_s": round(t_pre, 2), "encoder_100rows_s": round(t_enc, 2),
                 "sample": "oracle/_ref (reference sources, -O3 -ffast-math, OpenBLAS): 38-row prefill + 12 decoder steps + one 100-row "
-                          "encoder chunk on the full-size synthetic checkpoint; RTF = (encoder_100rows x 16.96 + prefill + 386 steps) / 30 s "
-                          "(encoder attention grows with the window, so this is a lower bound)"}
+                          "encoder chunk on the full-size synthetic checkpoint, timed in this process; RTF = (encoder_100rows x 16.96 + prefill + 386 steps) / 30 s"}
+        out = {"cores": os.cpu_count(), "kind": "reference",
+               "threads_note": "decode GEMV is single-threaded in the reference; OpenBLAS threads only in the M>1 GEMMs"}
+        if measured and measured.get("rtf_process"):
+            # Round 6: `value` is the MEASURED figure - the reference's unmodified CLI on the headline clip, end to end, on a GPU-box host
+            # (198 - 221 s per run: it does not fit a bench line, so it is run by tools/cpu_baseline_cli.py and committed per round);
+            # the bounded sample timed live in this process rides along as a cross-check.
+            out.update({"value": measured["rtf_process"], "unit": "wall s / audio s (RTF), 30 s clip, the reference's unmodified CLI end to end",
+                        "decode_tok_s": measured.get("decode_tok_s"), "measured_run": measured, "live_sample": live,
+                        "sample": "value: the whole headline workload (30 s clip, 386 decoder steps) through oracle/_ref/voxtral_ref_full, measured by "
+                                  "tools/cpu_baseline_cli.py on a GPU-box host (" + measured["source"] + "); live_sample: " + live["sample"]})
+        else:
+            out.update(live)
+        return out
     except Exception as ex:  # the baseline must never take the benchmark down
         return {"error": str(ex)}
 
@@ -439,8 +448,10 @@ def stream_mode(args, model, audio, v, dims, golden, golden_name, audio_desc, md
     s_step = model.time_decoder_step(50, kv_len)
     wbytes, kvbytes, _ = decode_bytes(dims, kv_len)
     roofline = {
-        "bound": "hbm", "kernel": "few-rows encoder layer of a 25-row streaming chunk (k_skinny x4, k_attn_small, k_attn_combine, "
-                                  "k_rows_finish x2: voxtral_encoder.c:452-636), all launches of one layer together",
+        "bound": "hbm", "kernel": ("few-rows encoder layer of a 25-row streaming chunk inside k_enc_stack (all 32 layers of a chunk as ONE persistent launch, "
+                                   "seven phases per layer: voxtral_encoder.c:452-636)" if "enc_stack" in model.active_paths()[1] else
+                                   "few-rows encoder layer of a 25-row streaming chunk (k_skinny x4, k_attn_small, k_attn_combine, "
+                                   "k_rows_finish x2: voxtral_encoder.c:452-636), all launches of one layer together"),
         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
         "bytes_per_launch": lbytes, "avg_us_per_launch": None if us_layer is None else round(us_layer, 2),
         "launch_unit": "one encoder layer (its launches back to back); a chunk is %d layers = %.3f ms" % (dims.enc_layers, t_chunk * 1e3),
@@ -472,8 +483,89 @@ def stream_mode(args, model, audio, v, dims, golden, golden_name, audio_desc, md
     }
     if not args.no_cpu_baseline and args.preset == "full":
         out["cpu_baseline"] = cpu_baseline_stream(mdir, dims)
-    model.close()
-    print(json.dumps(out))
+    return out
+
+
+def batch_measure(v, model, dims, seconds, passes=1, weights="bf16"):
+    """One-feed transcription of the night1968 clip tiled to `seconds`, `passes` timed passes on a warm engine: the compact line of
+    a non-headline configuration (value = RTF, parity against the reference's golden of exactly this input, decode-step roofline)."""
+    audio, golden, golden_name, audio_desc = headline_audio(seconds, "batch")
+    v.hip.vox_hip_sync(model.engine)
+    t0 = time.time()
+    enc_ms = pre_ms = dec_ms = 0.0
+    dec_steps = 0
+    for _ in range(passes):
+        r = model.transcribe(audio)
+        t = model.timing()
+        enc_ms += t["encode_ms"]; pre_ms += t["prefill_ms"]; dec_ms += t["decode_ms"]; dec_steps += t["decode_steps"]
+    v.hip.vox_hip_sync(model.engine)
+    wall = (time.time() - t0) / passes
+    n_tok = len(r["tokens"])
+    kv_len = int(min(dims.dec_window, max(1, 38 + n_tok // 2)))          # the mean context of this clip's decode steps
+    s_step = model.time_decoder_step(30, kv_len)
+    wbytes, kvbytes, _ = decode_bytes(dims, kv_len)
+    if weights == "fp8":
+        wbytes //= 2
+    if weights == "bf16":
+        parity = parity_block(r["tokens"], golden, golden_name)
+    else:
+        # fp8 decode weights are not a parity mode: agreement with the bf16 reference's greedy ids, free-running (BASELINE config 5's own
+        # criterion is "tokens match bf16 greedy": first_divergence is where it stops holding)
+        ref = golden["tokens"] if golden is not None else None
+        if ref is None:
+            parity = {"checked": False, "reason": "no golden"}
+        else:
+            t_ = np.asarray(r["tokens"]); n_ = min(len(t_), len(ref))
+            first = next((int(i) for i in range(n_) if t_[i] != ref[i]), None)
+            parity = {"checked": True, "criterion": "BASELINE config 5: ids equal to the bf16 greedy run (free-running)", "steps": int(len(ref)),
+                      "first_divergence": first, "matches": first is None and len(t_) == len(ref),
+                      "free_run_agreement": round(float((t_[:n_] == ref[:n_]).mean()), 4),
+                      "note": "teacher-forced agreement and its margin analysis: profiles/r0*_fp8_agreement*.json, tests/test_gpu_parity.py::test_fp8_decode_weights_track_bf16"}
+    return {
+        "metric": "real-time-factor, one feed", "value": round(wall / seconds, 5), "unit": "wall s / audio s (RTF)", "ms_per_pass": round(wall * 1e3, 2),
+        "passes": passes, "decode_tok_s": round(dec_steps / (dec_ms * 1e-3), 1) if dec_ms > 0 else None,
+        "decode_ms_per_token": round(dec_ms / max(dec_steps, 1), 4), "encode_ms": round(enc_ms / passes, 2), "prefill_ms": round(pre_ms / passes, 2),
+        "decoder_steps": n_tok, "parity": parity, "active_paths": model.active_paths()[1],
+        "roofline": {"bound": "hbm", "kernel": "one decoder step at this clip's mean context (all launches of the step)", "kv_len": kv_len,
+                     "algorithmic_bytes": wbytes + kvbytes, "ms": round(s_step * 1e3, 4), "achieved": round((wbytes + kvbytes) / s_step / 1e9, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((wbytes + kvbytes) / s_step / 1e9 / HBM_PEAK_GBS, 4),
+                     "method": "HIP events around 30 steps (vox_hip_time_decoder_step)"},
+        "config": {"workload": f"Voxtral-4B (full synthetic checkpoint, {weights} decode weights) on 1xMI355X, single {seconds:g} s clip ({audio_desc}), "
+                               "one vox_stream_feed + finish, greedy decode", "audio_seconds": seconds, "decode_weights": weights},
+    }
+
+
+def other_configs(args, v, model, dims, mdir, local_rank, win):
+    """The non-headline configurations of BASELINE.json as short passes behind the headline's timed region, under "configs" of the same
+    JSON line (round 6: they used to exist only as builder-run files under profiles/): config 3 itself (300 s in 0.5 s feeds, ids against
+    the reference's run of the same feeds), the 300 s one-feed clip, and config 5 (fp8 decode weights).  Each carries value, parity,
+    roofline.frac and its own config.workload; a part that fails reports its error instead of taking the headline down."""
+    import types
+    res = {}
+    try:
+        audio, golden, golden_name, audio_desc = headline_audio(300.0, "stream")
+        a2 = types.SimpleNamespace(warmup=0, steps=1, seconds=300.0, no_cpu_baseline=True, preset=args.preset)
+        o = stream_mode(a2, model, audio, v, dims, golden, golden_name, audio_desc, mdir)
+        res["stream"] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "parity", "chunk_latency_ms", "tokens_per_pass", "config", "active_paths")}
+        rf = o["roofline"]
+        res["stream"]["roofline"] = {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "avg_us_per_launch", "method")}
+        res["stream"]["roofline"]["decode_step_frac"] = rf["decode_step"]["frac_of_peak"]
+    except Exception as ex:      # noqa: BLE001
+        res["stream"] = {"error": repr(ex)}
+    try:
+        res["batch300"] = batch_measure(v, model, dims, 300.0)
+    except Exception as ex:      # noqa: BLE001
+        res["batch300"] = {"error": repr(ex)}
+    try:
+        m8 = v.Model(mdir, device=local_rank, weights="fp8", **win)
+        try:
+            m8.transcribe(headline_audio(30.0, "batch")[0])          # warm-up pass
+            res["fp8"] = batch_measure(v, m8, m8.dims, 30.0, passes=2, weights="fp8")
+        finally:
+            m8.close()
+    except Exception as ex:      # noqa: BLE001
+        res["fp8"] = {"error": repr(ex)}
+    return res
 
 
 def main():
@@ -489,6 +581,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc FETCH_SIZE sub-run (roofline.traffic)")
     ap.add_argument("--no-graph-floor", action="store_true",
                     help="skip the hipGraph replay of the empty-launch probe (use when the command runs under rocprofv3 --kernel-trace)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the short passes of the non-headline configurations (config 3, the 300 s clip, fp8) that the default run appends under \"configs\"")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: BASELINE config 5 (row-scaled e4m3 decoder weights for the decode GEMVs); not the headline")
     ap.add_argument("--mode", default="batch", choices=["batch", "stream"],
@@ -565,7 +659,10 @@ def main():
             golden, golden_name = np.load(rs_path, allow_pickle=True), rs_name
 
     if args.mode == "stream":
-        return stream_mode(args, model, audio, v, dims, golden, golden_name, audio_desc, mdir)
+        out = stream_mode(args, model, audio, v, dims, golden, golden_name, audio_desc, mdir)
+        model.close()
+        print(json.dumps(out))
+        return
 
     def one_pass():
         r = model.transcribe(audio)
@@ -618,6 +715,8 @@ def main():
     }
     if not args.no_cpu_baseline and args.preset == "full":
         out["cpu_baseline"] = cpu_baseline(mdir, dims)
+    if (not args.no_configs and args.preset == "full" and args.weights == "bf16" and mdir != real_model and float(args.seconds) == 30.0):
+        out["configs"] = other_configs(args, v, model, dims, mdir, local_rank, win)
     model.close()
     print(json.dumps(out))
 

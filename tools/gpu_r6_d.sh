@@ -3,12 +3,13 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r6d; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 python -c "import sys; sys.path.insert(0,'tests'); from conftest import model_dir; print(model_dir('full'))" > /dev/null 2>&1
+if [ "$1" = "cli" ]; then
 echo "== reference CLI on this host (cpu baseline, ~200 s)"
 timeout 900 python tools/cpu_baseline_cli.py profiles/r06_cpu_baseline_cli.json > $O/cpu_cli.log 2>&1; echo "rc=$?"; tail -3 $O/cpu_cli.log
 cp profiles/r06_cpu_baseline_cli.json $O/ 2>/dev/null
+fi
 echo "== default bench line (headline + configs)"
-/usr/bin/time -v timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
-grep -E "Elapsed|Maximum resident" $O/bench.err
+T0=$(date +%s.%N); timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$? wall $(echo "$(date +%s.%N) - $T0" | bc) s"
 python - <<PY
 import json
 d=json.loads([l for l in open("$O/bench.json") if l.startswith("{")][-1])

@@ -310,6 +310,11 @@ int vox_hip_fuse_stats(const vox_hip_engine_t *e, int *failures, int *armed, lon
  * maps) does not read as a time-out.  Holes (> 1 ms between two polls) are counted: *count = how many so far, *longest_us = the
  * longest.  Returns 0, -1 on error / no fused kernels. */
 int vox_hip_spin_holes(vox_hip_engine_t *e, unsigned long long *count, double *longest_us);
+/* fp8 mode (VOX_PATH_FP8_MFMA): k_rowsgemm_f8 splits the f32 activations into two e4m3 terms behind a fixed prescale, which covers
+ * |x| <= 112.  Activations beyond that are COUNTED; a prefill that counted any is repeated on the bf16 matrices and the fp8 MFMA prefill
+ * stays off for the engine (the bit disappears from vox_hip_active_paths).  *fallbacks = such repeats so far, *clamped = the device
+ * counter now (read and cleared; vox_hip_linear_bf16 impl 6 counts into it too). */
+int vox_hip_fp8_prefill_stats(vox_hip_engine_t *e, int *fallbacks, unsigned *clamped);
 /* The encoder stack kernel (VOX_PATH_ENC_STACK, k_enc_stack) needs its 256 workgroups co-resident too; a hand-off that times out makes
  * the engine repeat the chunk on the launch-per-GEMM path (VOX_PATH_SKINNY_ENC) and suspend the stack kernel for 64 chunks (doubling).
  * launches / failures so far, armed = 1 if it is live now.  vox_hip_debug_inject_enc_stack_timeout: test hook, the next chunk's check

@@ -1295,6 +1295,27 @@ def test_encoder_stack_timeout_repeats_the_chunk_on_the_launch_path(vox):
         ma.close(); mb.close()
 
 
+def test_fp8_mfma_rowsgemm_counts_activations_beyond_the_e4m3_range(vox, tiny):
+    """Round 6 (advisor): k_rowsgemm_f8's fixed prescale (2.0) covers |x| <= 112; what is beyond used to be clamped silently.  It is
+    counted now (and a prefill that counted anything is repeated on the bf16 matrices): in-range activations count nothing, one
+    outlier of 300 is seen."""
+    import ctypes as C
+    h = vox.hip
+    h.vox_hip_fp8_prefill_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint)]
+    fb, cl = C.c_int(), C.c_uint()
+    rng = np.random.default_rng(3)
+    M, K, N = 38, 512, 256
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = vo.f32_to_bf16((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    assert h.vox_hip_fp8_prefill_stats(tiny.engine, C.byref(fb), C.byref(cl)) == 0          # (clears what earlier tests may have left)
+    tiny.linear_bf16(x * 20.0, w, None, impl=6)                                              # up to ~90: inside
+    assert h.vox_hip_fp8_prefill_stats(tiny.engine, C.byref(fb), C.byref(cl)) == 0 and cl.value == 0, cl.value
+    x[17, 300] = 300.0
+    tiny.linear_bf16(x, w, None, impl=6)
+    assert h.vox_hip_fp8_prefill_stats(tiny.engine, C.byref(fb), C.byref(cl)) == 0 and cl.value >= 1, cl.value
+    assert h.vox_hip_fp8_prefill_stats(tiny.engine, C.byref(fb), C.byref(cl)) == 0 and cl.value == 0
+
+
 def test_few_rows_paths_agree_with_the_large_m_paths(vox):
     """The same encoder chunks (1 .. 128 rows, after a big first chunk and on a cold window) and the same decoder prefills
     (1 .. 128 rows, then three greedy steps) on two engines of one process: one with the k_rowsgemm path switched off

@@ -236,6 +236,8 @@ struct vox_hip_engine {
     uint16_t *tok_emb_s = nullptr;      // simulated-quantisation copy of the LM head (see DecLayer::wqkv_s)
     bool sim_on = false, sim_lm = false;
     bool fp8_prefill_bf16 = false;       // VOX_HIP_DISABLE=fp8_prefill: fp8 mode with the prefill on the bf16 matrices (rounds 2 - 4)
+    unsigned *d_f8_clamped = nullptr, *h_f8_clamped = nullptr;     // k_rowsgemm_f8: activations beyond the e4m3 range after the fixed prescale (device counter, pinned mirror)
+    int fp8_prefill_fallbacks = 0;
     bool fp8_attn_bf16 = false, fp8_lmhead_bf16 = false;     // A/B and agreement-study switches of the fp8 mode, read at creation
     // fused attention half of the decode step (vox_decfuse.h)
     bool use_fused = false;
@@ -309,8 +311,8 @@ struct vox_hip_engine {
     // debug taps of the decoder's residual stream (vox_hip_debug_tap_config): at the decode steps whose KV position is listed,
     // x at the start of every layer, x after every attention block and x after the last layer are copied to d_taps in stream order
     std::vector<int> tap_pos; float *d_taps = nullptr;
-    // Round 4: L2 prefetch of the next launch's first weight bytes (vox_decfuse.h, DfPrefetch).  VOX_HIP_PF="units,member_units,when"
-    // overrides the default (A/B).
+    // Round 4: L2 prefetch of the next launch's first weight bytes (vox_decfuse.h, DfPrefetch).  (the VOX_HIP_PF override of round 4 is gone: the
+    // measured default is a constant)
     // Default (measured): 24 KiB per target block (6.3 MB per launch) issued by the non-members in front of their Wo rows.
     static constexpr int pf_units = 24, pf_member_units = 0, pf_when = 3;      // DfPrefetch (vox_decfuse.h): 24 KiB per target block, by the non-members, in front of their Wo rows
 };
@@ -721,6 +723,16 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
     e->adapter_cap = 4096;
     if (dalloc(e, &e->adapter, (size_t)e->adapter_cap * DD)) return fail();
 
+    // switches that do not depend on the fused decode kernels being available (round 6: they used to be latched inside the block below,
+    // i.e. silently ignored on small presets, under VOX_HIP_CUMASK or with the fused kernels off - where a fallback is most likely needed)
+    e->fp8_attn_bf16 = vox_disabled("fp8_attn");
+    e->fp8_lmhead_bf16 = vox_disabled("fp8_lmhead");
+    e->fp8_prefill_bf16 = vox_disabled("fp8_prefill");
+    e->enc_tl_on = getenv("VOX_HIP_ENC_TL") != nullptr;
+    if (dalloc(e, &e->d_f8_clamped, 4) || hipMemset(e->d_f8_clamped, 0, 16) != hipSuccess ||
+        hipHostMalloc((void **)&e->h_f8_clamped, 16, hipHostMallocDefault) != hipSuccess) return fail();
+    e->h_f8_clamped[0] = 0;
+
     // fused attention half of the decode step: exact 4B decoder shapes on a 256-CU part (one workgroup per CU)
     {
         hipDeviceProp_t prop;
@@ -763,10 +775,6 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
             if (vox_disabled("merge12")) e->merge12 = 0;
             if (vox_disabled("merge12_long")) e->merge12_long = 0;
             if (vox_disabled("stack")) e->use_stack = 0;
-            e->fp8_attn_bf16 = vox_disabled("fp8_attn");
-            e->fp8_lmhead_bf16 = vox_disabled("fp8_lmhead");
-            e->fp8_prefill_bf16 = vox_disabled("fp8_prefill");
-            e->enc_tl_on = getenv("VOX_HIP_ENC_TL") != nullptr;
             if (ok && getenv("VOX_HIP_FUSE_TL") && hipMalloc((void **)&e->d_fuse_tl, 3 * 1024 * TL_STRIDE * 8) == hipSuccess)
                 hipMemset(e->d_fuse_tl, 0, 3 * 1024 * TL_STRIDE * 8);
         }
@@ -805,6 +813,8 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     F(e->d_es_tab); F(e->d_es_xa); F(e->d_es_xb); F(e->d_es_ssq); F(e->d_es_q); F(e->d_es_po); F(e->d_es_pml); F(e->d_es_wop); F(e->d_es_w2p);
     F(e->d_es_apl); F(e->d_es_hpl); F(e->d_es_flags); F(e->d_es_err); F(e->d_es_tl); F(e->es_carry.p);
     if (e->h_es_err) hipHostFree(e->h_es_err);
+    if (e->h_f8_clamped) hipHostFree(e->h_f8_clamped);
+    F(e->d_f8_clamped);
     Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
                    &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml, &e->ssplitk};
     for (Buf *b : bufs) F(b->p);
@@ -1293,7 +1303,7 @@ static int launch_rowsgemm_f8(vox_hip_engine *e, const float *X, int ldx, int n,
     cw = ((cw + RGF8_CPW - 1) / RGF8_CPW) * RGF8_CPW;
     const int S = (nchunks + cw - 1) / cw;
     RowsGemmF8Args a{};
-    a.X = X; a.ldx = ldx; a.n = n; a.W = W8; a.wscale = wscale; a.N = N; a.K = K; a.cw = cw; a.prescale = 2.0f; a.partial = partial;
+    a.X = X; a.ldx = ldx; a.n = n; a.W = W8; a.wscale = wscale; a.N = N; a.K = K; a.cw = cw; a.prescale = 2.0f; a.partial = partial; a.clamped = e->d_f8_clamped;
     const dim3 grid(nb, S), block(64 * RGF8_WPB);
     switch ((n + 15) / 16) {
         case 1: hipLaunchKernelGGL((k_rowsgemm_f8<RGF8_WPB, RGF8_CPW, 1>), grid, block, 0, e->stream, a); break;
@@ -2013,14 +2023,20 @@ static int decoder_prefill_dev(vox_hip_engine *e, float *x, int n) {
     return 0;
 }
 
+static int f8_prefill_clamped(vox_hip_engine *e);
 extern "C" int vox_hip_decoder_prefill(vox_hip_engine_t *e, const float *embeds, int seq_len) {
     if (!e || seq_len <= 0) return -1;
     HC(hipSetDevice(e->device));
     const int DD = e->d.dec_dim;
     if (ensure(e, e->sx, (size_t)seq_len * DD * 4)) return -1;
-    HC(hipMemcpyAsync(e->sx.p, embeds, (size_t)seq_len * DD * 4, hipMemcpyHostToDevice, e->stream));
-    if (decoder_prefill_dev(e, (float *)e->sx.p, seq_len)) return -1;
-    HC(esync(e));
+    const int pos0 = e->dec_pos;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HC(hipMemcpyAsync(e->sx.p, embeds, (size_t)seq_len * DD * 4, hipMemcpyHostToDevice, e->stream));      // (the rows pass works in place)
+        if (decoder_prefill_dev(e, (float *)e->sx.p, seq_len)) return -1;
+        HC(esync(e));
+        if (!f8_prefill_clamped(e)) break;
+        e->dec_pos = pos0;
+    }
     return 0;
 }
 
@@ -2136,7 +2152,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
         }
         if (e->h_stack_tab.size() != tab.size() || memcmp(e->h_stack_tab.data(), tab.data(), tab.size() * sizeof(DecStackLayer)) != 0) {
             HC(hipMemcpyAsync(e->d_stack_tab, tab.data(), tab.size() * sizeof(DecStackLayer), hipMemcpyHostToDevice, s));
-            HC(hipStreamSynchronize(s));          // (rare: the first step, or after the rings / ada vectors moved) the source is a local
+            HC(esync(e));                         // (rare: the first step, or after the rings / ada vectors moved) the source is a local; counted like every host wait
             e->h_stack_tab = tab;
         }
         DecStackArgs sa{};
@@ -2181,7 +2197,7 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
                     a.pf.units = std::min(e->pf_units, 72 * (e->use_fp8 ? 3 : 6)); a.pf.member_units = e->pf_member_units; a.pf.when = e->pf_when;
                 }
                 const bool emb = (l == 0 && build_embed);
-                // VOX_HIP_FP8_ATTN_BF16 (A/B): the round-3 state, qkv / wo on the bf16 matrices
+                // VOX_HIP_DISABLE=fp8_attn (A/B): the round-3 state, qkv / wo on the bf16 matrices
                 if (e->use_fp8 && e->use_dpp && !e->fp8_attn_bf16) {
                     // fp8 mode (BASELINE config 5): the projection and Wo matrices stream their row-scaled e4m3 copies too
                     a.wqkv = reinterpret_cast<const uint16_t *>(L.wqkv8); a.wo = reinterpret_cast<const uint16_t *>(L.wo8);
@@ -2402,7 +2418,7 @@ static int set_state(vox_hip_engine *e, int pos, int token, int64_t adapter_phys
 // is a suspension, not a verdict: a time-out means the 256 workgroups were not co-resident for a moment (another process or
 // stream held CUs), so after FUSE_REARM_STEPS clean steps on the chain (doubling with every further failure, capped) the
 // fused kernel is tried again - one transient contention event used to cost 0.2 ms per token for the engine's lifetime.
-// VOX_HIP_FUSE_NO_REARM=1 keeps the old sticky behaviour (A/B).
+// VOX_HIP_DISABLE=rearm keeps the old sticky behaviour (A/B).
 constexpr long FUSE_REARM_STEPS = 256;
 static int fused_failed(vox_hip_engine *e) {
     if (!e->use_fused) return 0;
@@ -2481,6 +2497,20 @@ extern "C" int vox_hip_spin_holes(vox_hip_engine_t *e, unsigned long long *count
     if (longest_us) *longest_us = std::max(e->spin_hole_max, w[0]) / 100.0;
     return 0;
 }
+// fp8 mode's prefill on the fp8 MFMA (k_rowsgemm_f8): *fallbacks = how often a prefill had to be repeated on the bf16 matrices because an
+// activation exceeded the e4m3 range after the prescale (the first time switches the fp8 MFMA prefill off for the engine); *clamped = the
+// device counter right now (read and cleared: the kernel-level entry vox_hip_linear_bf16(impl 6) counts into it too).
+extern "C" int vox_hip_fp8_prefill_stats(vox_hip_engine_t *e, int *fallbacks, unsigned *clamped) {
+    if (!e || !e->d_f8_clamped) return -1;
+    HC(hipSetDevice(e->device));
+    HC(esync(e));
+    unsigned c = 0;
+    HC(hipMemcpy(&c, e->d_f8_clamped, sizeof c, hipMemcpyDeviceToHost));
+    if (c) HC(hipMemset(e->d_f8_clamped, 0, sizeof c));
+    if (fallbacks) *fallbacks = e->fp8_prefill_fallbacks;
+    if (clamped) *clamped = c;
+    return 0;
+}
 // The encoder stack kernel (VOX_PATH_ENC_STACK): launches so far, hand-off time-outs so far, 1 if it is live now (0: suspended after a
 // time-out, or not available on this engine).  Returns 0, -1 on error.
 extern "C" int vox_hip_enc_stack_stats(const vox_hip_engine_t *e, long *launches, int *failures, int *armed) {
@@ -2534,8 +2564,32 @@ extern "C" int vox_hip_decoder_step(vox_hip_engine_t *e, const float *embed, flo
     return tok;
 }
 
+// fp8 mode: did the prefill that has just been waited for clamp an activation (k_rowsgemm_f8's fixed prescale covers |x| <= 112)?  Then its
+// K/V and logits are not to be trusted: the fp8 MFMA prefill is switched off for this engine (VOX_PATH_FP8_MFMA disappears from
+// vox_hip_active_paths) and the caller repeats the pass on the bf16 matrices.
+static int f8_prefill_clamped(vox_hip_engine *e) {
+    if (!e->use_fp8 || e->fp8_prefill_bf16 || !e->d_f8_clamped) return 0;
+    unsigned c = 0;
+    if (hipMemcpy(&c, e->d_f8_clamped, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (!c) return 0;
+    (void)hipMemset(e->d_f8_clamped, 0, sizeof c);
+    e->fp8_prefill_bf16 = true; e->fp8_prefill_fallbacks++;
+    fprintf(stderr, "vox_hip: WARNING fp8 prefill: %u activation group(s) beyond the e4m3 range after the prescale (|x| > 112); repeating the prefill on the "
+                    "bf16 matrices and keeping it there for this engine\n", c);
+    return 1;
+}
+static int prefill_stream_once(vox_hip_engine_t *e, int64_t first_row, int n_prompt, int bos, int pad, float *logits);
 extern "C" int vox_hip_decoder_prefill_stream(vox_hip_engine_t *e, int64_t first_row, int n_prompt, int bos, int pad, float *logits) {
     if (!e || n_prompt < 1) return -1;
+    const int pos0 = e->dec_pos; const int64_t cons0 = e->adapter_consumed;
+    int tok = prefill_stream_once(e, first_row, n_prompt, bos, pad, logits);
+    if (tok >= 0 && f8_prefill_clamped(e)) {
+        e->dec_pos = pos0; e->adapter_consumed = cons0;
+        tok = prefill_stream_once(e, first_row, n_prompt, bos, pad, logits);
+    }
+    return tok;
+}
+static int prefill_stream_once(vox_hip_engine_t *e, int64_t first_row, int n_prompt, int bos, int pad, float *logits) {
     HC(hipSetDevice(e->device));
     if (first_row < e->adapter_row0 || first_row + n_prompt > e->adapter_total) { g_err = "prefill_stream: adapter rows not resident"; return -1; }
     const int DD = e->d.dec_dim;
@@ -2650,6 +2704,8 @@ extern "C" void vox_hip_reset_encoder(vox_hip_engine_t *e) {
     // zero the causal-history rows (start-of-sequence padding)
     if (e->conv_in0.p) hipMemsetAsync(e->conv_in0.p, 0, (size_t)2 * e->d.mel_bins * 4, e->stream);
     if (e->conv_in1.p) hipMemsetAsync(e->conv_in1.p, 0, (size_t)2 * e->d.enc_dim * 4, e->stream);
+    // k_attn_small's per-head arrival counters are reset by the last arriver only: after an aborted or faulted launch they would stay non-zero
+    if (e->d_attn_arrive) hipMemsetAsync(e->d_attn_arrive, 0, (size_t)std::max(1, e->d.enc_heads) * 4, e->stream);
     esync(e);
 }
 // The same without waiting: the host-side counters are reset at once, the history rows are zeroed in stream order
@@ -2661,6 +2717,7 @@ extern "C" void vox_hip_reset_encoder_async(vox_hip_engine_t *e) {
     e->enc_pos = 0; e->mel_q = 0; e->c0_carry = 0; e->enc_res = 0;
     if (e->conv_in0.p) hipMemsetAsync(e->conv_in0.p, 0, (size_t)2 * e->d.mel_bins * 4, e->stream);
     if (e->conv_in1.p) hipMemsetAsync(e->conv_in1.p, 0, (size_t)2 * e->d.enc_dim * 4, e->stream);
+    if (e->d_attn_arrive) hipMemsetAsync(e->d_attn_arrive, 0, (size_t)std::max(1, e->d.enc_heads) * 4, e->stream);
 }
 // The engine's HIP stream (a hipStream_t) for callers that order their own work against it without a host wait
 // (multi_gpu.py wraps it in torch.cuda.ExternalStream so that RCCL send / recv are stream-ordered with the shard kernels),
@@ -3594,6 +3651,7 @@ extern "C" int vox_hip_enable_peer(vox_hip_engine_t *a, vox_hip_engine_t *b) {
     if (a->device == b->device) return 0;
     int can = 0;
     HC(hipDeviceCanAccessPeer(&can, a->device, b->device));
+    if (vox_disabled("peer")) can = 0;       // (tests: a node whose GPUs cannot map each other - the runtime then stages hipMemcpyPeerAsync through the host)
     if (can) {
         HC(hipSetDevice(a->device));
         hipError_t r = hipDeviceEnablePeerAccess(b->device, 0);

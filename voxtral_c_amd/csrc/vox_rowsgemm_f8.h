@@ -30,6 +30,7 @@ struct RowsGemmF8Args {
     int N, K;
     int cw;                                  // 64-wide K chunks per workgroup (blockIdx.y owns chunks [y cw, (y + 1) cw)), walked CPW at a time
     float prescale;                          // power of two applied to x before the split
+    unsigned *clamped;                       // counts activations beyond the e4m3 range after the prescale (|x ps| > 224): the host then repeats the pass in bf16
     float *partial;                          // [gridDim.y][n][N]
 };
 
@@ -83,6 +84,15 @@ __global__ __launch_bounds__(64 * WPB) void k_rowsgemm_f8(const RowsGemmF8Args a
                 // (clamped to the range both e4m3 flavours represent: a value beyond 224 / ps loses its excess over hi + lo / 16 = 238 / ps)
                 auto cl = [](float v) { return fminf(fmaxf(v, -224.0f), 224.0f); };
                 const float xv[8] = {cl(xa[it].x * ps), cl(xa[it].y * ps), cl(xa[it].z * ps), cl(xa[it].w * ps), cl(xb[it].x * ps), cl(xb[it].y * ps), cl(xb[it].z * ps), cl(xb[it].w * ps)};
+                // Round 6: a clamped activation is not silent any more.  The fixed prescale holds for activations up to 112 in magnitude;
+                // an outlier beyond that (gated hidden rows, Wo inputs of a real checkpoint) would corrupt the prefill's K/V without a trace:
+                // it is counted (workgroups of the first weight-row block only: every block sees the same rows) and the host falls back.
+                if (a.clamped && blockIdx.x == 0 && r < a.n) {
+                    const float lim = 224.0f / ps;
+                    const bool over = fabsf(xa[it].x) > lim || fabsf(xa[it].y) > lim || fabsf(xa[it].z) > lim || fabsf(xa[it].w) > lim ||
+                                      fabsf(xb[it].x) > lim || fabsf(xb[it].y) > lim || fabsf(xb[it].z) > lim || fabsf(xb[it].w) > lim;
+                    if (over) atomicAdd(a.clamped, 1u);
+                }
                 // (the builtins want literal word selectors: written out pair by pair)
                 int hw0 = 0, hw1 = 0, lw0 = 0, lw1 = 0;
                 hw0 = __builtin_amdgcn_cvt_pk_fp8_f32(xv[0], xv[1], hw0, false); hw0 = __builtin_amdgcn_cvt_pk_fp8_f32(xv[2], xv[3], hw0, true);

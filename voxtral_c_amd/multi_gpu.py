@@ -712,11 +712,18 @@ def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
     if not single and world > 1 and args.preset == "full" and os.environ.get("VOX_BENCH_CONFIG4", "1") != "0":
         c4_seconds = float(os.environ.get("VOX_BENCH_CONFIG4_SECONDS", 75.0 * world))
         c4_state = {"done": False}
+        c4_lock = threading.Lock()           # the watchdog thread and the main thread both "claim" the line: exactly one of them prints it
+
+        def c4_claim():
+            with c4_lock:
+                if c4_state["done"]:
+                    return False
+                c4_state["done"] = True
+                return True
 
         def c4_fallback(reason):
-            if c4_state["done"]:
+            if not c4_claim():
                 return
-            c4_state["done"] = True
             if rank == 0:
                 out["config4"] = {"completed": False, "reason": reason, "audio_seconds": c4_seconds}
                 print(json.dumps(out), flush=True)
@@ -759,9 +766,8 @@ def run_distributed_bench(args, rank, world, local_rank, mdir, dims):
             c4_timer.cancel()
             c4_fallback(f"{type(ex).__name__}: {ex}")
         c4_timer.cancel()
-        if c4_state["done"]:
+        if not c4_claim():
             return
-        c4_state["done"] = True
     if rank == 0:
         if c4 is not None:
             out["config4"] = c4

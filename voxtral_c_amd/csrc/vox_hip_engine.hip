@@ -627,6 +627,15 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
         return nullptr;
     }
     if (hipSetDevice(device) != hipSuccess) { g_err = "vox_hip: hipSetDevice failed"; return nullptr; }
+    {   // gfx950 only: the code object holds nothing else, and the hand-off protocols of the fused kernels (write-through sc1 stores acknowledged by
+        // memory, L1-bypassing sc1 loads, no fences: vox_decfuse.h, vox_encstack.h, vox_attn.h) are statements about this part's memory system
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            g_err = std::string("vox_hip: device is not gfx950 (") + prop.gcnArchName + "): this engine is written for MI355X only";
+            fprintf(stderr, "%s\n", g_err.c_str());
+            return nullptr;
+        }
+    }
     vox_hip_engine *e = new vox_hip_engine();
     e->device = device;
     e->d = d;

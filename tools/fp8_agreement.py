@@ -52,7 +52,8 @@ with v.Model(d) as m:
 
 for name, env in (("fp8 mode as shipped: e4m3 + f32 scale per row, all decode GEMVs + LM head", {}),
                   ("fp8 mode, LM head on the bf16 embedding", {"VOX_HIP_DISABLE": "fp8_lmhead"}),
-                  ("fp8 mode, qkv / wo on the bf16 matrices (round 3)", {"VOX_HIP_DISABLE": "fp8_attn"})):
+                  ("fp8 mode, qkv / wo on the bf16 matrices (round 3)", {"VOX_HIP_DISABLE": "fp8_attn"}),
+                  ("fp8 mode, mixed: LM head AND qkv / wo in bf16, only the FFN matrices in e4m3 (round 6)", {"VOX_HIP_DISABLE": "fp8_lmhead,fp8_attn"})):
     os.environ.update(env)
     with v.Model(d, weights="fp8") as m8:
         rows[name] = score(m8.transcribe(audio), m8.transcribe(audio, record_logits=512, force_tokens=ta), m8.time_decoder_step(50, 232))

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Round 6: k_enc_stack A/B (tree build against ab_base via VOX_LIB_DIR): us per layer by rows, + the stack kernel's parity tests
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r6i; rm -rf $O; mkdir -p $O
+export TMPDIR=/tmp
+python -c "import sys; sys.path.insert(0,'tests'); from conftest import model_dir; print(model_dir('full'))" > /dev/null 2>&1
+for r in 1 2 3; do
+  TAG="base" VOX_LIB_DIR=$(realpath ab_base) python tools/enc_rows_probe.py 25,1,8,16,32 750 30 2>&1 | tail -n 1 | tee -a $O/enc_rows_ab.txt
+  TAG="tree" python tools/enc_rows_probe.py 25,1,8,16,32 750 30 2>&1 | tail -n 1 | tee -a $O/enc_rows_ab.txt
+done
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -k "enc_stack or stream_small or smallrs or persistent" 2>&1 | tail -n 4 | tee -a $O/pytest.txt

@@ -53,7 +53,8 @@ constexpr int ES_KG5 = 16, ES_NG5 = 16;   // P5: K groups (320 wide) x row group
 constexpr int ES_NG3 = 8;                 // P3: column groups (160 rows of Wo) per head
 constexpr int ES_PHASES = 7;
 constexpr int ES_TL_STRIDE = 32;          // timeline words per workgroup (VOX_HIP_ENC_TL)
-constexpr int ES_LDS_BYTES = 90 * 1024;
+constexpr int ES_LDS_BYTES = 96 * 1024;
+constexpr int ES_P2_LD = 68, ES_P2_LDS = 132;     // attention phase: LDS row strides (floats) of the q / K / V tiles and of the score tile
 
 struct EncStackLayer {
     const uint16_t *wqkv;                 // [6144][1280] q rows, k rows, v rows
@@ -395,8 +396,9 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
         }
 
         // =========================== P2: attention partials of (head, key slice) ============================================
-        // k_attn_small's arithmetic (plain f32 FMAs: lane = key for the scores, lane = dim for P.V; vox_causal_attention,
-        // voxtral_kernels.c:412-482 up to summation order) on a slice of up to 128 keys = two 64-key tiles, both resident in LDS.  The
+        // vox_causal_attention's arithmetic (voxtral_kernels.c:412-482, up to summation order) on a slice of up to 128 keys, resident in LDS
+        // as f32; both products on the f32 matrix pipe (round 6: the FMA form - lane = key for the scores, lane = dim for P.V - was 9.6 us of
+        // VALU issue at two waves per SIMD), the softmax over the whole slice in between (k_attn_small merges 64-key tiles instead).  The
         // K / V rows of OLD positions do not depend on this layer's P1: they are requested before the wait; rows of this chunk's own
         // positions (the last slice or two) are fetched behind it.
         {
@@ -406,13 +408,15 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
             const int lo = max(0, a.pos0 - a.window + 1), hi = a.pos0 + n - 1;
             const int nkeys = hi - lo + 1, KS = (nkeys + ES_NSL - 1) / ES_NSL;
             const int t0 = lo + slice * KS, t1 = min(t0 + KS - 1, hi);        // this slice's keys [t0, t1] (empty if t0 > t1)
-            const int ntile = t0 > t1 ? 0 : (t1 - t0) / 64 + 1;               // 0, 1 or 2
-            float *qs = reinterpret_cast<float *>(es_lds);                    // [32][64]
-            float *ks = qs + 32 * 64;                                         // [2][64][65]
-            float *vs = ks + 2 * 64 * 65;                                     // [2][64][64]
-            float *ps = vs + 2 * 64 * 64;                                     // [2][32][64]
-            float *sm = ps + 2 * 32 * 64;                                     // [2][32] tile max
-            float *sl = sm + 64;                                              // [2][32] tile sum
+            // LDS (floats): q [32][68] | K [128][68] (later: the four key quarters' partial outputs) | V [128][68] | scores / probabilities [32][132] |
+            // slice max [32] | slice sum [32].  Row strides of 68 / 132 floats: the 16 lanes of a ds_read_b128 service group (16 rows, same
+            // column) hit 16 distinct 16-byte slots.
+            float *qs = reinterpret_cast<float *>(es_lds);                    // [32][68]
+            float *ks = qs + 32 * ES_P2_LD;                                   // [128][68]
+            float *vs = ks + 128 * ES_P2_LD;                                  // [128][68]
+            float *ss = vs + 128 * ES_P2_LD;                                  // [32][132]
+            float *sm = ss + 32 * ES_P2_LDS;                                  // [32] slice max
+            float *sl = sm + 32;                                              // [32] slice sum
             const __amdgpu_buffer_rsrc_t qr = es_rsrc(a.qbuf), kr_ = es_rsrc(L.kring), vr_ = es_rsrc(L.vring);
             // thread -> (key, 4 dims) x 2 per tile
             es_u32x4 kk[2][2], vv[2][2];
@@ -442,87 +446,104 @@ __global__ __launch_bounds__(ES_THREADS) void k_enc_stack(const EncStackArgs a) 
                         int pos; const unsigned off = kv_off(tile, it, pos);
                         if (pos <= t1 && pos >= a.pos0) { kk[tile][it] = es_ld16(kr_, off); vv[tile][it] = es_ld16(vr_, off); }      // this chunk's own rows
                     }
-                *reinterpret_cast<es_u32x4 *>(&qs[r * 64 + c]) = v;
+                *reinterpret_cast<es_u32x4 *>(&qs[r * ES_P2_LD + c]) = v;
 #pragma unroll
                 for (int tile = 0; tile < 2; tile++)
 #pragma unroll
                     for (int it = 0; it < 2; it++) {
-                        const int i = tid + it * ES_THREADS, key = i >> 4, cc = (i & 15) * 4;
-                        float *kd = ks + (tile * 64 + key) * 65 + cc;
-                        kd[0] = __uint_as_float(kk[tile][it].x); kd[1] = __uint_as_float(kk[tile][it].y);
-                        kd[2] = __uint_as_float(kk[tile][it].z); kd[3] = __uint_as_float(kk[tile][it].w);
-                        *reinterpret_cast<es_u32x4 *>(&vs[(tile * 64 + key) * 64 + cc]) = vv[tile][it];
+                        const int i = tid + it * ES_THREADS, key = tile * 64 + (i >> 4), cc = (i & 15) * 4;
+                        *reinterpret_cast<es_u32x4 *>(&ks[key * ES_P2_LD + cc]) = kk[tile][it];
+                        *reinterpret_cast<es_u32x4 *>(&vs[key * ES_P2_LD + cc]) = vv[tile][it];
                     }
             }
             __syncthreads();
-            // scores: wave = 4 query rows (all four in flight), lane = key
-            for (int tile = 0; tile < ntile; tile++) {
-                float kreg[64];
+            // Both products on the f32 matrix pipe (v_mfma_f32_32x32x2_f32: f32 products, f32 accumulation = the FMA chains of k_attn_small /
+            // vox_causal_attention, voxtral_kernels.c:412-482, up to summation order).  The 32x32x2 operand map: lane (i = lane & 31, g = lane >> 5)
+            // supplies A[i][k] and B[i][k] of the step's two k values; which k a (step, g) pair stands for is free as long as A and B agree:
+            // g = the half of the reduction range, so a lane reads CONSECUTIVE floats.  C: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 g.
+            const int i32 = lane & 31, g2 = lane >> 5;
+            const int nk = t1 - t0 + 1;                                       // keys of this slice (<= 0: empty)
+            // scores S[32 rows][key]: waves 0 .. 3 take 32 keys each (reduction over the 64 dims: 32 steps)
+            if (wv < 4 && 32 * wv < nk) {                                     // (wave-uniform)
+                float4 qa[8], kb[8];
 #pragma unroll
-                for (int d = 0; d < 64; d++) kreg[d] = ks[(tile * 64 + lane) * 65 + d];
-                const int t = t0 + 64 * tile + lane;
-                // two rows at a time (two independent FMA chains; all four in flight make the scheduler hoist the q reads of the unrolled loop:
-                // 250 registers and spills all over the kernel)
-#pragma unroll 1
-                for (int rp = 0; rp < 4; rp += 2) {
-                    float sc[2] = {0.f, 0.f};
-#pragma unroll
-                    for (int d = 0; d < 64; d += 4) {
-#pragma unroll
-                        for (int r = 0; r < 2; r++) {
-                            const float4 q4 = *reinterpret_cast<const float4 *>(&qs[(wv * 4 + rp + r) * 64 + d]);
-                            sc[r] = fmaf(q4.x, kreg[d], sc[r]); sc[r] = fmaf(q4.y, kreg[d + 1], sc[r]); sc[r] = fmaf(q4.z, kreg[d + 2], sc[r]); sc[r] = fmaf(q4.w, kreg[d + 3], sc[r]);
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 2; r++) {
-                        const int row = wv * 4 + rp + r, P = a.pos0 + row;
-                        const bool ok = row < n && t <= t1 && t <= P && t >= P - a.window + 1;
-                        const float sv = ok ? sc[r] * a.scale : -1e30f;
-                        const float mx = as_dpp_max(sv);
-                        const float pe = (ok && mx > -1e29f) ? expf(sv - mx) : 0.f;
-                        const float lsum = as_dpp_sum(pe);
-                        ps[(tile * 32 + row) * 64 + lane] = pe;
-                        if (lane == 0) { sm[tile * 32 + row] = mx > -1e29f ? mx : -1e30f; sl[tile * 32 + row] = lsum; }
-                    }
+                for (int j = 0; j < 8; j++) {
+                    qa[j] = *reinterpret_cast<const float4 *>(&qs[i32 * ES_P2_LD + 32 * g2 + 4 * j]);
+                    kb[j] = *reinterpret_cast<const float4 *>(&ks[(32 * wv + i32) * ES_P2_LD + 32 * g2 + 4 * j]);
                 }
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j].x, kb[j].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j].y, kb[j].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j].z, kb[j].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j].w, kb[j].w, acc, 0, 0, 0);
+                }
+                ES_MFMA_SETTLE();
+#pragma unroll
+                for (int r = 0; r < 16; r++) ss[((r & 3) + 8 * (r >> 2) + 4 * g2) * ES_P2_LDS + 32 * wv + i32] = acc[r];
             }
             __syncthreads();
-            // P.V: wave = 4 query rows, lane = dim; the two tiles are merged on their common max
-            float oacc[4] = {0.f, 0.f, 0.f, 0.f}, om[4] = {-1e30f, -1e30f, -1e30f, -1e30f}, ol[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int tile = 0; tile < ntile; tile++) {
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-                for (int k4 = 0; k4 < 64; k4 += 4) {
-                    const float *vb = vs + (tile * 64 + k4) * 64 + lane;
-                    const float v0 = vb[0], v1 = vb[64], v2 = vb[128], v3 = vb[192];
+            // softmax numerators over the slice's keys: wave = 4 query rows, lane = keys lane and lane + 64 (columns no wave computed are masked:
+            // they are read through a select, never through arithmetic)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float4 p4 = *reinterpret_cast<const float4 *>(&ps[(tile * 32 + wv * 4 + r) * 64 + k4]);
-                        acc[r] = fmaf(p4.x, v0, acc[r]); acc[r] = fmaf(p4.y, v1, acc[r]); acc[r] = fmaf(p4.z, v2, acc[r]); acc[r] = fmaf(p4.w, v3, acc[r]);
-                    }
-                }
+            for (int r = 0; r < 4; r++) {
+                const int row = wv * 4 + r, P = a.pos0 + row;
+                float sv[2]; bool ok[2];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = wv * 4 + r;
-                    const float mt = sm[tile * 32 + row], lt = sl[tile * 32 + row];
-                    if (tile == 0) { oacc[r] = acc[r]; om[r] = mt; ol[r] = lt; }
-                    else {
-                        const float mm = fmaxf(om[r], mt), f0 = expf(om[r] - mm), f1 = expf(mt - mm);
-                        oacc[r] = oacc[r] * f0 + acc[r] * f1; ol[r] = ol[r] * f0 + lt * f1; om[r] = mm;
-                    }
+                for (int h = 0; h < 2; h++) {
+                    const int key = lane + 64 * h, t = t0 + key;
+                    ok[h] = row < n && t <= t1 && t <= P && t >= P - a.window + 1;
+                    sv[h] = ok[h] ? ss[row * ES_P2_LDS + key] * a.scale : -1e30f;
                 }
+                const float mx = as_dpp_max(fmaxf(sv[0], sv[1]));
+                const float p0 = (ok[0] && mx > -1e29f) ? expf(sv[0] - mx) : 0.f, p1 = (ok[1] && mx > -1e29f) ? expf(sv[1] - mx) : 0.f;
+                const float lsum = as_dpp_sum(p0 + p1);
+                ss[row * ES_P2_LDS + lane] = p0; ss[row * ES_P2_LDS + lane + 64] = p1;
+                if (lane == 0) { sm[row] = mx > -1e29f ? mx : -1e30f; sl[row] = lsum; }
             }
+            __syncthreads();
+            // P.V: wave -> (32-dim half dt, 32-key quarter q4): O_q4[32 rows][32 dims], reduction over the quarter's keys in 16 steps; the four
+            // quarters meet in LDS (where K was)
+            {
+                const int dt = wv & 1, q4 = wv >> 1;
+                float4 pa[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) pa[j] = *reinterpret_cast<const float4 *>(&ss[i32 * ES_P2_LDS + 32 * q4 + 16 * g2 + 4 * j]);
+                float vb[16];
+#pragma unroll
+                for (int st = 0; st < 16; st++) vb[st] = vs[(32 * q4 + 16 * g2 + st) * ES_P2_LD + 32 * dt + i32];
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j].x, vb[4 * j], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j].y, vb[4 * j + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j].z, vb[4 * j + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j].w, vb[4 * j + 3], acc, 0, 0, 0);
+                }
+                ES_MFMA_SETTLE();
+                float *red = ks;                                              // [4 quarters][32 rows][68]
+#pragma unroll
+                for (int r = 0; r < 16; r++) red[(q4 * 32 + (r & 3) + 8 * (r >> 2) + 4 * g2) * ES_P2_LD + 32 * dt + i32] = acc[r];
+            }
+            __syncthreads();
             {
                 const __amdgpu_buffer_rsrc_t por = es_rsrc(a.part_o), pmr = es_rsrc(a.part_ml);
                 const size_t base = ((size_t)head * ES_NSL + slice) * 32;
+                const int row = tid >> 4, d4 = (tid & 15) * 4;
+                if (row < n) {
+                    float4 o = *reinterpret_cast<const float4 *>(&ks[row * ES_P2_LD + d4]);
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = wv * 4 + r;
-                    if (row < n) {
-                        es_st4(por, (unsigned)(((base + row) * 64 + lane) * 4), oacc[r]);
-                        if (lane == 0) es_st8(pmr, (unsigned)((base + row) * 8), es_u32x2{__float_as_uint(om[r]), __float_as_uint(ol[r])});
+                    for (int q4 = 1; q4 < 4; q4++) {
+                        const float4 t = *reinterpret_cast<const float4 *>(&ks[(q4 * 32 + row) * ES_P2_LD + d4]);
+                        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
                     }
+                    es_st16(por, (unsigned)(((base + row) * 64 + d4) * 4), es_f4(o.x, o.y, o.z, o.w));
+                    if ((tid & 15) == 0) es_st8(pmr, (unsigned)((base + row) * 8), es_u32x2{__float_as_uint(sm[row]), __float_as_uint(sl[row])});
                 }
             }
             ES_MARK(3);

@@ -1607,18 +1607,22 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
             if (ti == 0) DF_MARK(11);
             // scores: wave (0..7) -> 16 of the 128 dims for all 4 heads, lane -> key; the 8 partial sums per (head, key) meet in LDS
             if (wave < 8) {
+                // v_mfma_f32_4x4x1_16B_f32: 16 independent 4 x 4 outer products per instruction, block b = lanes 4b .. 4b + 3: lane l supplies
+                // A[i = l & 3] and B[j = l & 3] of its block and receives D[i = register][j = l & 3].  Block = 4 keys, i = head, j = key:
+                // a = q[head l & 3][d], b = K[key l][d] -> register i of lane l = S[head i][key l], one instruction per dim (f32 products, f32
+                // accumulation: the FMA chain it replaces, 16 matrix instructions instead of 64 FMAs + 12 LDS reads on the members' critical path)
                 const unsigned char *krow = kt + lane * 512;
-                float s4[4] = {0.f, 0.f, 0.f, 0.f};
+                const float *qh = qs + (lane & 3) * DF_HD;
+                f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const int ch = 4 * wave + c;
                     const float4 kv4 = *reinterpret_cast<const float4 *>(krow + ((ch ^ (lane & 31)) << 4));
-#pragma unroll
-                    for (int hh = 0; hh < 4; hh++) {
-                        const float4 q4 = *reinterpret_cast<const float4 *>(qs + hh * DF_HD + ch * 4);
-                        s4[hh] = fmaf(q4.x, kv4.x, s4[hh]); s4[hh] = fmaf(q4.y, kv4.y, s4[hh]);
-                        s4[hh] = fmaf(q4.z, kv4.z, s4[hh]); s4[hh] = fmaf(q4.w, kv4.w, s4[hh]);
-                    }
+                    const float4 q4 = *reinterpret_cast<const float4 *>(qh + ch * 4);
+                    s4 = __builtin_amdgcn_mfma_f32_4x4x1f32(q4.x, kv4.x, s4, 0, 0, 0);
+                    s4 = __builtin_amdgcn_mfma_f32_4x4x1f32(q4.y, kv4.y, s4, 0, 0, 0);
+                    s4 = __builtin_amdgcn_mfma_f32_4x4x1f32(q4.z, kv4.z, s4, 0, 0, 0);
+                    s4 = __builtin_amdgcn_mfma_f32_4x4x1f32(q4.w, kv4.w, s4, 0, 0, 0);
                 }
 #pragma unroll
                 for (int hh = 0; hh < 4; hh++) sc8[(hh * 8 + wave) * 64 + lane] = s4[hh];
@@ -1644,19 +1648,20 @@ __device__ __forceinline__ void df_attn12_body(const DecFuseArgs &a, unsigned ch
                 const int kq = tid >> 7;
                 const float *vcol = reinterpret_cast<const float *>(vt) + dd;
                 const int nv = min(DF_TILE, s_hi - t0 + 1);
-                float a4[4] = {0.f, 0.f, 0.f, 0.f};
+                // the same instruction with block = 4 dims, i = head, j = dim: a = P[head l & 3][key], b = V[key][dim l] -> register i = O[head i][dim]
+                f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+                const float *ph = pt + (tid & 3) * 64;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int k0 = 16 * kq + 4 * i;
                     float v[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) v[u] = k0 + u < nv ? vcol[(k0 + u) * 128] : 0.f;
-#pragma unroll
-                    for (int hh = 0; hh < 4; hh++) {
-                        const float4 p4 = *reinterpret_cast<const float4 *>(pt + hh * 64 + k0);
-                        a4[hh] = fmaf(p4.x, v[0], a4[hh]); a4[hh] = fmaf(p4.y, v[1], a4[hh]);
-                        a4[hh] = fmaf(p4.z, v[2], a4[hh]); a4[hh] = fmaf(p4.w, v[3], a4[hh]);
-                    }
+                    const float4 p4 = *reinterpret_cast<const float4 *>(ph + k0);
+                    a4 = __builtin_amdgcn_mfma_f32_4x4x1f32(p4.x, v[0], a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_4x4x1f32(p4.y, v[1], a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_4x4x1f32(p4.z, v[2], a4, 0, 0, 0);
+                    a4 = __builtin_amdgcn_mfma_f32_4x4x1f32(p4.w, v[3], a4, 0, 0, 0);
                 }
 #pragma unroll
                 for (int hh = 0; hh < 4; hh++) sc8[(kq * 4 + hh) * DF_HD + dd] = a4[hh];

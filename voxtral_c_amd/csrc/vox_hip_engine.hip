@@ -280,6 +280,16 @@ struct vox_hip_engine {
           *d_es_wop = nullptr, *d_es_w2p = nullptr;
     uint16_t *d_es_apl = nullptr, *d_es_hpl = nullptr;
     unsigned *d_es_flags = nullptr, *d_es_err = nullptr, *h_es_err = nullptr;
+    // Pinned host memory of the per-feed hot path (round 6): what a feed hands to the device (the decode state, its samples) and gets back
+    // (state, error words, token ids) goes through here, so that every copy is asynchronous and a decoder run waits ONCE.
+    struct HostPin {
+        DecState st_in[2]; DecState st_out;
+        unsigned fuse_err[16];
+        int tokens[MAX_RUN_STEPS];
+    } *pin = nullptr;
+    int pin_st_next = 0, pin_st_inflight = 0;      // set_state alternates two slots; a third call without a host wait in between waits first
+    static constexpr int SMP_SLOTS = 4; static constexpr size_t SMP_SLOT_BYTES = (size_t)256 << 10;
+    void *smp_pin[SMP_SLOTS] = {}; hipEvent_t smp_ev[SMP_SLOTS] = {}; bool smp_used[SMP_SLOTS] = {}; int smp_next = 0;
     unsigned long long *d_es_tl = nullptr;
     bool enc_tl_on = false;
     unsigned long long *d_enc_tl = nullptr;       // VOX_HIP_ENC_TL: [4 GEMM launches][1024 workgroups][16] timeline of one few-rows encoder layer
@@ -321,6 +331,7 @@ struct vox_hip_engine {
 // wavefront must not synchronise between shard_begin and shard_end, and the tests check that with this counter.
 static hipError_t esync(vox_hip_engine *e) {
     e->n_host_syncs++;
+    e->pin_st_inflight = 0;
     return hipStreamSynchronize(e->stream);
 }
 
@@ -741,6 +752,11 @@ extern "C" vox_hip_engine_t *vox_hip_engine_create(int device, const vox_hip_dim
     if (dalloc(e, &e->d_f8_clamped, 4) || hipMemset(e->d_f8_clamped, 0, 16) != hipSuccess ||
         hipHostMalloc((void **)&e->h_f8_clamped, 16, hipHostMallocDefault) != hipSuccess) return fail();
     e->h_f8_clamped[0] = 0;
+    if (hipHostMalloc((void **)&e->pin, sizeof(vox_hip_engine::HostPin), hipHostMallocDefault) != hipSuccess) return fail();
+    memset(e->pin, 0, sizeof(vox_hip_engine::HostPin));
+    for (int i = 0; i < vox_hip_engine::SMP_SLOTS; i++)
+        if (hipHostMalloc(&e->smp_pin[i], vox_hip_engine::SMP_SLOT_BYTES, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&e->smp_ev[i], hipEventDisableTiming) != hipSuccess) return fail();
 
     // fused attention half of the decode step: exact 4B decoder shapes on a 256-CU part (one workgroup per CU)
     {
@@ -823,6 +839,8 @@ extern "C" void vox_hip_engine_destroy(vox_hip_engine_t *e) {
     F(e->d_es_apl); F(e->d_es_hpl); F(e->d_es_flags); F(e->d_es_err); F(e->d_es_tl); F(e->es_carry.p);
     if (e->h_es_err) hipHostFree(e->h_es_err);
     if (e->h_f8_clamped) hipHostFree(e->h_f8_clamped);
+    if (e->pin) hipHostFree(e->pin);
+    for (int i = 0; i < vox_hip_engine::SMP_SLOTS; i++) { if (e->smp_pin[i]) hipHostFree(e->smp_pin[i]); if (e->smp_ev[i]) hipEventDestroy(e->smp_ev[i]); }
     F(e->d_f8_clamped);
     Buf *bufs[] = {&e->conv_in0, &e->conv_in1, &e->enc_out, &e->sx, &e->sxn, &e->sqkv, &e->sattn, &e->sgu, &e->sh,
                    &e->srope, &e->sim2col, &e->ssamples, &e->smid, &e->stmp_in, &e->stmp_out, &e->spart_o, &e->spart_ml, &e->ssplitk};
@@ -1584,7 +1602,21 @@ extern "C" int vox_hip_mel_frames(vox_hip_engine_t *e, const float *samples, int
     const int MB = e->d.mel_bins;
     const size_t ns = (size_t)(n_frames - 1) * MEL_HOP + MEL_NFFT;
     if (ensure(e, e->ssamples, ns * 4)) return -1;
-    HC(hipMemcpyAsync(e->ssamples.p, samples, ns * 4, hipMemcpyHostToDevice, e->stream));
+    // A streaming feed's samples (33 KB at -I 0.5) go through a pinned staging slot: the copy is asynchronous, the caller's buffer is free when
+    // this returns, and the host goes on to enqueue the conv stem while the mel kernel runs (round 6; before: a host wait per feed).  A slot
+    // is reused four feeds later, behind its own event.  Large transfers (a clip in one feed) keep the blocking form.
+    const bool staged = to_queue && !out_mel && ns * 4 <= vox_hip_engine::SMP_SLOT_BYTES && e->smp_pin[0];
+    int slot = -1;
+    if (staged) {
+        slot = e->smp_next; e->smp_next = (e->smp_next + 1) % vox_hip_engine::SMP_SLOTS;
+        if (e->smp_used[slot]) HC(hipEventSynchronize(e->smp_ev[slot]));
+        memcpy(e->smp_pin[slot], samples, ns * 4);
+        HC(hipMemcpyAsync(e->ssamples.p, e->smp_pin[slot], ns * 4, hipMemcpyHostToDevice, e->stream));
+        HC(hipEventRecord(e->smp_ev[slot], e->stream));
+        e->smp_used[slot] = true;
+    } else {
+        HC(hipMemcpyAsync(e->ssamples.p, samples, ns * 4, hipMemcpyHostToDevice, e->stream));
+    }
     float *dst;
     if (to_queue) {
         if (ensure_keep(e, e->conv_in0, (size_t)(2 + e->mel_q + n_frames) * MB * 4, (size_t)(2 + e->mel_q) * MB * 4)) return -1;
@@ -1596,7 +1628,7 @@ extern "C" int vox_hip_mel_frames(vox_hip_engine_t *e, const float *samples, int
     hipLaunchKernelGGL(k_mel_frames, dim3(n_frames), dim3(256), 0, e->stream, dst, MB, (const float *)e->ssamples.p,
                        e->hann, e->cosT, e->sinT, e->filtT);
     if (out_mel) HC(hipMemcpyAsync(out_mel, dst, (size_t)n_frames * MB * 4, hipMemcpyDeviceToHost, e->stream));
-    HC(esync(e));   // the host sample buffer may be reused by the caller
+    if (!staged) HC(esync(e));   // the host sample buffer may be reused by the caller
     if (to_queue) e->mel_q += n_frames;
     return 0;
 }
@@ -1827,6 +1859,7 @@ extern "C" int vox_hip_stream_encode(vox_hip_engine_t *e, int n_mel, int *conv_r
     // (round 6) the stack kernel may flag a chunk (a hand-off timed out): everything from the encoder stack on is then repeated on the
     // launch-per-GEMM path from the same conv-stem rows, with the stream state rewound to this point
     const int saved_pos = e->enc_pos, saved_res = e->enc_res; const int64_t saved_total = e->adapter_total;
+    bool waited = false;
     for (int attempt = 0; attempt < 2 && nq > 0; attempt++) {
         new_tokens = 0;
         if (ensure_keep(e, e->enc_out, (size_t)(3 + nq) * ED * 4, (size_t)3 * ED * 4)) return -1;
@@ -1861,14 +1894,19 @@ extern "C" int vox_hip_stream_encode(vox_hip_engine_t *e, int n_mel, int *conv_r
         }
         e->enc_res = leftover;
         if (!e->enc_stack_pending) break;
+        HC(hipEventRecord(e->ev1, s));           // (the timing event in front of the ONE host wait of this call)
         enc_stack_fetch(e);
         HC(esync(e));
+        waited = true;
         if (!enc_stack_failed(e)) break;
+        waited = false;
         e->enc_pos = saved_pos; e->enc_res = saved_res; e->adapter_total = saved_total;       // (the carried rows 0 .. 2 of enc_out were only read)
     }
     if (enc_residual) *enc_residual = e->enc_res;
-    HC(hipEventRecord(e->ev1, s));
-    HC(esync(e));
+    if (!waited) {
+        HC(hipEventRecord(e->ev1, s));
+        HC(esync(e));
+    }
     float ms = 0.f;
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
     e->timing.encode_ms += ms;
@@ -2415,10 +2453,13 @@ static int enqueue_step(vox_hip_engine *e, int kv_pos, bool build_embed, float *
 }
 
 static int set_state(vox_hip_engine *e, int pos, int token, int64_t adapter_phys_row) {
-    DecState st{};
+    // the source is a pinned slot (two, alternating), so nothing has to wait here: the copy is in stream order in front of the steps
+    // that read the state, and the host goes on enqueueing them (round 6; before: a stack variable and a host wait per run)
+    if (e->pin_st_inflight >= 2) HC(esync(e));
+    DecState &st = e->pin->st_in[e->pin_st_next];
+    e->pin_st_next ^= 1; e->pin_st_inflight++;
     st.pos = pos; st.token = token; st.n_out = 0; st.stop = 0; st.adapter_row = adapter_phys_row;
     HC(hipMemcpyAsync(e->d_st, &st, sizeof st, hipMemcpyHostToDevice, e->stream));
-    HC(esync(e));   // st lives on the host stack
     return 0;
 }
 
@@ -2429,10 +2470,16 @@ static int set_state(vox_hip_engine *e, int pos, int token, int64_t adapter_phys
 // fused kernel is tried again - one transient contention event used to cost 0.2 ms per token for the engine's lifetime.
 // VOX_HIP_DISABLE=rearm keeps the old sticky behaviour (A/B).
 constexpr long FUSE_REARM_STEPS = 256;
+static int fused_failed_words(vox_hip_engine *e, const unsigned *w);
 static int fused_failed(vox_hip_engine *e) {
     if (!e->use_fused) return 0;
     unsigned w[16] = {0};
     if (hipMemcpy(w, e->d_fuse_err, sizeof w, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return fused_failed_words(e, w);
+}
+// (w = the 16 error words as read back after the host wait - by the caller's own asynchronous copy on the hot path)
+static int fused_failed_words(vox_hip_engine *e, const unsigned *w) {
+    if (!e->use_fused) return 0;
     e->spin_hole_max = std::max(e->spin_hole_max, w[8]); e->spin_holes += w[9];
     if (w[8] | w[9]) (void)hipMemset(e->d_fuse_err + 8, 0, 2 * sizeof(unsigned));
     const unsigned err = w[0];
@@ -2664,9 +2711,10 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
     // the wait for the shard that holds the first row is another GPU's encoder time, not decode time: in front of ev0
     // (as prefill_stream does); waits for later shards inside the run overlap with decoding and stay where they are
     if (!e->row_fences.empty() && apply_row_fences(e, first_row)) return -1;
-    HC(hipEventRecord(e->ev0, s));
+    float ms_total = 0.f;
     while (done < n_steps) {
         const int batch = std::min(n_steps - done, logits_out ? 64 : MAX_RUN_STEPS);
+        HC(hipEventRecord(e->ev0, s));
         if (set_state(e, e->dec_pos, prev_token, first_row + done - e->adapter_row0)) return -1;
         float *lg = e->dlogits;
         if (logits_out) {
@@ -2678,12 +2726,20 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
             if (!e->row_fences.empty() && apply_row_fences(e, first_row + done + i)) return -1;
             if (enqueue_step(e, e->dec_pos + i, true, logits_out ? lg + (size_t)i * V : lg, eos_token, 1)) return -1;
         }
-        DecState st{};
-        HC(hipMemcpyAsync(&st, e->d_st, sizeof st, hipMemcpyDeviceToHost, s));
+        // ONE host wait per batch: the timing event, the state, the fused kernels' error words and the token ids all come back through
+        // pinned memory in stream order behind the steps (round 6; before: a wait + three blocking copies + a second wait per run, ~0.15 ms
+        // of a streaming feed)
+        HC(hipEventRecord(e->ev1, s));
+        HC(hipMemcpyAsync(&e->pin->st_out, e->d_st, sizeof(DecState), hipMemcpyDeviceToHost, s));
+        const bool fused_live = e->use_fused;
+        if (fused_live) HC(hipMemcpyAsync(e->pin->fuse_err, e->d_fuse_err, sizeof e->pin->fuse_err, hipMemcpyDeviceToHost, s));
+        HC(hipMemcpyAsync(e->pin->tokens, e->d_tokens, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, s));
         HC(esync(e));
-        if (fused_failed(e)) continue;          // the batch's results are void: run it again (now on the chain)
+        if (fused_live && fused_failed_words(e, e->pin->fuse_err)) continue;          // the batch's results are void: run it again (now on the chain)
+        { float ms = 0.f; hipEventElapsedTime(&ms, e->ev0, e->ev1); ms_total += ms; }
+        const DecState st = e->pin->st_out;
         const int got = st.n_out;
-        if (got > 0) HC(hipMemcpy(tokens_out + done, e->d_tokens, (size_t)got * sizeof(int), hipMemcpyDeviceToHost));
+        if (got > 0) memcpy(tokens_out + done, e->pin->tokens, (size_t)got * sizeof(int));
         if (logits_out && got > 0)
             HC(hipMemcpy(logits_out + (size_t)done * V, lg, (size_t)got * V * 4, hipMemcpyDeviceToHost));
         e->dec_pos += got;
@@ -2692,10 +2748,7 @@ extern "C" int vox_hip_decoder_run(vox_hip_engine_t *e, int64_t first_row, int n
         if (got > 0) prev_token = tokens_out[done - 1];
         if (st.stop || got < batch) break;
     }
-    HC(hipEventRecord(e->ev1, s));
-    HC(esync(e));
-    float ms = 0.f; hipEventElapsedTime(&ms, e->ev0, e->ev1);
-    e->timing.decode_ms += ms;
+    e->timing.decode_ms += ms_total;
     e->timing.decode_steps += done;
     e->adapter_consumed = std::max(e->adapter_consumed, first_row + done);
     return done;

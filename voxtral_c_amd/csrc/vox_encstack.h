@@ -168,10 +168,12 @@ __device__ __forceinline__ void es_poll(const EncStackArgs &a, unsigned target, 
         const __amdgpu_buffer_rsrc_t fr = es_rsrc(a.flags);
         const int f0 = threadIdx.x * 4;
         const bool n0 = need(f0), n1 = need(f0 + 1), n2 = need(f0 + 2), n3 = need(f0 + 3);
+        const bool any = n0 || n1 || n2 || n3;         // a lane none of whose four flags matters does not load (narrow waits touch 1 - 8 lines, not the whole KB)
         int res = 1;
         DfSpin sp;
         for (unsigned it = 0;; it++) {
-            const es_u32x4 f = es_ld16(fr, threadIdx.x * 16);
+            es_u32x4 f = es_u32x4{target, target, target, target};
+            if (any) f = es_ld16(fr, threadIdx.x * 16);
             const bool ok = (!n0 || (int)(f.x - target) >= 0) && (!n1 || (int)(f.y - target) >= 0) && (!n2 || (int)(f.z - target) >= 0) && (!n3 || (int)(f.w - target) >= 0);
             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
             if (it == 0) df_spin_begin(sp);

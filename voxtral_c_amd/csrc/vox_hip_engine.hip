@@ -3202,6 +3202,41 @@ extern "C" int vox_hip_quantize_decoder_fp8(vox_hip_engine_t *e) {
     HC(esync(e));
     HC(hipGetLastError());
     e->use_fp8 = true;
+    // Start-up cross-check of the fp8 MFMA family (round 6, advisor): k_rowsgemm_f8 on 38 rows x the first 256 quantised rows of layer 0's
+    // wq;wk;wv against the same e4m3 weights dequantised and multiplied in f32 (k_fp8_ref_gemm).  A wrong fragment layout is an O(1)
+    // error, the activation split an O(1e-3) one; on a mismatch the prefill stays on the bf16 matrices (VOX_PATH_FP8_MFMA is not reported).
+    if (e->use_mfma && !e->fp8_prefill_bf16 && d.dec_layers > 0 && e->dec[0].wqkv8) {
+        const int M = 38, N = 256, K = DD;
+        std::vector<float> hx((size_t)M * K);
+        unsigned lcg = 12345u;
+        for (auto &v : hx) { lcg = lcg * 1664525u + 1013904223u; v = ((int)(lcg >> 8) % 20001 - 10000) * 3e-4f; }     // uniform in (-3, 3)
+        float *dx = nullptr, *y0 = nullptr, *y1 = nullptr, *part = nullptr;
+        bool ok = hipMalloc((void **)&dx, hx.size() * 4) == hipSuccess && hipMalloc((void **)&y0, (size_t)M * N * 4) == hipSuccess &&
+                  hipMalloc((void **)&y1, (size_t)M * N * 4) == hipSuccess && hipMalloc((void **)&part, rgf8_partial_bytes(M, N, K)) == hipSuccess &&
+                  hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        double num = 0.0, den = 0.0;
+        if (ok) {
+            const int S = launch_rowsgemm_f8(e, dx, K, M, e->dec[0].wqkv8, e->dec[0].sqkv, N, K, part);
+            GemmArgs ra{nullptr, 0, nullptr, y1, N, M, N, K, nullptr, nullptr, 0, ACT_NONE, S, 0, part};
+            if (S > 0) hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((size_t)M * N)), dim3(256), 0, e->stream, ra);
+            hipLaunchKernelGGL(k_fp8_ref_gemm, dim3(N), dim3(64), 0, e->stream, y0, (const float *)dx, (const uint8_t *)e->dec[0].wqkv8,
+                               (const float *)e->dec[0].sqkv, (const float *)nullptr, M, N, K);
+            std::vector<float> h0((size_t)M * N), h1((size_t)M * N);
+            ok = S > 0 && esync(e) == hipSuccess && hipGetLastError() == hipSuccess &&
+                 hipMemcpy(h0.data(), y0, h0.size() * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                 hipMemcpy(h1.data(), y1, h1.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+            for (size_t i = 0; ok && i < h0.size(); i++) { const double dlt = (double)h1[i] - h0[i]; num += dlt * dlt; den += (double)h0[i] * h0[i]; }
+            ok = ok && den > 0.0 && num <= 4e-4 * den;          // rms error below 2 % of rms(y)
+        }
+        (void)hipMemsetAsync(e->d_f8_clamped, 0, 16, e->stream);   // (the check's own activations are not a prefill)
+        hipFree(dx); hipFree(y0); hipFree(y1); hipFree(part);
+        if (!ok) {
+            (void)hipGetLastError();
+            e->fp8_prefill_bf16 = true;
+            fprintf(stderr, "vox_hip: WARNING k_rowsgemm_f8 failed its start-up cross-check against the dequantised f32 product (relative rms error %.3g): "
+                            "fp8 mode's prefill runs on the bf16 matrices\n", den > 0.0 ? sqrt(num / den) : -1.0);
+        }
+    }
     return 0;
 }
 extern "C" int vox_hip_weight_format(vox_hip_engine_t *e) { return e ? (e->use_fp8 ? 1 : 0) : -1; }

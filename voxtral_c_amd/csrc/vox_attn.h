@@ -43,6 +43,7 @@ struct AttnArgs {
     const DecState *st;             // decoder step: qpos0 = st->pos (when non-null)
     // split-K (decoder)
     unsigned *arrive;               // k_attn_small: [n_heads] arrival counters (zero between launches): the last slice of a head to arrive merges it
+    uint16_t *out_planes; size_t out_plane;   // k_attn_enc_bf16, one key slice: the output ALSO as bf16 planes [3][n_q][ldo] (the Wo launch's operand: no k_split_planes pass)
     int xcd_map;                    // k_attn_enc_bf16: remap (tile, head) so that a head's query tiles share an XCD (see there)
     int split_keys;                 // keys per blockIdx.y
     float *part_o, *part_ml;        // [n_q][n_heads][nsplit][HD], [..][2]
@@ -418,10 +419,16 @@ __global__ __launch_bounds__(256, 3) void k_attn_enc_bf16(const AttnArgs a) {
 #pragma unroll
         for (int q4 = 0; q4 < 4; q4++) {
             const int d = 8 * q4 + 4 * lg;
-            *reinterpret_cast<float4 *>(op + d) =
-                make_float4(o0[4 * q4] * inv, o0[4 * q4 + 1] * inv, o0[4 * q4 + 2] * inv, o0[4 * q4 + 3] * inv);
-            *reinterpret_cast<float4 *>(op + 32 + d) =
-                make_float4(o1[4 * q4] * inv, o1[4 * q4 + 1] * inv, o1[4 * q4 + 2] * inv, o1[4 * q4 + 3] * inv);
+            const float4 v0 = make_float4(o0[4 * q4] * inv, o0[4 * q4 + 1] * inv, o0[4 * q4 + 2] * inv, o0[4 * q4 + 3] * inv);
+            const float4 v1 = make_float4(o1[4 * q4] * inv, o1[4 * q4 + 1] * inv, o1[4 * q4 + 2] * inv, o1[4 * q4 + 3] * inv);
+            if (a.out_planes) {          // (round 6) straight into the Wo launch's operand layout
+                uint16_t *pp = a.out_planes + (size_t)qi * a.ldo + h * HD;
+                planes_store4(pp + d, a.out_plane, v0);
+                planes_store4(pp + 32 + d, a.out_plane, v1);
+            } else {
+                *reinterpret_cast<float4 *>(op + d) = v0;
+                *reinterpret_cast<float4 *>(op + 32 + d) = v1;
+            }
         }
     }
 }

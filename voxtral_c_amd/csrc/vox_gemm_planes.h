@@ -290,6 +290,44 @@ __global__ __launch_bounds__(256) void k_rmsnorm_planes(uint16_t *planes, size_t
     }
 }
 
+// Split-K reduce + epilogue (k_splitk_reduce: partials in split order, bias, residual) of a launch whose output is the residual stream, and the
+// RMSNorm that follows it (k_rmsnorm_planes) in ONE pass over the row: block = row (round 6: two ~5 us launches less per layer of a large chunk).
+__global__ __launch_bounds__(256) void k_splitk_reduce_norm_planes(const GemmArgs a, uint16_t *planes, size_t plane, const float *w, const float *ada, float eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, N = a.N;
+    const size_t total = (size_t)a.M * N;
+    float *yr = a.Y + (size_t)row * a.ldy;
+    float ss = 0.f;
+    for (int i = tid * 4; i < N; i += 1024) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < a.ksplit; z++) {
+            const float4 p = *reinterpret_cast<const float4 *>(a.partial + (size_t)z * total + (size_t)row * N + i);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        if (a.bias) { const float4 b = *reinterpret_cast<const float4 *>(a.bias + i); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (a.resid) {
+            const float4 r = *reinterpret_cast<const float4 *>(a.resid + (size_t)row * a.ldr + i);
+            v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w;
+        }
+        *reinterpret_cast<float4 *>(yr + i) = v;
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)N + eps);
+    for (int i = tid * 4; i < N; i += 1024) {
+        float4 v = *reinterpret_cast<const float4 *>(yr + i);              // (this thread's own stores)
+        const float4 g = *reinterpret_cast<const float4 *>(w + i);
+        v.x = v.x * inv * g.x; v.y = v.y * inv * g.y; v.z = v.z * inv * g.z; v.w = v.w * inv * g.w;
+        if (ada) {
+            const float4 s = *reinterpret_cast<const float4 *>(ada + i);
+            v.x *= (1.0f + s.x); v.y *= (1.0f + s.y); v.z *= (1.0f + s.z); v.w *= (1.0f + s.w);
+        }
+        planes_store4(planes + (size_t)row * N + i, plane, v);
+    }
+}
+
 // x[M][K] (f32, row stride ldx) -> planes [3][M][K]
 __global__ __launch_bounds__(256) void k_split_planes(uint16_t *planes, size_t plane, const float *x, int ldx, int M, int K) {
     const size_t total4 = (size_t)M * K / 4;

@@ -500,9 +500,13 @@ static int launch_gemm(vox_hip_engine *e, const float *X, int ldx, const uint16_
 static bool gp_wide(int tiles_wide) { return tiles_wide >= 600; }
 
 // y = sum_p Xp[p] . W^T on pre-split activations (vox_gemm_planes.h); same epilogue / split-K contract as launch_gemm.
+// nf (optional): the RMSNorm that follows this launch's output (the residual stream) - when the launch is split along K, its reduce pass
+// applies it too and writes the normalised rows as planes (k_splitk_reduce_norm_planes); *nf_done says whether that happened.
+struct NormFuse { uint16_t *planes; size_t plane; const float *w, *ada; float eps; };
 static int launch_gemm_planes(vox_hip_engine *e, const uint16_t *Xp, size_t plane, int ldxp, const uint16_t *W, float *Y, int ldy,
                               int M, int N, int K, const float *bias, const float *resid, int ldr, int act,
-                              int epi = GP_EPI_STD, const GemmArgs *extra = nullptr) {
+                              int epi = GP_EPI_STD, const GemmArgs *extra = nullptr, const NormFuse *nf = nullptr, bool *nf_done = nullptr) {
+    if (nf_done) *nf_done = false;
     GemmArgs a{nullptr, 0, W, Y, ldy, M, N, K, bias, resid, ldr, act, 1, 0, nullptr};
     a.Xp = Xp; a.xp_plane = plane; a.ldxp = ldxp;
     if (epi == GP_EPI_SWIGLU) {       // N = hidden columns, W = [w1; w3]; output = bf16 planes of the gated hidden rows
@@ -554,7 +558,12 @@ static int launch_gemm_planes(vox_hip_engine *e, const uint16_t *Xp, size_t plan
             hipLaunchKernelGGL(kern, dim3(8 * ((groups + 7) / 8) * tn), dim3(256), lds, e->stream, a);
             a.xcd_tn = 0;
         }
-        hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((size_t)M * N)), dim3(256), 0, e->stream, a);
+        if (nf && nf_done && act == ACT_NONE && N % 4 == 0 && ldy % 4 == 0 && (!resid || ldr % 4 == 0)) {
+            hipLaunchKernelGGL(k_splitk_reduce_norm_planes, dim3(M), dim3(256), 0, e->stream, a, nf->planes, nf->plane, nf->w, nf->ada, nf->eps);
+            *nf_done = true;
+        } else {
+            hipLaunchKernelGGL(k_splitk_reduce, dim3(grid1d((size_t)M * N)), dim3(256), 0, e->stream, a);
+        }
     } else {
         hipLaunchKernelGGL(kern, dim3(tn, tm), dim3(256), lds, e->stream, a);
     }
@@ -995,7 +1004,11 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
                           const uint16_t *wqkv, const float *bqkv, const uint16_t *wo, const float *bo,
                           const uint16_t *w13, const uint16_t *w2, const float *b2,
                           const float *n1, const float *n2, const float *ada,
-                          float *kring, float *vring, int ring_cap) {
+                          float *kring, float *vring, int ring_cap,
+                          const float *next_n1 = nullptr, uint16_t **xplanes = nullptr) {
+    // next_n1 / xplanes (round 6, the encoder's layer loop): *xplanes != null on entry = the planes of this layer's normalised input, left
+    // there by the previous layer's W2 reduce pass; on return *xplanes = the planes of (x, next_n1) if this layer's W2 launch could apply the
+    // next layer's attention_norm in its reduce pass, null otherwise.
     float *xn = (float *)e->sxn.p, *qkv = (float *)e->sqkv.p, *attn = (float *)e->sattn.p;
     float *gu = (float *)e->sgu.p, *h = (float *)e->sh.p, *tab = (float *)e->srope.p;
     const int N3 = c.QD + 2 * c.KVD;
@@ -1013,8 +1026,12 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
     // as 96 workgroups x 40 sequential K slices: 56 us against ~26 for split-K + reduce + RoPE)
     const bool fuse_epi = planes && e->use_epi && n >= 512 && (c.QD + c.KVD) % 2 == 0 && c.H % 64 == 0;
     // 1. attention_norm   2. merged QKV projection (+ q/v bias on the encoder, voxtral_encoder.c:542-544)
+    uint16_t *const xin = xplanes ? *xplanes : nullptr;
+    if (xplanes) *xplanes = nullptr;
+    uint16_t *const Pset0 = P, *const Pset1 = P ? P + (size_t)3 * n * std::max(std::max(c.D, c.QD), c.H) : nullptr;
     if (planes) {
-        hipLaunchKernelGGL(k_rmsnorm_planes, dim3(n), dim3(256), 0, s, P, (size_t)n * c.D, (const float *)x, c.D, n1, (const float *)nullptr, c.D, c.eps);
+        if (xin && (xin == Pset0 || xin == Pset1)) P = xin;      // (normalised by the previous layer's W2 reduce)
+        else hipLaunchKernelGGL(k_rmsnorm_planes, dim3(n), dim3(256), 0, s, P, (size_t)n * c.D, (const float *)x, c.D, n1, (const float *)nullptr, c.D, c.eps);
         if (fuse_epi) {
             GemmArgs x{}; x.rope_tab = tab; x.rope_cols = c.QD + c.KVD; x.head_dim = c.hd;
             if (launch_gemm_planes(e, P, (size_t)n * c.D, c.D, wqkv, qkv, N3, n, N3, c.D, bqkv, nullptr, 0, ACT_NONE, GP_EPI_ROPE, &x)) return -1;
@@ -1028,6 +1045,7 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
                        qkv, N3, n, c.QD + c.KVD, c.hd, tab);
     // 4. attention over [window tail in the ring] + [this chunk]
     const float scale = 1.0f / sqrtf((float)c.hd);
+    bool attn_planes = false;
     if (c.is_enc) {
         AttnArgs a{};
         a.out = attn; a.ldo = c.QD; a.q = qkv; a.ldq = N3; a.n_q = n; a.qpos0 = pos0;
@@ -1045,6 +1063,9 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
                 a.part_o = (float *)e->spart_o.p; a.part_ml = (float *)e->spart_ml.p;
             }
             a.xcd_map = 1;
+            // (round 6) one key slice: the MFMA kernel writes its output straight as the Wo launch's planes (no k_split_planes pass)
+            attn_planes = planes && ks == 1 && e->use_attn_mfma && c.hd == 64 && c.heads == c.kv_heads && !vox_disabled("enc_fuse");
+            if (attn_planes) { a.out_planes = P; a.out_plane = (size_t)n * c.QD; }
             if (e->use_attn_mfma && c.hd == 64 && c.heads == c.kv_heads)
                 hipLaunchKernelGGL(k_attn_enc_bf16, dim3(qt, c.heads, ks), dim3(256), 0, s, a);
             else
@@ -1083,14 +1104,29 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
     }
     if (planes) {
         // 5. x += attn.Wo^T (+bo)   6. ffn_norm (+ ada)   7. SwiGLU: merged W1;W3 GEMM, gate, W2 (+b2) + residual
-        hipLaunchKernelGGL(k_split_planes, dim3(grid1d((size_t)n * c.QD / 4)), dim3(256), 0, s, P, (size_t)n * c.QD, (const float *)attn, c.QD, n, c.QD);
-        if (launch_gemm_planes(e, P, (size_t)n * c.QD, c.QD, wo, x, c.D, n, c.D, c.QD, bo, x, c.D, ACT_NONE)) return -1;
-        hipLaunchKernelGGL(k_rmsnorm_planes, dim3(n), dim3(256), 0, s, P, (size_t)n * c.D, (const float *)x, c.D, n2, ada, c.D, c.eps);
+        if (!attn_planes)
+            hipLaunchKernelGGL(k_split_planes, dim3(grid1d((size_t)n * c.QD / 4)), dim3(256), 0, s, P, (size_t)n * c.QD, (const float *)attn, c.QD, n, c.QD);
+        // (round 6) a split-K Wo launch reduces, adds the residual and applies the ffn_norm in one pass; its planes go to the second plane set
+        // (the launch itself still reads the first one)
+        uint16_t *Pn = P == Pset0 ? Pset1 : Pset0;
+        const NormFuse nf{Pn, (size_t)n * c.D, n2, ada, c.eps};
+        bool normed = false;
+        if (launch_gemm_planes(e, P, (size_t)n * c.QD, c.QD, wo, x, c.D, n, c.D, c.QD, bo, x, c.D, ACT_NONE, GP_EPI_STD, nullptr,
+                               vox_disabled("enc_fuse") ? nullptr : &nf, &normed)) return -1;
+        if (normed) std::swap(P, Pn);
+        else hipLaunchKernelGGL(k_rmsnorm_planes, dim3(n), dim3(256), 0, s, P, (size_t)n * c.D, (const float *)x, c.D, n2, ada, c.D, c.eps);
         if (fuse_epi) {
-            uint16_t *P2 = P + (size_t)3 * n * std::max(std::max(c.D, c.QD), c.H);
+            uint16_t *P2 = Pn;           // (the plane set that does NOT hold the normalised rows)
             GemmArgs xa{}; xa.Yp = P2; xa.yp_plane = (size_t)n * c.H;
             if (launch_gemm_planes(e, P, (size_t)n * c.D, c.D, w13, nullptr, 0, n, c.H, c.D, nullptr, nullptr, 0, ACT_NONE, GP_EPI_SWIGLU, &xa)) return -1;
-            if (launch_gemm_planes(e, P2, (size_t)n * c.H, c.H, w2, x, c.D, n, c.D, c.H, b2, x, c.D, ACT_NONE)) return -1;
+            // (round 6) the W2 launch's reduce pass also applies the NEXT layer's attention_norm; its planes go where this layer's
+            // normalised rows were (the W1;W3 launch is done with them)
+            const NormFuse nfn{P, (size_t)n * c.D, next_n1, nullptr, c.eps};
+            bool nnormed = false;
+            const bool try_next = xplanes && next_n1 && !vox_disabled("enc_fuse");
+            if (launch_gemm_planes(e, P2, (size_t)n * c.H, c.H, w2, x, c.D, n, c.D, c.H, b2, x, c.D, ACT_NONE, GP_EPI_STD, nullptr,
+                                   try_next ? &nfn : nullptr, &nnormed)) return -1;
+            if (xplanes) *xplanes = nnormed ? P : nullptr;
             return 0;
         }
         if (launch_gemm_planes(e, P, (size_t)n * c.D, c.D, w13, gu, 2 * c.H, n, 2 * c.H, c.D, nullptr, nullptr, 0, ACT_NONE)) return -1;
@@ -1544,10 +1580,11 @@ static int encoder_rows_dev(vox_hip_engine *e, float *x, int n, float *out) {
         else if (e->enc_stack_now && enc_stack_usable(e, n)) return encoder_rows_stack(e, x, n, out);
         return encoder_rows_skinny(e, x, n, out);
     }
+    uint16_t *xplanes = nullptr;          // planes of the next layer's normalised input, when the previous layer's W2 reduce pass left them
     for (int l = 0; l < e->d.enc_layers; l++) {
         EncLayer &L = e->enc[l];
         if (run_layer_rows(e, x, n, e->enc_pos, c, L.wqkv, L.bqkv, L.wo, L.bo, L.w13, L.w2, L.b2, L.n1, L.n2,
-                           nullptr, L.kring, L.vring, e->enc_ring_cap)) return -1;
+                           nullptr, L.kring, L.vring, e->enc_ring_cap, l + 1 < e->d.enc_layers ? e->enc[l + 1].n1 : nullptr, &xplanes)) return -1;
     }
     hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, e->stream, out, c.D, x, c.D, e->enc_final_norm,
                        (const float *)nullptr, c.D, c.eps);

@@ -52,6 +52,9 @@ struct GemmArgs {
     const float *rope_tab; int rope_cols, head_dim;
     // k_gemm_planes, split-K launches: 1-D grid in XCD-aware order (xcd_tn = N tiles, xcd_tm = M tiles; 0 = plain 3-D grid)
     int xcd_tn, xcd_tm;
+    // GP_EPI_ROPE, optional (round 6): rows >= ring_row0 of the k / v columns (column >= ring_col0: k, >= ring_col0 + ring_kvd: v) ALSO go to
+    // their slots of the position-indexed K / V rings - row r to slot (ring_pos0 + r - ring_row0) % ring_cap - instead of a k_ring_append pass
+    float *kring, *vring; int ring_cap, ring_kvd, ring_col0, ring_row0, ring_pos0;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {

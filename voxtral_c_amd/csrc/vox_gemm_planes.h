@@ -241,7 +241,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(const GemmArgs a) {
                         const float2 cs = *reinterpret_cast<const float2 *>(a.rope_tab + ((size_t)row * half + pd) * 2);
                         v = (col & 1) ? other * cs.y + v * cs.x : v * cs.x - other * cs.y;
                     }
-                    if (row < M && col < N) a.Y[(size_t)row * a.ldy + col] = v;
+                    if (row < M && col < N) {
+                        a.Y[(size_t)row * a.ldy + col] = v;
+                        if (a.kring && col >= a.ring_col0 && row >= a.ring_row0) {
+                            const int kc = col - a.ring_col0;
+                            const int slot = (a.ring_pos0 + row - a.ring_row0) % a.ring_cap;
+                            if (kc < a.ring_kvd) a.kring[(size_t)slot * a.ring_kvd + kc] = v;
+                            else a.vring[(size_t)slot * a.ring_kvd + kc - a.ring_kvd] = v;
+                        }
+                    }
                 }
             }
     } else {

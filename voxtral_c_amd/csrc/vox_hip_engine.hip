@@ -522,6 +522,8 @@ static int launch_gemm_planes(vox_hip_engine *e, const uint16_t *Xp, size_t plan
     }
     if (epi == GP_EPI_ROPE) {
         a.rope_tab = extra->rope_tab; a.rope_cols = extra->rope_cols; a.head_dim = extra->head_dim;
+        a.kring = extra->kring; a.vring = extra->vring; a.ring_cap = extra->ring_cap; a.ring_kvd = extra->ring_kvd;
+        a.ring_col0 = extra->ring_col0; a.ring_row0 = extra->ring_row0; a.ring_pos0 = extra->ring_pos0;
         const int tm_ = (M + GB_M - 1) / GB_M;
         if (gp_wide(tm_ * ((N + 255) / 256))) {
             hipLaunchKernelGGL((k_gemm_planes<2, 4, GP_EPI_ROPE>), dim3((N + 255) / 256, tm_), dim3(256), (size_t)2 * gp_stage_bytes(4), e->stream, a);
@@ -1024,6 +1026,7 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
     }
     // (only for chunks that fill the chip with tiles: the epilogue variants have no split-K, and a 68-row pass ran its QKV launch
     // as 96 workgroups x 40 sequential K slices: 56 us against ~26 for split-K + reduce + RoPE)
+    bool ring_in_epi = false;
     const bool fuse_epi = planes && e->use_epi && n >= 512 && (c.QD + c.KVD) % 2 == 0 && c.H % 64 == 0;
     // 1. attention_norm   2. merged QKV projection (+ q/v bias on the encoder, voxtral_encoder.c:542-544)
     uint16_t *const xin = xplanes ? *xplanes : nullptr;
@@ -1034,6 +1037,13 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
         else hipLaunchKernelGGL(k_rmsnorm_planes, dim3(n), dim3(256), 0, s, P, (size_t)n * c.D, (const float *)x, c.D, n1, (const float *)nullptr, c.D, c.eps);
         if (fuse_epi) {
             GemmArgs x{}; x.rope_tab = tab; x.rope_cols = c.QD + c.KVD; x.head_dim = c.hd;
+            // (round 6) the epilogue also files the rows the next chunk will need in the K / V rings - where that cannot overwrite a row THIS
+            // chunk's attention still reads from the ring: no older position in the window (pos0 == 0), or room for both
+            ring_in_epi = c.is_enc && (pos0 == 0 || n <= ring_cap - c.window) && !vox_disabled("enc_fuse");
+            if (ring_in_epi) {
+                const int keep = std::min(n, c.window);
+                x.kring = kring; x.vring = vring; x.ring_cap = ring_cap; x.ring_kvd = c.KVD; x.ring_col0 = c.QD; x.ring_row0 = n - keep; x.ring_pos0 = pos0 + n - keep;
+            }
             if (launch_gemm_planes(e, P, (size_t)n * c.D, c.D, wqkv, qkv, N3, n, N3, c.D, bqkv, nullptr, 0, ACT_NONE, GP_EPI_ROPE, &x)) return -1;
         } else if (launch_gemm_planes(e, P, (size_t)n * c.D, c.D, wqkv, qkv, N3, n, N3, c.D, bqkv, nullptr, 0, ACT_NONE)) return -1;
     } else {
@@ -1076,8 +1086,9 @@ static int run_layer_rows(vox_hip_engine *e, float *x, int n, int pos0, const Ro
         }
         // keep the last min(n, window) rows for the next chunk
         const int keep = std::min(n, c.window);
-        hipLaunchKernelGGL(k_ring_append, dim3(grid1d((size_t)keep * c.KVD / 4)), dim3(256), 0, s,
-                           kring, vring, ring_cap, c.KVD, qkv, N3, c.QD, c.QD + c.KVD, n - keep, keep, pos0 + n - keep);
+        if (!ring_in_epi)
+            hipLaunchKernelGGL(k_ring_append, dim3(grid1d((size_t)keep * c.KVD / 4)), dim3(256), 0, s,
+                               kring, vring, ring_cap, c.KVD, qkv, N3, c.QD, c.QD + c.KVD, n - keep, keep, pos0 + n - keep);
     } else {
         hipLaunchKernelGGL(k_ring_append, dim3(grid1d((size_t)n * c.KVD / 4)), dim3(256), 0, s,
                            kring, vring, ring_cap, c.KVD, qkv, N3, c.QD, c.QD + c.KVD, 0, n, pos0);

@@ -1316,6 +1316,31 @@ def test_fp8_mfma_rowsgemm_counts_activations_beyond_the_e4m3_range(vox, tiny):
     assert h.vox_hip_fp8_prefill_stats(tiny.engine, C.byref(fb), C.byref(cl)) == 0 and cl.value == 0
 
 
+def test_large_chunk_encoder_fusions_are_bit_identical(vox):
+    """Round 6: a large chunk's layer folds four small launches into their producers - the attention kernel writes the Wo launch's
+    planes, the split-K reduce passes of Wo / W2 apply the following RMSNorm (k_splitk_reduce_norm_planes), the q;k;v epilogue files
+    the ring rows (voxtral_encoder.c:452-636; the same arithmetic in the same order).  Against the old launch sequence
+    (VOX_HIP_DISABLE=enc_fuse, read per call) on the same engine: identical bits, for a cold first chunk (ring rows from the epilogue),
+    a second large chunk behind it (k_ring_append: the window still needs the slots), and the small chunks that then read the rings."""
+    with vox.Model(model_dir("small")) as m:
+        d = m.dims
+        for sizes in ([800, 25, 68], [600], [1664, 30], [520, 520, 25]):
+            outs = []
+            for off in (False, True):
+                if off:
+                    os.environ["VOX_HIP_DISABLE"] = "enc_fuse"
+                try:
+                    m.reset_encoder(); m.reset_counters()
+                    rr = np.random.default_rng(11 + sum(sizes))
+                    outs.append([m.encoder_forward_incremental(rr.standard_normal((n, d.enc_dim)).astype(np.float32)) for n in sizes])
+                finally:
+                    if off:
+                        del os.environ["VOX_HIP_DISABLE"]
+            for n, a, b in zip(sizes, outs[0], outs[1]):
+                assert np.isfinite(a).all()
+                assert np.array_equal(a, b), (sizes, n, float(np.abs(a - b).max()))
+
+
 def test_few_rows_paths_agree_with_the_large_m_paths(vox):
     """The same encoder chunks (1 .. 128 rows, after a big first chunk and on a cold window) and the same decoder prefills
     (1 .. 128 rows, then three greedy steps) on two engines of one process: one with the k_rowsgemm path switched off
